@@ -1,0 +1,75 @@
+"""Pins the CPU restatement (oracle/mp_oracle.py) against golden vectors produced by the
+reference's OWN modules (tests/golden/make_golden.py, run in the authoring container)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import mp_oracle as O
+from oracle.fixtures import unpack_adj, unpack_specs
+
+LAYER_CASES = ["ggnn_layer_sum", "ggnn_layer_mean", "ggnn_layer_max", "ggnn_layer_min",
+               "mlp_layer_sum_target", "mlp_layer_max_target", "mlp_layer_mean_notarget",
+               "mlp_layer_sum_hidden1", "mlp_layer_max_noln_nodense"]
+TOL = 2e-6  # explicit-formula LayerNorm/GRU vs torch's fused CPU kernels
+
+
+@pytest.mark.parametrize("name", LAYER_CASES)
+def test_single_layer_matches_reference(name):
+    g = load_golden(name)
+    adj, (spec,) = unpack_adj(g), unpack_specs(g)
+    x = torch.from_numpy(g["x"])
+    y = O.run_layer_stack(x, adj, [spec])
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=TOL)
+    # fp64 evaluation of the same spec: error attribution, budget is 1e-5
+    y64 = O.run_layer_stack(x.double(), adj, [O.cast_spec(spec, torch.float64)])
+    assert np.abs(y64.numpy() - g["y"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("name,bwd,selfe", [("gnn_stack_ggnn_typilus", True, True),
+                                            ("gnn_stack_mlp_varmisuse", True, True)])
+def test_container_matches_reference(name, bwd, selfe):
+    g = load_golden(name)
+    adj, specs = unpack_adj(g), unpack_specs(g)
+    x = torch.from_numpy(g["x"])
+    n_types_before = len(adj)
+    y, num_edges = O.gnn_forward(x, adj, specs, bwd, selfe)
+    assert len(adj) == n_types_before, "oracle must not mutate the caller's list"
+    assert num_edges == int(g["num_edges"])           # graphneuralnetwork.py:198
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=1e-5)
+
+
+def test_augmentation_order():
+    a = [(torch.tensor([0, 1]), torch.tensor([1, 2])), (torch.tensor([2]), torch.tensor([0]))]
+    aug = O.augment_adjacency(a, 3, True, True)
+    assert len(aug) == 5
+    assert aug[2][0].tolist() == [1, 2] and aug[2][1].tolist() == [0, 1]   # reversed type 0
+    assert aug[3][0].tolist() == [0] and aug[3][1].tolist() == [2]         # reversed type 1
+    assert aug[4][0].tolist() == [0, 1, 2] == aug[4][1].tolist()           # self edges last
+
+
+def test_batcher_bit_exact():
+    g = load_golden("batcher")
+    T0 = len(g["edge_type_order"])
+    graphs = []
+    for gi in range(int(g["num_graphs_in"])):
+        refs = {k.split(".")[-1]: g[k] for k in g.files if k.startswith(f"g{gi}.ref.")}
+        graphs.append({"num_nodes": int(g[f"g{gi}.num_nodes"]),
+                       "adjacency_lists": [(g[f"g{gi}.adj.{t}.src"], g[f"g{gi}.adj.{t}.dst"])
+                                           for t in range(T0)],
+                       "reference_nodes": refs})
+    mbs = list(O.batch_graphs(graphs, T0, int(g["stop_after"])))
+    assert len(mbs) == int(g["num_minibatches"])
+    for bi, mb in enumerate(mbs):
+        assert mb["num_graphs"] == int(g[f"mb{bi}.num_graphs"])
+        assert mb["node_to_graph_idx"].dtype == torch.int64
+        np.testing.assert_array_equal(mb["node_to_graph_idx"].numpy(), g[f"mb{bi}.node_to_graph_idx"])
+        for t in range(T0):
+            s, d = mb["adjacency_lists"][t]
+            assert s.dtype == torch.int64 and d.dtype == torch.int64
+            np.testing.assert_array_equal(s.numpy(), g[f"mb{bi}.adj.{t}.src"])
+            np.testing.assert_array_equal(d.numpy(), g[f"mb{bi}.adj.{t}.dst"])
+        for k in mb["reference_node_ids"]:
+            np.testing.assert_array_equal(mb["reference_node_ids"][k].numpy(), g[f"mb{bi}.ref_ids.{k}"])
+            np.testing.assert_array_equal(mb["reference_node_graph_idx"][k].numpy(),
+                                          g[f"mb{bi}.ref_gidx.{k}"])
