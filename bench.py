@@ -1,0 +1,268 @@
+#!/usr/bin/env python
+"""bench.py -- edges/s per message-passing layer on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one minibatch whose inputs are already resident in
+HBM: build the graph plan (dst-sorted CSR) for that minibatch + every message-passing layer of the
+workload.  Nothing is cached across steps (the plan cache is cleared each step).
+
+Primary workload (N=1): BASELINE.json configs[1] -- synthetic random graph, 200k nodes / 1.1M
+edges, one MLP-MP layer, hidden 128, sum aggregation, fp32.  The Graph2Class-style batch
+(configs[2], 8 GGNN layers, T=17) is measured in the same run and reported under "graph2class".
+For N>1 the graph is sharded by destination-node range (weak scaling: every rank owns 200k
+nodes and their 1.1M in-edges, sources uniform over all N*200k nodes) with one RCCL all-to-all of
+de-duplicated halo rows per layer.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true")
+    return p.parse_args()
+
+
+def dist_setup(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    return rank, world, torch.device("cuda", local if world > 1 else 0)
+
+
+def barrier_sync(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds, world, dev):
+    if world == 1:
+        return seconds
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def make_cfg2(dev, rank, world):
+    """configs[1]; for world > 1 every rank owns its own 200k-node destination range."""
+    from ptgnn_amd import layers as L, workloads
+    N, E, H = 200_000, 1_100_000, 128
+    torch.manual_seed(1234)
+    layer = L.MlpMessagePassingLayer(H, H, H, 1, "sum").to(dev).eval()
+    if world == 1:
+        adj = workloads.random_graph(N, E)
+        x = workloads.node_states(N, H)
+        state = {"adj": [(s.to(dev), d.to(dev)) for s, d in adj], "x": x.to(dev), "cpu_adj": adj, "cpu_x": x}
+    else:
+        from ptgnn_amd import sharded
+        state = sharded.make_weak_scaling_shard(N, E, H, rank, world, dev, seed=1234)
+    state.update(layer=layer, N=N, E=E, H=H, layers_per_step=1,
+                 desc="cfg2: synthetic random graph N=200k E=1.1M, 1 MLP-MP layer H=M=128, T=1, sum")
+    return state
+
+
+def step_cfg2(st, world):
+    from ptgnn_amd import ops
+    ops.clear_plan_cache()
+    with torch.no_grad():
+        if world == 1:
+            adj = st["adj"]
+            feats = [None]
+            return st["layer"](st["x"], adj, None, {}, {}, feats)
+        from ptgnn_amd import sharded
+        return sharded.layer_forward(st["layer"], st)
+
+
+def make_cfg3(dev):
+    from ptgnn_amd import layers as L, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    H = 128
+    mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234)
+    T = 17
+    torch.manual_seed(1234)
+    ggnn = L.GatedMessagePassingLayer(H, H, T, "max")
+    r1 = L.ConcatResidualLayer(H)
+    last = L.GatedMessagePassingLayer(2 * H, H, T, "max")
+    mods = [r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last]
+    net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).to(dev).eval()
+    N = mb["num_nodes"]
+    E_raw = sum(int(a[0].shape[0]) for a in mb["adjacency_lists"])
+    return {"net": net, "x": workloads.node_states(N, H, seed=5).to(dev),
+            "adj": [(s.to(dev), d.to(dev)) for s, d in mb["adjacency_lists"]],
+            "n2g": mb["node_to_graph_idx"].to(dev),
+            "refs": {k: v.to(dev) for k, v in mb["reference_node_ids"].items()},
+            "refg": {k: v.to(dev) for k, v in mb["reference_node_graph_idx"].items()},
+            "G": mb["num_graphs"], "N": N, "E": 2 * E_raw + N, "H": H, "layers_per_step": 8,
+            "desc": f"cfg3: Graph2Class-style batch, 48 graphs N={N}, T0=8->T=17, E={2 * E_raw + N} "
+                    "(incl. reverse+self), Typilus GGNN arch: 8 GGNN layers H=128 (+concat residual), max"}
+
+
+def step_cfg3(st):
+    from ptgnn_amd import ops
+    ops.clear_plan_cache()
+    with torch.no_grad():
+        return st["net"](node_data={"input": st["x"]}, adjacency_lists=st["adj"], edge_feature_data=[],
+                         node_to_graph_idx=st["n2g"], reference_node_ids=st["refs"],
+                         reference_node_graph_idx=st["refg"], num_graphs=st["G"])
+
+
+# ------------------------------------------------------------------------------------------------
+def timed_region(step_fn, steps, warmup, world, dev):
+    from ptgnn_amd import ops
+    for _ in range(warmup):
+        step_fn()
+    timer = ops.KernelTimer()
+    barrier_sync(world)
+    ops.set_kernel_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    barrier_sync(world)
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    return max_over_ranks(dt, world, dev), timer.summary()
+
+
+def kernel_table(summary):
+    table = {}
+    for name, d in summary.items():
+        ms = d["ms"] / d["calls"]
+        row = {"calls": d["calls"], "avg_ms": round(ms, 5)}
+        if name in ("linear", "gru_cell"):
+            tf = d["flops"] / d["calls"] / (ms * 1e-3) / 1e12
+            row.update(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                       frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
+        else:
+            gbs = d["bytes"] / d["calls"] / (ms * 1e-3) / 1e9
+            row.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                       frac=round(gbs / HBM_PEAK_GBS, 4))
+        row["total_ms"] = round(d["ms"], 4)
+        table[name] = row
+    return table
+
+
+def cpu_baseline_cfg2(st):
+    """The CPU restatement of the reference path (oracle = 'port') on this box's host cores, on the
+    SAME config-2 inputs: 1 warm-up + 3 timed forwards of the MLP-MP layer."""
+    from oracle import mp_oracle as O
+    spec = st["layer"].export_weights()
+    x, adj = st["cpu_x"], st["cpu_adj"]
+    feats = [torch.empty(st["E"], 0)]
+    with torch.no_grad():
+        O.mlp_mp_layer(x, adj, feats, spec)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.mlp_mp_layer(x, adj, feats, spec)
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[1]
+    return {"value": round(st["E"] / med, 1), "unit": "edges/s", "cores": torch.get_num_threads(),
+            "kind": "port", "host_cpus": os.cpu_count(),
+            "sample": f"cfg2 full size (N=200k, E=1.1M), 1 MLP-MP layer forward, median of 3 = {med:.3f}s, "
+                      "torch-CPU fp32 restatement of the reference layer (oracle/mp_oracle.py)"}
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    rank, world, dev = dist_setup(args)
+    from ptgnn_amd import _lib
+    _lib.load()
+
+    if args.workload == "cfg2":
+        st = make_cfg2(dev, rank, world)
+        step = lambda: step_cfg2(st, world)  # noqa: E731
+    else:
+        if world > 1:
+            raise SystemExit("cfg3 is a single-GPU workload (whole graphs; shard by graph = replicas)")
+        st = make_cfg3(dev)
+        step = lambda: step_cfg3(st)  # noqa: E731
+
+    seconds, summary = timed_region(step, args.steps, args.warmup, world, dev)
+    ms_per_step = seconds / args.steps * 1e3
+    layers = st["layers_per_step"]
+    edges_all_ranks = st["E"] * world
+    value = edges_all_ranks / (seconds / args.steps / layers)
+    ktab = kernel_table(summary)
+    dominant = max(ktab, key=lambda k: ktab[k]["total_ms"])
+    roof = {k: ktab[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+    roof.update(kernel=dominant, avg_ms=ktab[dominant]["avg_ms"], traffic=None)
+
+    result = {
+        "metric": "edges/sec per MP layer", "value": round(value, 1), "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": st["desc"], "nodes_per_gpu": st["N"], "edges_per_gpu": st["E"],
+                   "hidden": st["H"], "mp_layers_per_step": layers, "mode": "forward (inference), fp32",
+                   "plan_build_in_step": True,
+                   "parallelism": "single GPU" if world == 1 else f"dst-range shard x{world} + halo all-to-all"},
+        "nodes_per_sec_per_layer": round(st["N"] * world / (seconds / args.steps / layers), 1),
+        "edges_per_sec_readme_convention": round(edges_all_ranks / (seconds / args.steps), 1),
+        "roofline": roof, "kernels": ktab,
+    }
+
+    if rank == 0 and world == 1:
+        if args.workload == "cfg2" and not args.no_secondary:
+            st3 = make_cfg3(dev)
+            sec3, sum3 = timed_region(lambda: step_cfg3(st3), max(5, args.steps // 2), 2, 1, dev)
+            k3 = max(5, args.steps // 2)
+            result["graph2class"] = {
+                "workload": st3["desc"], "ms_per_forward": round(sec3 / k3 * 1e3, 4),
+                "edges_per_sec_per_layer": round(st3["E"] / (sec3 / k3 / 8), 1),
+                "nodes_per_sec_per_layer": round(st3["N"] / (sec3 / k3 / 8), 1),
+                "edges_per_sec_readme_convention": round(st3["E"] / (sec3 / k3), 1),
+                "vs_readme_v100_inference_2527k": round(st3["E"] / (sec3 / k3) / 2.527e6, 2),
+                "kernels": kernel_table(sum3)}
+            del st3
+        if args.workload == "cfg2" and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_cfg2(st)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+/*
+ * ptgnn_amd -- MI355X (gfx950 / CDNA4) message-passing core for microsoft/ptgnn.
+ *
+ * C ABI of libptgnn_amd.so.  The reference (100 % Python) has no FFI of its own for this path;
+ * its device work is delegated to `torch` and the third-party `torch_scatter` wheel.  Each entry
+ * point below names the reference call site(s) (paths relative to the ptgnn checkout) whose
+ * device work it replaces.  INTEGRATION.md shows the ctypes binding a ptgnn maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is documented "host";
+ *   - the library never allocates, frees or retains user-visible memory: outputs and
+ *     workspaces are caller-owned (in the Python host they are torch tensors, so the caching
+ *     allocator, streams and graph capture keep working);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); no entry point
+ *     synchronises the host;
+ *   - return value: 0 = ok, <0 = PTGNN_AMD_E*; ptgnn_amd_last_error() returns a thread-local
+ *     message for the last failure on the calling thread;
+ *   - fp32 row-major matrices; a leading dimension `ld*` is counted in floats;
+ *   - kernels are stateless and re-entrant; the only global state is an immutable per-process
+ *     device-property cache.
+ */
+#ifndef PTGNN_AMD_H_
+#define PTGNN_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTGNN_AMD_VERSION 100 /* 0.1.0 */
+
+enum {
+  PTGNN_AMD_OK = 0,
+  PTGNN_AMD_EINVAL = -1,       /* bad argument (null pointer, negative size, bad enum)         */
+  PTGNN_AMD_EUNSUPPORTED = -2, /* shape outside what the kernels were built for                 */
+  PTGNN_AMD_EHIP = -3,         /* a HIP runtime call or launch failed                           */
+  PTGNN_AMD_EWORKSPACE = -4,   /* workspace too small                                           */
+  PTGNN_AMD_ERANGE = -5        /* an index was out of [0, num_nodes) (only from *_validate)     */
+};
+
+/* reduce: the `aggregation_fn` strings accepted by AbstractMessagePassingLayer._aggregate_messages
+ * (ptgnn/neuralmodels/gnn/messagepassing/abstractmessagepassing.py:38-50 -> torch_scatter.scatter):
+ * "sum"/"add" = 0, "mean" = 1, "max" = 2, "min" = 3.  Empty segments yield 0 for every mode. */
+enum { PTGNN_AMD_SUM = 0, PTGNN_AMD_MEAN = 1, PTGNN_AMD_MAX = 2, PTGNN_AMD_MIN = 3 };
+
+/* Row epilogue fused into the aggregation kernel (MlpMessagePassingLayer,
+ * mlpmessagepassing.py:114-117 + :56-58): message activation GELU (exact erf) and LayerNorm. */
+enum { PTGNN_AMD_EPI_NONE = 0, PTGNN_AMD_EPI_GELU = 1, PTGNN_AMD_EPI_LAYERNORM = 2,
+       PTGNN_AMD_EPI_GELU_LAYERNORM = 3 };
+
+/* activation fused into ptgnn_amd_linear_f32 */
+enum { PTGNN_AMD_ACT_NONE = 0, PTGNN_AMD_ACT_TANH = 1, PTGNN_AMD_ACT_RELU = 2 };
+
+int ptgnn_amd_version(void);
+const char *ptgnn_amd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph plan: merge the per-edge-type adjacency lists of one minibatch into ONE
+ * destination-sorted CSR that all L message-passing layers of a forward reuse.
+ *
+ * Replaces: `torch.cat([adj[1] ...])` + the per-type Python loop + the unsorted scatter index
+ *   (gatedmessagepassing.py:46,50-64; mlpmessagepassing.py:81-112) -- the adjacency is the same
+ *   for every layer (graphneuralnetwork.py:122-131), so the sort is paid once per batch.
+ *
+ * Input : num_types pairs of int64 device arrays (exactly the tensors ptgnn's
+ *         GraphNeuralNetworkModel.finalize_minibatch produces, graphneuralnetwork.py:461-467),
+ *         given as HOST arrays of device pointers + HOST array of lengths.
+ * Output: rowptr[num_nodes+1]; for CSR slot i (in-edges of node v occupy
+ *         rowptr[v]..rowptr[v+1], in the reference's message order = type-major, then edge
+ *         order, i.e. the sort is STABLE so fp32 sums fold in the same order as the CPU path):
+ *           col[i]  = (src << type_bits) | edge_type     (type_bits = ceil(log2(num_types)))
+ *           perm[i] = position of the edge in the type-major concatenation (nullable)
+ * Requires num_nodes << type_bits < 2^31 and num_edges < 2^31, else EUNSUPPORTED.
+ * ---------------------------------------------------------------------------------------- */
+size_t ptgnn_amd_csr_workspace_bytes(int64_t num_edges, int64_t num_nodes);
+int ptgnn_amd_type_bits(int32_t num_types);
+int ptgnn_amd_csr_build(const int64_t *const *src_per_type, /* host [num_types] of device ptrs */
+                        const int64_t *const *dst_per_type, /* host [num_types] of device ptrs */
+                        const int64_t *edges_per_type,      /* host [num_types]                */
+                        int32_t num_types, int64_t num_nodes,
+                        int swap_src_dst, /* 1: build the transposed plan (rows = sources)     */
+                        int32_t *rowptr, int32_t *col, int32_t *perm /* nullable */,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* Optional debug aid (the reference performs no range check either): counts indices outside
+ * [0, num_nodes) into *bad_count (device int32, caller zeroes it). */
+int ptgnn_amd_validate_indices(const int64_t *idx, int64_t n, int64_t num_nodes,
+                               int32_t *bad_count, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused gather -> (+ destination term) -> segment reduce -> (row epilogue).
+ *
+ *   out[v, :] = EPI( REDUCE_{i in rowptr[v]..rowptr[v+1]}  Ysrc[src_i, t_i*M : (t_i+1)*M]
+ *                                                         (+ Ydst[v,   t_i*M : (t_i+1)*M]) )
+ *   with (src_i, t_i) unpacked from col[i].
+ *
+ * Replaces, for one layer: F.embedding gathers, torch.cat, the per-type Linear outputs being
+ *   materialised as [E, M], torch.cat of messages/targets and torch_scatter.scatter
+ *   (gatedmessagepassing.py:54-68; mlpmessagepassing.py:88-112; abstractmessagepassing.py:44-50),
+ *   using  Linear_t(x_src) == (X W_t^T)[src]  (bias-free Linear commutes with the row gather),
+ *   and for MLP-MP with target state  W_t [x_u ; x_v] = W_t^s x_u + W_t^d x_v.
+ *
+ *   ysrc : [num_src_rows, ld_y] ; block t of M columns holds X W_t^T.  With type_bits == 0 and
+ *          ld_y == M this is also the plain segment reduce of a materialised message matrix
+ *          (col = perm), i.e. the torch_scatter seam itself.
+ *   ydst : nullable, same layout, indexed by the DESTINATION node.
+ *   argout: nullable int32 [num_nodes, M]; for max/min the winning CSR slot, -1 if empty
+ *          (backward routing; torch_scatter's arg_out).
+ *   ln_gamma/ln_beta: LayerNorm affine parameters (EPI_*LAYERNORM only).
+ * ---------------------------------------------------------------------------------------- */
+int ptgnn_amd_gather_reduce_f32(const float *ysrc, const float *ydst /* nullable */,
+                                int64_t ld_y, const int32_t *rowptr, const int32_t *col,
+                                int32_t type_bits, int64_t num_nodes, int32_t msg_dim,
+                                int reduce, int epilogue, const float *ln_gamma,
+                                const float *ln_beta, float ln_eps, float *out, int64_t ld_out,
+                                int32_t *argout /* nullable */, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * y = act(x W^T + b) on the matrix cores with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces nn.Linear at gatedmessagepassing.py:20-23,57-61 (all T edge-type weights stacked
+ * into one [T*M, H] matrix => ONE wide GEMM instead of T ragged ones), mlp.py:54-75,
+ * mlpmessagepassing.py:60-63 (Linear + Tanh), residuallayers.py:112-116.
+ *   x [rows, k] (ld_x), w [n_out, k] row-major contiguous (nn.Linear layout), bias nullable.
+ * ---------------------------------------------------------------------------------------- */
+int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int64_t ld_x, const float *w,
+                         int32_t n_out, const float *bias, int act, float *y, int64_t ld_y,
+                         void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * h' = GRUCell(a, h)  (gate order r, z, n), gatedmessagepassing.py:25,69.
+ *   a [n, m], h [n, hd], w_ih [3hd, m], w_hh [3hd, hd], b_ih/b_hh [3hd], out [n, hd].
+ *   Gate GEMMs run on fp32 MFMA with the gate non-linearities fused in the epilogue; no
+ *   [n, 3hd] intermediates reach HBM.
+ * ---------------------------------------------------------------------------------------- */
+int ptgnn_amd_gru_cell_f32(const float *a, int64_t ld_a, const float *h, int64_t ld_h,
+                           const float *w_ih, const float *w_hh, const float *b_ih,
+                           const float *b_hh, int64_t n, int32_t m, int32_t hd, float *out,
+                           int64_t ld_out, void *stream);
+
+/* Row gather out[i, :] = x[idx[i], :] (F.embedding at gatedmessagepassing.py:54-56,
+ * mlpmessagepassing.py:88,91) for the general per-edge path (edge features / training dropout /
+ * mlp_hidden_layers > 0) and for task heads (output_node_representations[node_idx_references]). */
+int ptgnn_amd_gather_rows_f32(const float *x, int64_t ld_x, const int64_t *idx, int64_t n_idx,
+                              int32_t dim, float *out, int64_t ld_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGNN_AMD_H_ */

@@ -1,0 +1,65 @@
+"""ctypes binding of libptgnn_amd.so (the C ABI declared in include/ptgnn_amd.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or an entry point fails,
+callers get a RuntimeError (never a silent eager/PyTorch substitute)."""
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  (must be imported first: the library binds to torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libptgnn_amd.so")
+
+_c = ctypes
+_i64, _i32, _vp, _f32 = _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_float
+
+# name -> (restype, argtypes); mirrors include/ptgnn_amd.h one to one
+SIGNATURES = {
+    "ptgnn_amd_version": (_c.c_int, []),
+    "ptgnn_amd_last_error": (_c.c_char_p, []),
+    "ptgnn_amd_csr_workspace_bytes": (_c.c_size_t, [_i64, _i64]),
+    "ptgnn_amd_type_bits": (_c.c_int, [_i32]),
+    "ptgnn_amd_csr_build": (_c.c_int, [_vp, _vp, _vp, _i32, _i64, _c.c_int, _vp, _vp, _vp, _vp,
+                                       _c.c_size_t, _vp]),
+    "ptgnn_amd_validate_indices": (_c.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "ptgnn_amd_gather_reduce_f32": (_c.c_int, [_vp, _vp, _i64, _vp, _vp, _i32, _i64, _i32, _c.c_int,
+                                               _c.c_int, _vp, _vp, _f32, _vp, _i64, _vp, _vp]),
+    "ptgnn_amd_linear_f32": (_c.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _c.c_int, _vp, _i64,
+                                        _vp]),
+    "ptgnn_amd_gru_cell_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
+                                          _vp, _i64, _vp]),
+    "ptgnn_amd_gather_rows_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class PtgnnAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise PtgnnAmdError(
+                    f"{LIB_PATH} is missing: build it with `python -m ptgnn_amd.build` "
+                    "(ptgnn_amd has no CPU/eager fallback by design)")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if the .so is stale
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().ptgnn_amd_last_error()
+        raise PtgnnAmdError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

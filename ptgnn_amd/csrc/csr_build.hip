@@ -1,0 +1,216 @@
+// Graph plan construction: per-edge-type int64 adjacency lists -> one destination-sorted CSR.
+// See include/ptgnn_amd.h (ptgnn_amd_csr_build) for the contract and the reference lines replaced.
+//
+// Pipeline (all on `stream`, no host sync):
+//   1. k_pack   : walk the T lists (pointer table in the kernel argument segment), narrow to
+//                 int32, emit key = row (dst), payload = packed (src << type_bits | type) and the
+//                 edge position in the type-major concatenation.
+//   2. stable LSD radix sort of (key, position) over ceil(log2(N)) bits (rocPRIM device sort).
+//   3. k_finish : payload gather into CSR order + rowptr from key boundaries.
+// HBM-bound integer work: 8 B/edge read once, O(passes * 8 B/edge) inside the sort.
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace ptgnn_amd {
+namespace {
+
+constexpr int kMaxTypes = 64;
+
+struct TypeTable {
+  const int64_t *src[kMaxTypes];
+  const int64_t *dst[kMaxTypes];
+  int64_t offset[kMaxTypes + 1];  // exclusive prefix of edges_per_type
+  int32_t num_types;
+  int32_t type_base;  // global type id of entry 0 (for > kMaxTypes chunking)
+};
+
+__global__ __launch_bounds__(256) void k_pack(TypeTable tab, int32_t type_bits, int swap,
+                                              uint32_t *__restrict__ keys,
+                                              int32_t *__restrict__ pos,
+                                              int32_t *__restrict__ packed, int64_t pos_base) {
+  const int64_t total = tab.offset[tab.num_types];
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    // binary search for the type (<= 6 steps; table lives in SGPR/scalar cache)
+    int lo = 0, hi = tab.num_types;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tab.offset[mid] <= e) lo = mid; else hi = mid;
+    }
+    const int64_t i = e - tab.offset[lo];
+    int64_t s = tab.src[lo][i], d = tab.dst[lo][i];
+    if (swap) { const int64_t t = s; s = d; d = t; }
+    const int64_t g = pos_base + e;
+    keys[g] = (uint32_t)d;
+    pos[g] = (int32_t)g;
+    packed[g] = (int32_t)((s << type_bits) | (int64_t)(tab.type_base + lo));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_finish(const uint32_t *__restrict__ keys_sorted,
+                                                const int32_t *__restrict__ pos_sorted,
+                                                const int32_t *__restrict__ packed,
+                                                int64_t num_edges, int64_t num_nodes,
+                                                int32_t *__restrict__ rowptr,
+                                                int32_t *__restrict__ col,
+                                                int32_t *__restrict__ perm) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (num_edges == 0) {
+    for (int64_t v = i; v <= num_nodes; v += (int64_t)gridDim.x * blockDim.x) rowptr[v] = 0;
+    return;
+  }
+  if (i >= num_edges) return;
+  const int32_t p = pos_sorted[i];
+  col[i] = packed[p];
+  if (perm) perm[i] = p;
+  const int64_t k = keys_sorted[i];
+  const int64_t kprev = (i == 0) ? -1 : (int64_t)keys_sorted[i - 1];
+  for (int64_t v = kprev + 1; v <= k; ++v) rowptr[v] = (int32_t)i;  // rows (kprev, k] start here
+  if (i == num_edges - 1)
+    for (int64_t v = k + 1; v <= num_nodes; ++v) rowptr[v] = (int32_t)num_edges;
+}
+
+__global__ __launch_bounds__(256) void k_validate(const int64_t *__restrict__ idx, int64_t n,
+                                                  int64_t num_nodes, int32_t *bad) {
+  int local = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = idx[i];
+    local += (v < 0 || v >= num_nodes);
+  }
+  if (local) atomicAdd(bad, local);
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct WsLayout {
+  size_t keys_in, keys_out, pos_in, pos_out, packed, sort_tmp, sort_tmp_bytes, total;
+};
+
+int end_bit_for(int64_t num_nodes) {
+  int b = 1;
+  while (((int64_t)1 << b) < num_nodes) ++b;
+  return b;
+}
+
+hipError_t sort_tmp_bytes(int64_t num_edges, int64_t num_nodes, size_t *bytes) {
+  *bytes = 0;
+  if (num_edges == 0) return hipSuccess;
+  return rocprim::radix_sort_pairs(nullptr, *bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                   (int32_t *)nullptr, (int32_t *)nullptr, (size_t)num_edges, 0,
+                                   end_bit_for(num_nodes), (hipStream_t)0);
+}
+
+bool layout(int64_t num_edges, int64_t num_nodes, WsLayout *L) {
+  size_t tmp = 0;
+  if (sort_tmp_bytes(num_edges, num_nodes, &tmp) != hipSuccess) return false;
+  const size_t e4 = align_up((size_t)num_edges * 4, 256);
+  size_t o = 0;
+  L->keys_in = o;  o += e4;
+  L->keys_out = o; o += e4;
+  L->pos_in = o;   o += e4;
+  L->pos_out = o;  o += e4;
+  L->packed = o;   o += e4;
+  L->sort_tmp = o; o += align_up(tmp, 256);
+  L->sort_tmp_bytes = tmp;
+  L->total = o + 256;
+  return true;
+}
+
+}  // namespace
+}  // namespace ptgnn_amd
+
+using namespace ptgnn_amd;
+
+extern "C" int ptgnn_amd_type_bits(int32_t num_types) {
+  int b = 0;
+  while ((1 << b) < num_types) ++b;
+  return b;
+}
+
+extern "C" size_t ptgnn_amd_csr_workspace_bytes(int64_t num_edges, int64_t num_nodes) {
+  if (num_edges < 0 || num_nodes < 0) return 0;
+  WsLayout L;
+  if (!layout(num_edges, num_nodes, &L)) return 0;
+  return L.total;
+}
+
+extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
+                                   const int64_t *const *dst_per_type,
+                                   const int64_t *edges_per_type, int32_t num_types,
+                                   int64_t num_nodes, int swap_src_dst, int32_t *rowptr,
+                                   int32_t *col, int32_t *perm, void *workspace,
+                                   size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTGNN_REQUIRE(num_types >= 0 && num_nodes >= 0, PTGNN_AMD_EINVAL, "csr_build: negative size");
+  PTGNN_REQUIRE(rowptr != nullptr, PTGNN_AMD_EINVAL, "csr_build: rowptr is null");
+  PTGNN_REQUIRE(num_types == 0 || (src_per_type && dst_per_type && edges_per_type),
+                PTGNN_AMD_EINVAL, "csr_build: null type tables");
+  int64_t num_edges = 0;
+  for (int t = 0; t < num_types; ++t) {
+    PTGNN_REQUIRE(edges_per_type[t] >= 0, PTGNN_AMD_EINVAL, "csr_build: negative edge count");
+    PTGNN_REQUIRE(edges_per_type[t] == 0 || (src_per_type[t] && dst_per_type[t]),
+                  PTGNN_AMD_EINVAL, "csr_build: null adjacency list for type %d", t);
+    num_edges += edges_per_type[t];
+  }
+  const int type_bits = ptgnn_amd_type_bits(num_types);
+  PTGNN_REQUIRE(num_edges < ((int64_t)1 << 31) && (num_nodes << type_bits) < ((int64_t)1 << 31),
+                PTGNN_AMD_EUNSUPPORTED,
+                "csr_build: num_edges=%lld / num_nodes=%lld x 2^%d exceed the int32 plan format",
+                (long long)num_edges, (long long)num_nodes, type_bits);
+  PTGNN_REQUIRE(num_edges == 0 || col != nullptr, PTGNN_AMD_EINVAL, "csr_build: col is null");
+  WsLayout L;
+  PTGNN_REQUIRE(layout(num_edges, num_nodes, &L), PTGNN_AMD_EHIP, "csr_build: sort size query failed");
+  PTGNN_REQUIRE(workspace_bytes >= L.total && (workspace || L.total == 0), PTGNN_AMD_EWORKSPACE,
+                "csr_build: workspace %zu < required %zu", workspace_bytes, L.total);
+  char *ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  uint32_t *keys_in = (uint32_t *)(ws + L.keys_in), *keys_out = (uint32_t *)(ws + L.keys_out);
+  int32_t *pos_in = (int32_t *)(ws + L.pos_in), *pos_out = (int32_t *)(ws + L.pos_out);
+  int32_t *packed = (int32_t *)(ws + L.packed);
+
+  if (num_edges > 0) {
+    int64_t base = 0;
+    for (int t0 = 0; t0 < num_types; t0 += kMaxTypes) {
+      TypeTable tab;
+      tab.num_types = (num_types - t0 < kMaxTypes) ? (num_types - t0) : kMaxTypes;
+      tab.type_base = t0;
+      tab.offset[0] = 0;
+      for (int t = 0; t < tab.num_types; ++t) {
+        tab.src[t] = src_per_type[t0 + t];
+        tab.dst[t] = dst_per_type[t0 + t];
+        tab.offset[t + 1] = tab.offset[t] + edges_per_type[t0 + t];
+      }
+      const int64_t chunk = tab.offset[tab.num_types];
+      if (chunk > 0) {
+        const int64_t blocks = (chunk + 255) / 256;
+        k_pack<<<(unsigned)(blocks < 4096 ? blocks : 4096), 256, 0, stream>>>(
+            tab, type_bits, swap_src_dst, keys_in, pos_in, packed, base);
+        PTGNN_LAUNCH_CHECK();
+      }
+      base += chunk;
+    }
+    size_t tmp = L.sort_tmp_bytes;
+    PTGNN_HIP(rocprim::radix_sort_pairs(ws + L.sort_tmp, tmp, keys_in, keys_out, pos_in, pos_out,
+                                        (size_t)num_edges, 0, end_bit_for(num_nodes), stream));
+  }
+  const int64_t work = num_edges > 0 ? num_edges : 1;
+  const int64_t blocks = num_edges > 0 ? (work + 255) / 256 : 64;
+  k_finish<<<(unsigned)blocks, 256, 0, stream>>>(keys_out, pos_out, packed, num_edges, num_nodes,
+                                                 rowptr, col, perm);
+  PTGNN_LAUNCH_CHECK();
+  return PTGNN_AMD_OK;
+}
+
+extern "C" int ptgnn_amd_validate_indices(const int64_t *idx, int64_t n, int64_t num_nodes,
+                                          int32_t *bad_count, void *stream_) {
+  PTGNN_REQUIRE(n >= 0 && bad_count && (n == 0 || idx), PTGNN_AMD_EINVAL, "validate: bad args");
+  if (n == 0) return PTGNN_AMD_OK;
+  const int64_t blocks = (n + 255) / 256;
+  k_validate<<<(unsigned)(blocks < 2048 ? blocks : 2048), 256, 0, (hipStream_t)stream_>>>(
+      idx, n, num_nodes, bad_count);
+  PTGNN_LAUNCH_CHECK();
+  return PTGNN_AMD_OK;
+}

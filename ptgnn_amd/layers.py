@@ -1,0 +1,463 @@
+"""Drop-in message-passing layers: same class names, constructor keywords, forward signature,
+properties and (name-mangled) parameter names as the reference's
+ptgnn/neuralmodels/gnn/messagepassing/{abstractmessagepassing,gatedmessagepassing,
+mlpmessagepassing,residuallayers}.py and ptgnn/neuralmodels/mlp.py -- so
+``GraphNeuralNetworkModel(message_passing_layer_creator=...)`` (graphneuralnetwork.py:231,298)
+accepts them unchanged and ``layer.load_state_dict(reference_layer.state_dict())`` just works.
+
+What is different is HOW a layer runs.  Inference (`torch.no_grad()` or no input requires grad,
+dropout inactive, no edge features, single-Linear edge transform) takes the fused MI355X path:
+
+    plan  = dst-sorted CSR of ALL edge types, built once per minibatch          (csr_build.hip)
+    Y     = X [W_0; ...; W_{T-1}]^T              one wide fp32-MFMA GEMM        (dense_f32.hip)
+    A     = reduce_{in-edges} Y[src, type] (+ Y_dst[v, type]) (+GELU+LayerNorm) (gather_reduce.hip)
+    X'    = GRUCell(A, X)  |  tanh(A W^T + b)    fp32-MFMA, fused epilogues     (dense_f32.hip)
+
+using  Linear_t(x_src) == (X W_t^T)[src]  (a bias-free Linear commutes with the row gather) and,
+for the MLP layer with target state,  W_t [x_u ; x_v] = W_t^s x_u + W_t^d x_v.
+
+Everything else (training with grad, per-edge dropout, edge features, deeper edge MLPs, custom
+aggregation modules) takes the general per-edge path: torch dense ops on the GPU plus the HIP
+segment-reduce seam with its autograd rule (ptgnn_amd/scatter.py).  Neither path runs on the CPU.
+"""
+from typing import Dict, List, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from ptgnn_amd import _lib, ops
+from ptgnn_amd.scatter import segment_reduce
+
+try:  # inside a ptgnn install the layers ARE ptgnn layers
+    from ptgnn.neuralmodels.gnn.messagepassing.abstractmessagepassing import (  # type: ignore
+        AbstractMessageAggregation, AbstractMessagePassingLayer)
+except Exception:  # standalone (e.g. the GPU box): identical interface
+    class AbstractMessagePassingLayer(nn.Module):
+        """Interface of abstractmessagepassing.py:8-60."""
+
+        def forward(self, node_states, adjacency_lists, node_to_graph_idx, reference_node_ids,
+                    reference_node_graph_idx, edge_features) -> torch.Tensor:
+            raise NotImplementedError
+
+        def _aggregate_messages(self, messages, message_targets, num_nodes, aggregation_fn: str):
+            from ptgnn_amd.scatter import scatter
+            msg_dtype = messages.dtype
+            return scatter(messages.to(torch.float32), index=message_targets, dim=0,
+                           dim_size=num_nodes, reduce=aggregation_fn).to(msg_dtype)
+
+        @property
+        def input_state_dimension(self) -> int:
+            raise NotImplementedError
+
+        @property
+        def output_state_dimension(self) -> int:
+            raise NotImplementedError
+
+    class AbstractMessageAggregation(nn.Module):
+        def forward(self, messages, message_targets, num_nodes):
+            raise NotImplementedError
+
+        def output_state_size(self, message_input_size: int) -> int:
+            raise NotImplementedError
+
+Adj = List[Tuple[torch.Tensor, torch.Tensor]]
+
+
+def _versions(params) -> Tuple:
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
+def _no_grad_needed(*tensors) -> bool:
+    if not torch.is_grad_enabled():
+        return True
+    return not any(t is not None and t.requires_grad for t in tensors)
+
+
+def _check_device(node_states: torch.Tensor):
+    if not node_states.is_cuda:
+        raise _lib.PtgnnAmdError(
+            "ptgnn_amd layers run on the MI355X only; node_states is on "
+            f"{node_states.device}. (Use the reference layers for a CPU run.)")
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP (ptgnn/neuralmodels/mlp.py) -- same Sequential index layout => same state_dict keys
+# ------------------------------------------------------------------------------------------------
+class MLP(nn.Module):
+    def __init__(self, input_dimension: int, output_dimension: int,
+                 hidden_layers: Union[List[int], int] = 1, use_biases: bool = False,
+                 activation: Optional[nn.Module] = nn.ReLU(), dropout_rate: float = 0.0):
+        super().__init__()
+        if isinstance(hidden_layers, int):
+            width = 32 if output_dimension == 1 else output_dimension  # mlp.py:34-43
+            sizes = [width] * hidden_layers
+        else:
+            sizes = list(hidden_layers)
+        if len(sizes) > 1:
+            assert activation is not None, "Multiple linear layers without an activation"
+        mods: List[nn.Module] = []
+        d = input_dimension
+        for h in sizes:                       # hidden block: Dropout, Linear, (activation)
+            lin = nn.Linear(d, h, bias=use_biases)
+            nn.init.xavier_uniform_(lin.weight)
+            mods += [nn.Dropout(p=dropout_rate), lin] + ([activation] if activation is not None else [])
+            d = h
+        out = nn.Linear(d, output_dimension, bias=use_biases)   # output block: Dropout, Linear
+        nn.init.xavier_uniform_(out.weight)
+        mods += [nn.Dropout(p=dropout_rate), out]
+        self.__mlp_modules = nn.Sequential(*mods)
+
+    @property
+    def linears(self) -> List[nn.Linear]:
+        return [m for m in self.__mlp_modules if isinstance(m, nn.Linear)]
+
+    @property
+    def is_single_linear(self) -> bool:
+        ls = self.linears
+        return len(ls) == 1 and ls[0].bias is None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.__mlp_modules(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# GGNN layer
+# ------------------------------------------------------------------------------------------------
+class GatedMessagePassingLayer(AbstractMessagePassingLayer):
+    """GGNN layer; constructor and semantics of gatedmessagepassing.py:8-77."""
+
+    def __init__(self, state_dimension: int, message_dimension: int, num_edge_types: int,
+                 message_aggregation_function: str, dropout_rate: float = 0.0,
+                 edge_feature_dimension: int = 0):
+        super().__init__()
+        self.__edge_message_transformation_layers = nn.ModuleList(
+            [nn.Linear(state_dimension + edge_feature_dimension, message_dimension, bias=False)
+             for _ in range(num_edge_types)])
+        for lin in self.__edge_message_transformation_layers:
+            nn.init.xavier_normal_(lin.weight, gain=(1 / num_edge_types) ** 0.5)
+        self.__state_update = nn.GRUCell(input_size=message_dimension, hidden_size=state_dimension)
+        nn.init.orthogonal_(self.__state_update.weight_hh)
+        nn.init.xavier_uniform_(self.__state_update.weight_ih)
+        nn.init.normal_(self.__state_update.bias_hh, std=1e-5)
+        nn.init.normal_(self.__state_update.bias_ih, std=1e-5)
+        self.__state_dimension = state_dimension
+        self.__aggregation_fn = message_aggregation_function
+        self.__dropout = nn.Dropout(p=dropout_rate)
+        self._message_dimension = message_dimension
+        self._edge_feature_dimension = edge_feature_dimension
+        self._stacked = None  # (versions, [T*M, H] weight)
+
+    # -- fused path -------------------------------------------------------------------------
+    def _stacked_edge_weights(self) -> torch.Tensor:
+        ws = [lin.weight for lin in self.__edge_message_transformation_layers]
+        key = _versions(ws)
+        if self._stacked is None or self._stacked[0] != key:
+            with torch.no_grad():
+                self._stacked = (key, torch.cat([w.detach() for w in ws], dim=0).contiguous())
+        return self._stacked[1]
+
+    def _fused_ok(self, node_states, edge_features) -> bool:
+        if self._edge_feature_dimension != 0 or any(f is not None and f.shape[-1] != 0 for f in edge_features):
+            return False
+        if self.training and self.__dropout.p > 0:
+            return False
+        if node_states.dtype != torch.float32:
+            return False
+        return _no_grad_needed(node_states, *self.parameters())
+
+    def forward(self, node_states: torch.Tensor, adjacency_lists: Adj, node_to_graph_idx,
+                reference_node_ids: Dict[str, torch.Tensor],
+                reference_node_graph_idx: Dict[str, torch.Tensor],
+                edge_features: List[torch.Tensor]) -> torch.Tensor:
+        assert len(adjacency_lists) == len(self.__edge_message_transformation_layers)
+        _check_device(node_states)
+        num_nodes = node_states.shape[0]
+        plan = ops.plan_for(adjacency_lists, num_nodes)
+        gru = self.__state_update
+        if self._fused_ok(node_states, edge_features):
+            y = ops.linear(node_states, self._stacked_edge_weights())          # [N, T*M]
+            agg = ops.gather_reduce(y, plan, self._message_dimension, self.__aggregation_fn)
+            return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
+
+        # general per-edge path (training / dropout / edge features): message order = type-major
+        all_messages = []
+        for (src, _), feats, lin in zip(adjacency_lists, edge_features,
+                                        self.__edge_message_transformation_layers):
+            inp = node_states.index_select(0, src)
+            if feats is not None and feats.shape[-1] > 0:
+                inp = torch.cat([inp, feats], dim=-1)
+            all_messages.append(lin(self.__dropout(inp)))
+        messages = torch.cat(all_messages, dim=0)
+        agg = segment_reduce(messages.to(torch.float32), plan, self.__aggregation_fn).to(messages.dtype)
+        return gru(agg, node_states)
+
+    @property
+    def input_state_dimension(self) -> int:
+        return self.__state_dimension
+
+    @property
+    def output_state_dimension(self) -> int:
+        return self.__state_dimension
+
+    def export_weights(self) -> Dict:
+        """Weights in the layout the parity oracle consumes (tests only read this)."""
+        gru = self.__state_update
+        return {"kind": "ggnn",
+                "edge_w": [l.weight.detach().cpu() for l in self.__edge_message_transformation_layers],
+                "w_ih": gru.weight_ih.detach().cpu(), "w_hh": gru.weight_hh.detach().cpu(),
+                "b_ih": gru.bias_ih.detach().cpu(), "b_hh": gru.bias_hh.detach().cpu(),
+                "agg": self.__aggregation_fn}
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP message passing layer
+# ------------------------------------------------------------------------------------------------
+class MlpMessagePassingLayer(AbstractMessagePassingLayer):
+    """Constructor and semantics of mlpmessagepassing.py:12-125."""
+
+    def __init__(self, input_state_dimension: int, output_state_dimension: int,
+                 message_dimension: int, num_edge_types: int,
+                 message_aggregation_function: Union[str, AbstractMessageAggregation],
+                 message_activation: Optional[nn.Module] = nn.GELU(),
+                 use_target_state_as_message_input: bool = True,
+                 mlp_hidden_layers: Union[List[int], int] = 0, use_layer_norm: bool = True,
+                 use_dense_layer: bool = True, dropout_rate: float = 0.0,
+                 dense_activation: Optional[nn.Module] = nn.Tanh(), features_dimension: int = 0):
+        super().__init__()
+        self.__input_state_dim = input_state_dimension
+        self.__use_target_state_as_message_input = use_target_state_as_message_input
+        self.__output_state_dim = output_state_dimension
+        msg_in = (2 if use_target_state_as_message_input else 1) * input_state_dimension
+        self.__edge_message_transformation_layers = nn.ModuleList(
+            [MLP(input_dimension=msg_in + features_dimension, output_dimension=message_dimension,
+                 hidden_layers=mlp_hidden_layers) for _ in range(num_edge_types)])
+        self.__aggregation_fn = message_aggregation_function
+        if isinstance(message_aggregation_function, str):
+            agg_size = message_dimension
+        else:
+            agg_size = message_aggregation_function.output_state_size(message_dimension)
+        self.__message_activation = message_activation
+        upd: List[nn.Module] = []
+        ln = dense = act = None
+        if use_layer_norm:
+            ln = nn.LayerNorm(agg_size)
+            upd.append(ln)
+        if use_dense_layer:
+            dense = nn.Linear(agg_size, output_state_dimension)
+            nn.init.xavier_uniform_(dense.weight)
+            upd.append(dense)
+            if dense_activation is not None:
+                act = dense_activation
+                upd.append(act)
+        drop = nn.Dropout(p=dropout_rate)
+        upd.append(drop)
+        # registered ONCE, under the reference's name => identical state_dict keys; the aliases below
+        # bypass nn.Module registration on purpose
+        self.__state_update = nn.Sequential(*upd)
+        for name, mod in (("_ln", ln), ("_dense", dense), ("_dense_act", act), ("_dropout", drop)):
+            object.__setattr__(self, name, mod)
+        self._message_dimension = message_dimension
+        self._features_dimension = features_dimension
+        self._stacked = None
+
+    # -- fused path -------------------------------------------------------------------------
+    def _stacked_edge_weights(self) -> torch.Tensor:
+        ws = [m.linears[0].weight for m in self.__edge_message_transformation_layers]
+        key = _versions(ws)
+        if self._stacked is None or self._stacked[0] != key:
+            H = self.__input_state_dim
+            with torch.no_grad():
+                parts = [w.detach()[:, :H] for w in ws]
+                if self.__use_target_state_as_message_input:
+                    parts += [w.detach()[:, H:2 * H] for w in ws]
+                self._stacked = (key, torch.cat(parts, dim=0).contiguous())   # [(1|2)*T*M, H]
+        return self._stacked[1]
+
+    def _fused_ok(self, node_states, edge_features) -> bool:
+        if not isinstance(self.__aggregation_fn, str):
+            return False
+        if self._features_dimension != 0 or any(f is not None and f.shape[-1] != 0 for f in edge_features):
+            return False
+        if not all(m.is_single_linear for m in self.__edge_message_transformation_layers):
+            return False
+        if node_states.dtype != torch.float32:
+            return False
+        return _no_grad_needed(node_states, *self.parameters())
+
+    def _update(self, agg: torch.Tensor, fused_epilogue_done: bool) -> torch.Tensor:
+        x = agg
+        if not fused_epilogue_done:
+            if self.__message_activation is not None:
+                x = self.__message_activation(x)
+            if self._ln is not None:
+                x = self._ln(x)
+        if self._dense is not None:
+            if x.is_cuda and x.dtype == torch.float32 and _no_grad_needed(x, *self._dense.parameters()):
+                tanh = isinstance(self._dense_act, nn.Tanh)
+                x = ops.linear(x, self._dense.weight, self._dense.bias, act="tanh" if tanh else None)
+                if self._dense_act is not None and not tanh:
+                    x = self._dense_act(x)
+            else:
+                x = self._dense(x)
+                if self._dense_act is not None:
+                    x = self._dense_act(x)
+        return self._dropout(x)
+
+    def forward(self, node_states: torch.Tensor, adjacency_lists: Adj, node_to_graph_idx,
+                reference_node_ids: Dict[str, torch.Tensor],
+                reference_node_graph_idx: Dict[str, torch.Tensor],
+                edge_features: List[torch.Tensor]) -> torch.Tensor:
+        assert len(adjacency_lists) == len(self.__edge_message_transformation_layers), \
+            "The number of adjacency lists must be equal to the number of edge types."
+        _check_device(node_states)
+        num_nodes = node_states.shape[0]
+        T, M = len(adjacency_lists), self._message_dimension
+
+        if self._fused_ok(node_states, edge_features):
+            plan = ops.plan_for(adjacency_lists, num_nodes)
+            y = ops.linear(node_states, self._stacked_edge_weights())
+            ysrc = y[:, :T * M]
+            ydst = y[:, T * M:] if self.__use_target_state_as_message_input else None
+            act = self.__message_activation
+            gelu_ok = act is None or (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none")
+            ln_ok = self._ln is None or (M <= 512 and self._ln.elementwise_affine
+                                         and self._ln.bias is not None)
+            if gelu_ok and ln_ok:
+                epi = (ops.EPI_GELU if act is not None else 0) | (ops.EPI_LAYERNORM if self._ln is not None else 0)
+                agg = ops.gather_reduce(
+                    ysrc, plan, M, self.__aggregation_fn, ydst=ydst, epilogue=epi,
+                    ln_weight=self._ln.weight if self._ln is not None else None,
+                    ln_bias=self._ln.bias if self._ln is not None else None,
+                    ln_eps=self._ln.eps if self._ln is not None else 1e-5)
+                return self._update(agg, True)
+            agg = ops.gather_reduce(ysrc, plan, M, self.__aggregation_fn, ydst=ydst)
+            return self._update(agg, False)
+
+        # general per-edge path
+        all_targets, all_messages = [], []
+        for (src, dst), feats, edge_mlp in zip(adjacency_lists, edge_features,
+                                               self.__edge_message_transformation_layers):
+            all_targets.append(dst)
+            inp = node_states.index_select(0, src)
+            if self.__use_target_state_as_message_input:
+                inp = torch.cat([inp, node_states.index_select(0, dst)], dim=-1)
+            if feats is not None and feats.shape[-1] > 0:
+                inp = torch.cat([inp, feats], dim=-1)
+            all_messages.append(edge_mlp(inp))
+        messages = torch.cat(all_messages, dim=0)
+        if isinstance(self.__aggregation_fn, str):
+            plan = ops.plan_for(adjacency_lists, num_nodes)
+            agg = segment_reduce(messages.to(torch.float32), plan, self.__aggregation_fn).to(messages.dtype)
+        else:
+            agg = self.__aggregation_fn(messages=messages, message_targets=torch.cat(all_targets, dim=0),
+                                        num_nodes=num_nodes)
+        return self._update(agg, False)
+
+    @property
+    def input_state_dimension(self) -> int:
+        return self.__input_state_dim
+
+    @property
+    def output_state_dimension(self) -> int:
+        return self.__output_state_dim
+
+    def export_weights(self) -> Dict:
+        c = lambda t: None if t is None else t.detach().cpu()  # noqa: E731
+        return {"kind": "mlp",
+                "edge_mlp": [[l.weight.detach().cpu() for l in m.linears]
+                             for m in self.__edge_message_transformation_layers],
+                "use_target": self.__use_target_state_as_message_input, "agg": self.__aggregation_fn,
+                "gelu": self.__message_activation is not None,
+                "ln_w": c(self._ln.weight) if self._ln is not None else None,
+                "ln_b": c(self._ln.bias) if self._ln is not None else None,
+                "dense_w": c(self._dense.weight) if self._dense is not None else None,
+                "dense_b": c(self._dense.bias) if self._dense is not None else None,
+                "tanh": self._dense_act is not None}
+
+
+# ------------------------------------------------------------------------------------------------
+# residual layers (residuallayers.py): elementwise glue that every shipped stack uses
+# ------------------------------------------------------------------------------------------------
+class _ResidualOriginLayer(AbstractMessagePassingLayer):
+    def __init__(self, input_dim: int, target_layer):
+        super().__init__()
+        self.__target_layer = target_layer   # registered like the reference (same state_dict keys)
+        self.__input_dim = input_dim
+
+    def forward(self, node_states, adjacency_lists, node_to_graph_idx, reference_node_ids,
+                reference_node_graph_idx, edge_features):
+        self.__target_layer._original_input = node_states
+        return node_states
+
+    @property
+    def input_state_dimension(self) -> int:
+        return self.__input_dim
+
+    @property
+    def output_state_dimension(self) -> int:
+        return self.__input_dim
+
+
+class _ResidualBase(AbstractMessagePassingLayer):
+    def __init__(self, input_dim: int):
+        super().__init__()
+        self._original_input = None
+        self._input_dim = input_dim
+
+    def pass_through_dummy_layer(self) -> _ResidualOriginLayer:
+        return _ResidualOriginLayer(self._input_dim, target_layer=self)
+
+    def _pop(self) -> torch.Tensor:
+        assert self._original_input is not None, "Initial Pass Through Layer was not used."
+        x, self._original_input = self._original_input, None
+        return x
+
+    @property
+    def input_state_dimension(self) -> int:
+        return self._input_dim
+
+
+class MeanResidualLayer(_ResidualBase):
+    def forward(self, node_states, adjacency_lists, node_to_graph_idx, reference_node_ids,
+                reference_node_graph_idx, edge_features):
+        return (self._pop() + node_states) * 0.5   # == stack(..).mean(-1) bit for bit (/2 is exact)
+
+    @property
+    def output_state_dimension(self) -> int:
+        return self._input_dim
+
+
+class ConcatResidualLayer(_ResidualBase):
+    def forward(self, node_states, adjacency_lists, node_to_graph_idx, reference_node_ids,
+                reference_node_graph_idx, edge_features):
+        return torch.cat((self._pop(), node_states), dim=-1)
+
+    @property
+    def output_state_dimension(self) -> int:
+        return 2 * self._input_dim
+
+
+class LinearResidualLayer(_ResidualBase):
+    def __init__(self, state_dimension1: int, state_dimension2: int, target_state_size: int,
+                 dropout_rate: float = 0.0):
+        super().__init__(state_dimension1)
+        self.__input_dim2 = state_dimension2
+        self.__linear_combination = nn.Linear(state_dimension1 + state_dimension2, target_state_size,
+                                              bias=False)
+        self.__dropout = nn.Dropout(p=dropout_rate)
+
+    def forward(self, node_states, adjacency_lists, node_to_graph_idx, reference_node_ids,
+                reference_node_graph_idx, edge_features):
+        x = torch.cat((self._pop(), node_states), dim=-1)
+        lin = self.__linear_combination
+        if x.is_cuda and x.dtype == torch.float32 and _no_grad_needed(x, lin.weight):
+            return self.__dropout(ops.linear(x, lin.weight))
+        return self.__dropout(lin(x))
+
+    @property
+    def input_state_dimension(self) -> int:
+        return self.__input_dim2
+
+    @property
+    def output_state_dimension(self) -> int:
+        return self.__linear_combination.out_features

@@ -1,0 +1,304 @@
+"""Python host wrappers over the C ABI (include/ptgnn_amd.h).
+
+torch is plumbing here: it owns device memory (outputs/workspaces are torch tensors so the caching
+allocator and stream semantics are preserved) and supplies the current HIP stream.  All compute
+happens in libptgnn_amd.so; there is no eager fallback.
+"""
+import ctypes
+import weakref
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from ptgnn_amd import _lib
+
+REDUCE_IDS = {"sum": 0, "add": 0, "mean": 1, "max": 2, "min": 3}
+EPI_NONE, EPI_GELU, EPI_LAYERNORM, EPI_GELU_LAYERNORM = 0, 1, 2, 3
+ACT_IDS = {None: 0, "none": 0, "tanh": 1, "relu": 2}
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class KernelTimer:
+    """Optional HIP-event bracket around every C-ABI launch (bench.py's live roofline numbers).
+    Events are recorded on the stream the kernel is launched on; nothing synchronises until
+    `summary()` is called."""
+
+    def __init__(self):
+        self.records = []   # (name, start_event, end_event, work dict)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, work in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["bytes"] += work.get("bytes", 0.0)
+            d["flops"] += work.get("flops", 0.0)
+        return out
+
+
+_TIMER: Optional[KernelTimer] = None
+
+
+def set_kernel_timer(timer: Optional[KernelTimer]):
+    global _TIMER
+    _TIMER = timer
+
+
+class _timed:
+    __slots__ = ("name", "work", "s")
+
+    def __init__(self, name, **work):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _TIMER is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMER is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            _TIMER.records.append((self.name, self.s, e, self.work))
+        return False
+
+
+def _require_cuda_f32(name: str, t: torch.Tensor, dims: int = 2):
+    if not t.is_cuda:
+        raise _lib.PtgnnAmdError(
+            f"{name} must live on the GPU: ptgnn_amd has no CPU path (got device {t.device})")
+    if t.dtype != torch.float32:
+        raise _lib.PtgnnAmdError(f"{name} must be float32 (got {t.dtype})")
+    if t.dim() != dims:
+        raise _lib.PtgnnAmdError(f"{name} must be {dims}-D (got shape {tuple(t.shape)})")
+
+
+def _rowmajor(t: torch.Tensor) -> torch.Tensor:
+    """Accept row-major 2-D views with unit inner stride (e.g. column slices); copy otherwise."""
+    if t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    if t.shape[1] == 1 and t.stride(0) >= 1:
+        return t
+    return t.contiguous()
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ------------------------------------------------------------------------------------------------
+# graph plan
+# ------------------------------------------------------------------------------------------------
+class GraphPlan:
+    """Destination-sorted CSR of all edge types of one minibatch (see ptgnn_amd_csr_build).
+
+    rowptr int32 [N+1]; col int32 [E] = (src << type_bits) | type; perm int32 [E] = position of
+    the CSR slot's edge in the type-major concatenation of the adjacency lists.
+    """
+
+    __slots__ = ("rowptr", "col", "perm", "type_bits", "num_nodes", "num_edges", "num_types",
+                 "_transposed", "_adj_refs", "__weakref__")
+
+    def __init__(self, rowptr, col, perm, type_bits, num_nodes, num_edges, num_types):
+        self.rowptr, self.col, self.perm = rowptr, col, perm
+        self.type_bits, self.num_nodes = type_bits, num_nodes
+        self.num_edges, self.num_types = num_edges, num_types
+        self._transposed = None
+        self._adj_refs = None
+
+
+def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num_nodes: int,
+               transposed: bool = False, want_perm: bool = True) -> GraphPlan:
+    """One stable sort per minibatch; reused by every layer of the forward."""
+    lib = _lib.load()
+    T = len(adjacency_lists)
+    if T == 0:
+        raise _lib.PtgnnAmdError("build_plan: at least one edge type is required")
+    dev = None
+    srcs, dsts, counts = [], [], []
+    for t, (s, d) in enumerate(adjacency_lists):
+        if not (s.is_cuda and d.is_cuda):
+            raise _lib.PtgnnAmdError("build_plan: adjacency lists must be CUDA tensors (no CPU path)")
+        if s.dtype != torch.int64 or d.dtype != torch.int64:
+            raise _lib.PtgnnAmdError("build_plan: adjacency lists must be int64 "
+                                     "(GraphNeuralNetworkModel.finalize_minibatch layout)")
+        if s.dim() != 1 or s.shape != d.shape:
+            raise _lib.PtgnnAmdError(f"build_plan: edge type {t}: src/dst must be equal-length 1-D")
+        s, d = s.contiguous(), d.contiguous()
+        dev = s.device if dev is None else dev
+        srcs.append(s)
+        dsts.append(d)
+        counts.append(int(s.shape[0]))
+    E = sum(counts)
+    type_bits = lib.ptgnn_amd_type_bits(T)
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if want_perm else None
+    ws_bytes = lib.ptgnn_amd_csr_workspace_bytes(E, num_nodes)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    PtrArr, CntArr = ctypes.c_void_p * T, ctypes.c_int64 * T
+    src_ptrs = PtrArr(*[s.data_ptr() if s.numel() else None for s in srcs])
+    dst_ptrs = PtrArr(*[d.data_ptr() if d.numel() else None for d in dsts])
+    cnts = CntArr(*counts)
+    # algorithmic bytes: read 16 B/edge (int64 src+dst), write 4 B/edge col (+4 perm) + rowptr
+    with _timed("csr_build", bytes=E * (16 + 4 + (4 if want_perm else 0)) + 4.0 * (num_nodes + 1)):
+        rc = lib.ptgnn_amd_csr_build(ctypes.cast(src_ptrs, ctypes.c_void_p),
+                                     ctypes.cast(dst_ptrs, ctypes.c_void_p),
+                                     ctypes.cast(cnts, ctypes.c_void_p), T, num_nodes,
+                                     1 if transposed else 0, rowptr.data_ptr(), col.data_ptr(),
+                                     perm.data_ptr() if perm is not None else None, ws.data_ptr(),
+                                     ws_bytes, _stream(rowptr))
+    _lib.check(rc, "ptgnn_amd_csr_build")
+    # `ws`, `srcs`, `dsts` are stream-ordered: torch's caching allocator only hands their memory to
+    # later work on the same stream, so dropping the references here is safe.
+    # col/perm keep >= 1 element so their base pointer is never null (E == 0 batches are legal)
+    return GraphPlan(rowptr, col, perm, type_bits, num_nodes, E, T)
+
+
+_PLAN_CACHE: List[GraphPlan] = []
+_PLAN_CACHE_SIZE = 4
+
+
+def plan_for(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num_nodes: int) -> GraphPlan:
+    """Plan lookup keyed on the *identity and version* of the adjacency tensors, so the L layers of
+    one forward (which all receive the same tensors, graphneuralnetwork.py:122-131) share one
+    sort.  Weak references guarantee a freed-and-reallocated tensor can never alias a stale plan."""
+    for plan in _PLAN_CACHE:
+        refs = plan._adj_refs
+        if plan.num_nodes != num_nodes or len(refs) != len(adjacency_lists):
+            continue
+        ok = True
+        for (rs, vs, rd, vd), (s, d) in zip(refs, adjacency_lists):
+            if rs() is not s or rd() is not d or s._version != vs or d._version != vd:
+                ok = False
+                break
+        if ok:
+            return plan
+    plan = build_plan(adjacency_lists, num_nodes)
+    plan._adj_refs = [(weakref.ref(s), s._version, weakref.ref(d), d._version)
+                      for s, d in adjacency_lists]
+    _PLAN_CACHE.insert(0, plan)
+    del _PLAN_CACHE[_PLAN_CACHE_SIZE:]
+    return plan
+
+
+def clear_plan_cache():
+    del _PLAN_CACHE[:]
+
+
+# ------------------------------------------------------------------------------------------------
+# kernels
+# ------------------------------------------------------------------------------------------------
+def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str,
+                  ydst: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
+                  ln_weight: Optional[torch.Tensor] = None, ln_bias: Optional[torch.Tensor] = None,
+                  ln_eps: float = 1e-5, return_arg: bool = False, type_bits: Optional[int] = None,
+                  col: Optional[torch.Tensor] = None):
+    """out[v] = EPI(reduce_{slots of v} ysrc[src, t*M:(t+1)*M] (+ ydst[v, t*M:(t+1)*M]))."""
+    lib = _lib.load()
+    _require_cuda_f32("ysrc", ysrc)
+    ysrc = _rowmajor(ysrc)
+    ld_y = _ld(ysrc)
+    if ydst is not None:
+        _require_cuda_f32("ydst", ydst)
+        ydst = _rowmajor(ydst)
+        if _ld(ydst) != ld_y:
+            raise _lib.PtgnnAmdError("gather_reduce: ysrc and ydst must share a leading dimension")
+    if reduce not in REDUCE_IDS:
+        raise ValueError(f"unknown aggregation function {reduce!r}")
+    N = plan.num_nodes
+    out = torch.empty(N, msg_dim, dtype=torch.float32, device=ysrc.device)
+    arg = None
+    if return_arg:
+        arg = torch.empty(N, msg_dim, dtype=torch.int32, device=ysrc.device)
+    if epilogue & EPI_LAYERNORM:
+        ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+    tb = plan.type_bits if type_bits is None else type_bits
+    colt = plan.col if col is None else col
+    # algorithmic bytes (SURVEY.md 8d "(L)"): per edge one message row + its col entry; per node the
+    # output row, the rowptr entry and (MLP-MP) the destination-term row; gathers get no cache credit
+    nbytes = (plan.num_edges * (4.0 * msg_dim + 4) + N * (4.0 * msg_dim + 4)
+              + (N * 4.0 * msg_dim if ydst is not None else 0.0)
+              + (N * 4.0 * msg_dim if arg is not None else 0.0))
+    with _timed("gather_reduce", bytes=nbytes):
+        rc = lib.ptgnn_amd_gather_reduce_f32(
+            ysrc.data_ptr(), ydst.data_ptr() if ydst is not None else None, ld_y,
+            plan.rowptr.data_ptr(), colt.data_ptr(), tb, N, msg_dim,
+            REDUCE_IDS[reduce], epilogue,
+            ln_weight.data_ptr() if ln_weight is not None else None,
+            ln_bias.data_ptr() if ln_bias is not None else None, float(ln_eps),
+            out.data_ptr(), msg_dim, arg.data_ptr() if arg is not None else None, _stream(out))
+    _lib.check(rc, "ptgnn_amd_gather_reduce_f32")
+    return (out, arg) if return_arg else out
+
+
+def segment_reduce(messages: torch.Tensor, plan: GraphPlan, reduce: str, return_arg: bool = False):
+    """The torch_scatter seam over a plan: messages [E, D] are in the type-major concatenation
+    order of the adjacency lists (abstractmessagepassing.py:38-50)."""
+    _require_cuda_f32("messages", messages)
+    if messages.shape[0] != plan.num_edges:
+        raise _lib.PtgnnAmdError("segment_reduce: messages rows != number of edges in the plan")
+    if plan.perm is None:
+        raise _lib.PtgnnAmdError("segment_reduce: plan was built without perm")
+    return gather_reduce(messages, plan, messages.shape[1], reduce, return_arg=return_arg,
+                         type_bits=0, col=plan.perm)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           act: Optional[str] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act(x W^T + b) on fp32 MFMA.  weight is nn.Linear layout [n_out, k]."""
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    _require_cuda_f32("weight", weight)
+    x, weight = _rowmajor(x), weight.contiguous()
+    rows, k = x.shape
+    n_out = weight.shape[0]
+    if weight.shape[1] != k:
+        raise _lib.PtgnnAmdError(f"linear: x has {k} columns but weight expects {weight.shape[1]}")
+    if out is None:
+        out = torch.empty(rows, n_out, dtype=torch.float32, device=x.device)
+    if bias is not None:
+        bias = bias.contiguous()
+    with _timed("linear", flops=2.0 * rows * k * n_out, bytes=4.0 * (rows * k + n_out * k + rows * n_out)):
+        rc = lib.ptgnn_amd_linear_f32(x.data_ptr(), rows, k, _ld(x), weight.data_ptr(), n_out,
+                                      bias.data_ptr() if bias is not None else None, ACT_IDS[act],
+                                      out.data_ptr(), _ld(out), _stream(out))
+    _lib.check(rc, "ptgnn_amd_linear_f32")
+    return out
+
+
+def gru_cell(a: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh) -> torch.Tensor:
+    lib = _lib.load()
+    _require_cuda_f32("a", a)
+    _require_cuda_f32("h", h)
+    a, h = _rowmajor(a), _rowmajor(h)
+    n, m = a.shape
+    hd = h.shape[1]
+    out = torch.empty(n, hd, dtype=torch.float32, device=a.device)
+    with _timed("gru_cell", flops=2.0 * n * 3 * hd * (m + hd), bytes=4.0 * (n * (m + 2 * hd) + 3 * hd * (m + hd))):
+        rc = lib.ptgnn_amd_gru_cell_f32(a.data_ptr(), _ld(a), h.data_ptr(), _ld(h),
+                                        w_ih.contiguous().data_ptr(), w_hh.contiguous().data_ptr(),
+                                        b_ih.contiguous().data_ptr(), b_hh.contiguous().data_ptr(),
+                                        n, m, hd, out.data_ptr(), hd, _stream(out))
+    _lib.check(rc, "ptgnn_amd_gru_cell_f32")
+    return out
+
+
+def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    x = _rowmajor(x)
+    if idx.dtype != torch.int64 or not idx.is_cuda:
+        raise _lib.PtgnnAmdError("gather_rows: idx must be a CUDA int64 tensor")
+    idx = idx.contiguous()
+    out = torch.empty(idx.shape[0], x.shape[1], dtype=torch.float32, device=x.device)
+    rc = lib.ptgnn_amd_gather_rows_f32(x.data_ptr(), _ld(x), idx.data_ptr(), idx.shape[0],
+                                       x.shape[1], out.data_ptr(), x.shape[1], _stream(out))
+    _lib.check(rc, "ptgnn_amd_gather_rows_f32")
+    return out

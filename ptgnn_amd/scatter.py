@@ -1,0 +1,90 @@
+"""`torch_scatter`-compatible facade on the HIP segment-reduce kernel, plus the autograd seam.
+
+Mirrors the call the reference makes at its single hot-path scatter site
+(ptgnn/neuralmodels/gnn/messagepassing/abstractmessagepassing.py:44-50):
+``scatter(src, index=targets, dim=0, dim_size=num_nodes, reduce=fn)`` with `src` [E, D] and a 1-D
+int64 `index`.  Semantics follow torch_scatter 2.0.x: sum/mean/max/min, empty segments -> 0,
+mean divides by max(count, 1); backward: sum -> gather, mean -> gather / count, max/min -> the
+gradient flows only to the arg-max/min source element.
+"""
+from typing import Optional
+
+import torch
+
+from ptgnn_amd import _lib, ops
+
+
+class _SegmentReduce(torch.autograd.Function):
+    """messages [E, D] (type-major edge order) --plan--> [N, D]."""
+
+    @staticmethod
+    def forward(ctx, messages, plan, reduce):
+        need_arg = reduce in ("max", "min") and messages.requires_grad
+        msg = messages if messages.shape[0] > 0 else messages.new_zeros(1, messages.shape[1])
+        res = ops.gather_reduce(msg, plan, messages.shape[1], reduce, return_arg=need_arg,
+                                type_bits=0, col=plan.perm)
+        ctx.plan, ctx.reduce, ctx.num_edges = plan, reduce, messages.shape[0]
+        if need_arg:
+            out, arg = res
+            ctx.save_for_backward(arg)
+            ctx.mark_non_differentiable(arg)
+            return out
+        return res
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan, reduce, E = ctx.plan, ctx.reduce, ctx.num_edges
+        grad_out = grad_out.contiguous()
+        D = grad_out.shape[1]
+        if E == 0:
+            return grad_out.new_zeros(0, D), None, None
+        # slot -> destination row (expand rowptr), slot -> original edge position (perm)
+        deg = (plan.rowptr[1:] - plan.rowptr[:-1]).to(torch.int64)
+        slot_dst = torch.repeat_interleave(torch.arange(plan.num_nodes, device=grad_out.device), deg,
+                                           output_size=E)
+        perm = plan.perm[:E].to(torch.int64)
+        if reduce in ("sum", "add", "mean"):
+            g = grad_out
+            if reduce == "mean":
+                g = grad_out / deg.clamp(min=1).to(grad_out.dtype).unsqueeze(1)
+            grad_slots = ops.gather_rows(g, slot_dst)               # [E, D] in CSR slot order
+            grad_msg = torch.empty_like(grad_slots)
+            grad_msg[perm] = grad_slots
+            return grad_msg, None, None
+        (arg,) = ctx.saved_tensors                                  # [N, D] winning slot or -1
+        grad_msg = grad_out.new_zeros(E * D)
+        valid = arg >= 0
+        slot = arg.clamp(min=0).to(torch.int64)
+        flat = perm[slot] * D + torch.arange(D, device=grad_out.device).unsqueeze(0)
+        grad_msg.index_put_((flat[valid],), grad_out[valid], accumulate=False)
+        return grad_msg.view(E, D), None, None
+
+
+def segment_reduce(messages: torch.Tensor, plan: "ops.GraphPlan", reduce: str) -> torch.Tensor:
+    """Differentiable `_aggregate_messages` over a prebuilt plan."""
+    if reduce not in ops.REDUCE_IDS:
+        raise ValueError(f"unknown aggregation function {reduce!r}")
+    return _SegmentReduce.apply(messages, plan, reduce)
+
+
+def scatter(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional[torch.Tensor] = None,
+            dim_size: Optional[int] = None, reduce: str = "sum") -> torch.Tensor:
+    """torch_scatter.scatter for the layout the ptgnn hot path uses: 2-D (or 1-D) `src`, 1-D int64
+    `index` along dim 0.  Anything else raises (no silent fallback)."""
+    if out is not None:
+        raise _lib.PtgnnAmdError("ptgnn_amd.scatter: the `out=` form is not supported")
+    squeeze = False
+    if src.dim() == 1:
+        src, squeeze = src.unsqueeze(1), True
+    if dim < 0:
+        dim += src.dim() - (1 if squeeze else 0)
+    if dim != 0 or src.dim() != 2 or index.dim() != 1 or index.shape[0] != src.shape[0]:
+        raise _lib.PtgnnAmdError("ptgnn_amd.scatter supports src [E, D] / [E] with a 1-D index along "
+                                 f"dim 0 (got src {tuple(src.shape)}, index {tuple(index.shape)}, dim {dim})")
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() > 0 else 0
+    dt = src.dtype
+    # torch_scatter semantics: a plan whose "source" column is unused; (index, index) gives dst=index
+    plan = ops.build_plan([(index, index)], int(dim_size))
+    res = segment_reduce(src.to(torch.float32), plan, reduce).to(dt)
+    return res.squeeze(1) if squeeze else res

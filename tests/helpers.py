@@ -1,0 +1,91 @@
+"""Test helpers: build ptgnn_amd layers from oracle layer specs (golden fixtures / random)."""
+import torch
+from torch import nn
+
+from ptgnn_amd import layers as L
+
+
+def layer_from_spec(spec):
+    if spec["kind"] == "ggnn":
+        T = len(spec["edge_w"])
+        M, H = spec["edge_w"][0].shape
+        lay = L.GatedMessagePassingLayer(H, M, T, spec["agg"])
+        sd = lay.state_dict()
+        p = "_GatedMessagePassingLayer__"
+        for t in range(T):
+            sd[f"{p}edge_message_transformation_layers.{t}.weight"] = spec["edge_w"][t]
+        sd[p + "state_update.weight_ih"], sd[p + "state_update.weight_hh"] = spec["w_ih"], spec["w_hh"]
+        sd[p + "state_update.bias_ih"], sd[p + "state_update.bias_hh"] = spec["b_ih"], spec["b_hh"]
+        lay.load_state_dict(sd)
+        return lay
+    if spec["kind"] == "mlp":
+        T = len(spec["edge_mlp"])
+        ws = spec["edge_mlp"][0]
+        M = ws[-1].shape[0]
+        in_w = ws[0].shape[1]
+        H = in_w // 2 if spec["use_target"] else in_w
+        hidden = [w.shape[0] for w in ws[:-1]]
+        out_dim = spec["dense_w"].shape[0] if spec["dense_w"] is not None else M
+        lay = L.MlpMessagePassingLayer(
+            H, out_dim, M, T, spec["agg"],
+            message_activation=nn.GELU() if spec["gelu"] else None,
+            use_target_state_as_message_input=spec["use_target"], mlp_hidden_layers=hidden,
+            use_layer_norm=spec["ln_w"] is not None, use_dense_layer=spec["dense_w"] is not None,
+            dense_activation=nn.Tanh() if spec["tanh"] else None)
+        sd = lay.state_dict()
+        p = "_MlpMessagePassingLayer__"
+        for t in range(T):
+            keys = sorted((k for k in sd if k.startswith(f"{p}edge_message_transformation_layers.{t}.")),
+                          key=lambda k: int(k.split(".")[-2]))
+            for k, w in zip(keys, spec["edge_mlp"][t]):
+                sd[k] = w
+        idx = 0
+        if spec["ln_w"] is not None:
+            sd[f"{p}state_update.{idx}.weight"], sd[f"{p}state_update.{idx}.bias"] = spec["ln_w"], spec["ln_b"]
+            idx += 1
+        if spec["dense_w"] is not None:
+            sd[f"{p}state_update.{idx}.weight"], sd[f"{p}state_update.{idx}.bias"] = spec["dense_w"], spec["dense_b"]
+        lay.load_state_dict(sd)
+        return lay
+    raise ValueError(spec["kind"])
+
+
+def stack_from_specs(specs):
+    """Oracle spec list (with tied layers and residual markers) -> list of ptgnn_amd modules."""
+    built, residuals, mods = {}, {}, []
+    for i, spec in enumerate(specs):
+        k = spec["kind"]
+        if k in ("ggnn", "mlp"):
+            if id(spec) not in built:
+                built[id(spec)] = layer_from_spec(spec)
+            mods.append(built[id(spec)])
+        elif k == "residual_origin":
+            mods.append(("origin", spec["name"], len(mods)))
+        elif k in ("residual_concat", "residual_mean"):
+            # find the dim of the stashed state: output dim of whatever precedes the origin marker
+            origin_pos = next(m[2] for m in mods if isinstance(m, tuple) and m[1] == spec["name"])
+            dim = _dim_before(mods, origin_pos, specs)
+            res = (L.ConcatResidualLayer if k == "residual_concat" else L.MeanResidualLayer)(dim)
+            mods[origin_pos] = res.pass_through_dummy_layer()
+            mods.append(res)
+        else:
+            raise ValueError(k)
+    return mods
+
+
+def _dim_before(mods, pos, specs):
+    for m in reversed(mods[:pos]):
+        if not isinstance(m, tuple):
+            return m.output_state_dimension
+    for m in mods[pos + 1:]:
+        if not isinstance(m, tuple):
+            return m.input_state_dimension
+    raise ValueError
+
+
+def to_cuda_adj(adj):
+    return [(s.cuda(), d.cuda()) for s, d in adj]
+
+
+def empty_feats(adj, device):
+    return [torch.empty(a[0].shape[0], 0, device=device) for a in adj]

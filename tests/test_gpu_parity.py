@@ -1,0 +1,366 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path through the C ABI versus the CPU
+oracle on the same seeded inputs, versus the golden fixtures produced by the reference's own
+modules, and -- at BASELINE.json config-2 size -- through size-independent properties.
+
+Bars: integer/index outputs bit-exact; max/min aggregation bit-exact; fp32 sums bit-exact where the
+fold order is the reference's (segment reduce) and |delta| <= 1e-5 for full layers (north_star).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import empty_feats, layer_from_spec, stack_from_specs, to_cuda_adj
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # BASELINE.json north_star: fp32 node states within 1e-5 of the reference CPU path
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need the MI355X (run them through gpurun)")
+    from ptgnn_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+
+
+def ref_csr(adj, num_nodes, transposed=False):
+    """numpy restatement of the plan: stable sort of the type-major edge list by destination."""
+    T = len(adj)
+    tb = int(np.ceil(np.log2(T))) if T > 1 else 0
+    src = np.concatenate([a[0].numpy() for a in adj]) if T else np.zeros(0, np.int64)
+    dst = np.concatenate([a[1].numpy() for a in adj]) if T else np.zeros(0, np.int64)
+    typ = np.concatenate([np.full(a[0].shape[0], t, np.int64) for t, a in enumerate(adj)])
+    if transposed:
+        src, dst = dst, src
+    order = np.argsort(dst, kind="stable")
+    rowptr = np.zeros(num_nodes + 1, np.int64)
+    np.add.at(rowptr, dst + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    col = (src[order] << tb) | typ[order]
+    return rowptr.astype(np.int32), col.astype(np.int32), order.astype(np.int32), tb
+
+
+# ------------------------------------------------------------------------------------------------
+# plan (integer work: bit exact)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["random3", "one_empty_type", "all_empty", "hub", "single", "many_types"])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_csr_build_bit_exact(case, transposed):
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n = 1000
+    ri = lambda c: torch.randint(0, n, (c,), generator=g, dtype=torch.int64)  # noqa: E731
+    z = torch.zeros(0, dtype=torch.int64)
+    adj = {
+        "random3": [(ri(5000), ri(5000)), (ri(17), ri(17)), (ri(2500), ri(2500))],
+        "one_empty_type": [(ri(300), ri(300)), (z, z), (ri(40), ri(40))],
+        "all_empty": [(z, z), (z, z)],
+        "hub": [(ri(20000), torch.full((20000,), 7, dtype=torch.int64)), (ri(100), ri(100))],
+        "single": [(ri(1), ri(1))],
+        "many_types": [(ri(50 + 13 * t), ri(50 + 13 * t)) for t in range(23)],
+    }[case]
+    plan = ops.build_plan(to_cuda_adj(adj), n, transposed=transposed)
+    rowptr, col, perm, tb = ref_csr(adj, n, transposed)
+    E = len(col)
+    assert plan.num_edges == E and plan.type_bits == tb and plan.num_types == len(adj)
+    np.testing.assert_array_equal(plan.rowptr.cpu().numpy(), rowptr)
+    np.testing.assert_array_equal(plan.col[:E].cpu().numpy(), col)
+    np.testing.assert_array_equal(plan.perm[:E].cpu().numpy(), perm)
+
+
+def test_csr_build_rejects_cpu_and_int32():
+    from ptgnn_amd import PtgnnAmdError, ops
+    a = torch.zeros(3, dtype=torch.int64)
+    with pytest.raises(PtgnnAmdError):
+        ops.build_plan([(a, a)], 4)
+    with pytest.raises(PtgnnAmdError):
+        ops.build_plan([(a.cuda().int(), a.cuda().int())], 4)
+
+
+def test_plan_cache_identity():
+    from ptgnn_amd import ops
+    ops.clear_plan_cache()
+    a = torch.arange(10, device="cuda")
+    adj = [(a, a.flip(0).contiguous())]
+    p1 = ops.plan_for(adj, 10)
+    assert ops.plan_for([(adj[0][0], adj[0][1])], 10) is p1          # same tensors -> same plan
+    assert ops.plan_for([(a.clone(), adj[0][1])], 10) is not p1      # different tensor object
+    adj[0][0].add_(0)                                                 # version bump -> rebuilt
+    assert ops.plan_for(adj, 10) is not p1
+
+
+# ------------------------------------------------------------------------------------------------
+# the scatter seam
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
+@pytest.mark.parametrize("dim", [1, 3, 24, 64, 128, 200, 256, 512, 640])
+def test_scatter_matches_oracle(reduce, dim):
+    from oracle import scatter_ref
+    from ptgnn_amd.scatter import scatter
+    g = torch.Generator().manual_seed(dim)
+    E, N = 6000, 701
+    src = torch.randn(E, dim, generator=g)
+    idx = torch.randint(0, N - 1, (E,), generator=g)
+    idx[idx == 13] = 14                       # empty segments: 13 and N-1
+    idx[:900] = 5                             # one long segment (crosses the x4 unroll many times)
+    want = scatter_ref.scatter(src, idx, dim=0, dim_size=N, reduce=reduce)
+    got = scatter(src.cuda(), idx.cuda(), dim=0, dim_size=N, reduce=reduce).cpu()
+    assert got.dtype == torch.float32 and got.shape == want.shape
+    if reduce == "mean":
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+    else:
+        # same fold order as the reference's CPU scatter_add_ / order-independent max,min
+        np.testing.assert_array_equal(got.numpy(), want.numpy())
+    assert float(got[13].abs().sum()) == 0.0 and float(got[N - 1].abs().sum()) == 0.0
+
+
+def test_scatter_known_answers_and_1d():
+    from ptgnn_amd.scatter import scatter
+    src = torch.tensor([[1.0, -2.0], [3.0, 4.0], [5.0, -6.0], [-7.0, 8.0], [0.5, 0.25]]).cuda()
+    idx = torch.tensor([2, 0, 2, 2, 0]).cuda()
+    exp = {"sum": [[3.5, 4.25], [0, 0], [-1.0, 0.0], [0, 0]],
+           "max": [[3.0, 4.0], [0, 0], [5.0, 8.0], [0, 0]],
+           "min": [[0.5, 0.25], [0, 0], [-7.0, -6.0], [0, 0]]}
+    for r, e in exp.items():
+        np.testing.assert_array_equal(scatter(src, idx, 0, dim_size=4, reduce=r).cpu().numpy(),
+                                      np.asarray(e, np.float32))
+    out = scatter(src[:, 0].contiguous(), idx, dim=0, reduce="add")  # dim_size from index.max()+1
+    np.testing.assert_array_equal(out.cpu().numpy(), np.asarray([3.5, 0.0, -1.0], np.float32))
+    out = scatter(torch.zeros(0, 3).cuda(), torch.zeros(0, dtype=torch.int64).cuda(), 0, dim_size=5,
+                  reduce="max")
+    assert tuple(out.shape) == (5, 3) and float(out.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
+def test_scatter_backward_matches_oracle_autograd(reduce):
+    from oracle import scatter_ref
+    from ptgnn_amd.scatter import scatter
+    g = torch.Generator().manual_seed(11)
+    E, N, D = 3000, 257, 48
+    src = torch.randn(E, D, generator=g)
+    idx = torch.randint(0, N - 3, (E,), generator=g)
+    go = torch.randn(N, D, generator=g)
+    a = src.clone().requires_grad_(True)
+    scatter_ref.scatter(a, idx, dim=0, dim_size=N, reduce=reduce).backward(go)
+    b = src.clone().cuda().requires_grad_(True)
+    scatter(b, idx.cuda(), dim=0, dim_size=N, reduce=reduce).backward(go.cuda())
+    np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense blocks
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,k,n_out", [(1, 1, 1), (7, 5, 3), (129, 64, 64), (300, 128, 256),
+                                          (1000, 130, 70), (257, 256, 384), (4096, 128, 2176)])
+@pytest.mark.parametrize("act,bias", [(None, False), ("tanh", True), ("relu", True)])
+def test_linear_matches_fp32_reference(rows, k, n_out, act, bias):
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(rows + k)
+    x = torch.randn(rows, k, generator=g)
+    w = torch.randn(n_out, k, generator=g) / k ** 0.5
+    b = torch.randn(n_out, generator=g) if bias else None
+    want = x.double() @ w.double().t()
+    if b is not None:
+        want = want + b.double()
+    want = {"tanh": torch.tanh, "relu": torch.relu, None: lambda v: v}[act](want)
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda() if bias else None, act=act).cpu()
+    np.testing.assert_allclose(got.numpy(), want.float().numpy(), rtol=0, atol=TOL)
+
+
+def test_linear_strided_views():
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(300, 96, generator=g).cuda()
+    w = torch.randn(40, 32, generator=g).cuda()
+    x = big[:, 32:64]                                   # column slice: ld 96
+    out = torch.zeros(300, 100, device="cuda")
+    ops.linear(x, w, out=out[:, 10:50])
+    want = (x.double().cpu() @ w.double().cpu().t()).float()
+    np.testing.assert_allclose(out[:, 10:50].cpu().numpy(), want.numpy(), atol=TOL)
+    assert float(out[:, :10].abs().sum()) == 0 and float(out[:, 50:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("n,m,h", [(1, 4, 4), (77, 24, 16), (300, 128, 128), (513, 128, 256),
+                                   (200, 100, 36)])
+def test_gru_cell_matches_oracle(n, m, h):
+    from oracle import mp_oracle as O
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(n)
+    a, hh = torch.randn(n, m, generator=g), torch.randn(n, h, generator=g)
+    w_ih, w_hh = torch.randn(3 * h, m, generator=g) / m ** 0.5, torch.randn(3 * h, h, generator=g) / h ** 0.5
+    b_ih, b_hh = torch.randn(3 * h, generator=g) * 0.1, torch.randn(3 * h, generator=g) * 0.1
+    want = O.gru_cell(a, hh, w_ih, w_hh, b_ih, b_hh)
+    torch_want = torch.nn.functional.gru_cell(a, hh, w_ih, w_hh, b_ih, b_hh)
+    np.testing.assert_allclose(want.numpy(), torch_want.numpy(), atol=2e-6)   # oracle == torch GRUCell
+    got = ops.gru_cell(a.cuda(), hh.cuda(), w_ih.cuda(), w_hh.cuda(), b_ih.cuda(), b_hh.cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=TOL)
+
+
+def test_gather_rows():
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for d in (1, 7, 64, 128, 300):
+        x = torch.randn(500, d, generator=g)
+        idx = torch.randint(0, 500, (1234,), generator=g)
+        got = ops.gather_rows(x.cuda(), idx.cuda()).cpu()
+        np.testing.assert_array_equal(got.numpy(), x[idx].numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# layers against golden fixtures of the reference's own modules + against the oracle
+# ------------------------------------------------------------------------------------------------
+LAYER_CASES = ["ggnn_layer_sum", "ggnn_layer_mean", "ggnn_layer_max", "ggnn_layer_min",
+               "mlp_layer_sum_target", "mlp_layer_max_target", "mlp_layer_mean_notarget",
+               "mlp_layer_sum_hidden1", "mlp_layer_max_noln_nodense"]
+
+
+@pytest.mark.parametrize("name", LAYER_CASES)
+@pytest.mark.parametrize("path", ["fused", "general"])
+def test_layer_matches_reference_golden(name, path):
+    from oracle.fixtures import unpack_adj, unpack_specs
+    from ptgnn_amd import ops
+    g = load_golden(name)
+    adj, (spec,) = unpack_adj(g), unpack_specs(g)
+    layer = layer_from_spec(spec).cuda().eval()
+    x = torch.from_numpy(g["x"]).cuda()
+    cadj = to_cuda_adj(adj)
+    ops.clear_plan_cache()
+    if path == "fused":
+        with torch.no_grad():
+            y = layer(x, cadj, None, {}, {}, empty_feats(cadj, "cuda"))
+    else:  # grad-enabled => per-edge path with the HIP scatter seam
+        y = layer(x.requires_grad_(True), cadj, None, {}, {}, empty_feats(cadj, "cuda"))
+        assert y.requires_grad
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("name", ["gnn_stack_ggnn_typilus", "gnn_stack_mlp_varmisuse"])
+def test_container_matches_reference_golden(name):
+    from oracle.fixtures import unpack_adj, unpack_specs
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    g = load_golden(name)
+    adj, specs = unpack_adj(g), unpack_specs(g)
+    net = GraphNeuralNetwork(stack_from_specs(specs), torch.nn.Identity(), introduce_backwards_edges=True,
+                             add_self_edges=True).cuda().eval()
+    x = torch.from_numpy(g["x"]).cuda()
+    n2g = torch.from_numpy(g["node_to_graph_idx"]).cuda()
+    refs = {"supernodes": torch.tensor([0, 5, 21, 40, 59]).cuda()}
+    ref_g = {"supernodes": torch.tensor([0, 0, 1, 2, 2]).cuda()}
+    cadj = to_cuda_adj(adj)
+    n_before = len(cadj)
+    with torch.no_grad():
+        out = net(node_data={"input": x}, adjacency_lists=cadj, edge_feature_data=[],
+                  node_to_graph_idx=n2g, reference_node_ids=refs, reference_node_graph_idx=ref_g,
+                  num_graphs=3)
+        out2 = net(node_data={"input": x}, adjacency_lists=cadj, edge_feature_data=[],
+                   node_to_graph_idx=n2g, reference_node_ids=refs, reference_node_graph_idx=ref_g,
+                   num_graphs=3)                                   # callable twice (no list mutation)
+    assert len(cadj) == n_before
+    np.testing.assert_allclose(out.output_node_representations.cpu().numpy(), g["y"], rtol=0, atol=TOL)
+    np.testing.assert_array_equal(out.output_node_representations.cpu().numpy(),
+                                  out2.output_node_representations.cpu().numpy())   # deterministic
+    # index fields are the very same tensor objects, passed through (graphneuralnetwork.py:202-209)
+    assert out.node_to_graph_idx is n2g and out.node_idx_references is refs
+    assert out.node_graph_idx_reference is ref_g and out.num_graphs == 3
+    assert out.reference_nodes_idx is refs and out.input_node_representations is x
+    m = net.report_metrics()
+    assert m["num_edges"] == 2 * int(g["num_edges"]) and m["num_graphs"] == 6 and m["num_nodes"] == 120
+    # the task-head access pattern (graph2class.py:84-89)
+    head = out.output_node_representations[out.node_idx_references["supernodes"]]
+    np.testing.assert_allclose(head.cpu().numpy(), g["y"][[0, 5, 21, 40, 59]], rtol=0, atol=TOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs: oracle at sizes it finishes in seconds, properties at full size
+# ------------------------------------------------------------------------------------------------
+def _mlp_layer(H, M, T, agg, seed):
+    from ptgnn_amd import layers as L
+    torch.manual_seed(seed)
+    return L.MlpMessagePassingLayer(H, H, M, T, agg)
+
+
+@pytest.mark.parametrize("agg", ["sum", "max", "mean"])
+def test_config2_full_size_vs_oracle(agg):
+    """BASELINE config 2: N=200k, E=1.1M, 1 MLP-MP layer H=128 -- fp32 vs CPU parity."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import ops, workloads
+    N, E, H = 200_000, 1_100_000, 128
+    adj = workloads.random_graph(N, E)
+    x = workloads.node_states(N, H)
+    layer = _mlp_layer(H, H, 1, agg, 1234).eval()
+    want = O.mlp_mp_layer(x, adj, [torch.empty(E, 0)], layer.export_weights())
+    layer = layer.cuda()
+    cadj = to_cuda_adj(adj)
+    ops.clear_plan_cache()
+    with torch.no_grad():
+        got = layer(x.cuda(), cadj, None, {}, {}, empty_feats(cadj, "cuda")).cpu()
+    err = float((got - want).abs().max())
+    assert err <= TOL, f"max |delta| = {err:.3e}"
+    assert torch.isfinite(got).all()
+
+
+def test_config3_graph2class_stack_vs_oracle():
+    """BASELINE config 3 shape (T0=8 -> T=17, Typilus GGNN arch, max) at a reduced node count the
+    CPU oracle finishes in seconds; the full size is covered by the property test below."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    H = 128
+    mb = workloads.batched_graphs(6, 1500, 8, 2.2, seed=7)
+    N = mb["num_nodes"]
+    torch.manual_seed(3)
+    ggnn = L.GatedMessagePassingLayer(H, H, 17, "max")
+    r1 = L.ConcatResidualLayer(H)
+    last = L.GatedMessagePassingLayer(2 * H, H, 17, "max")
+    mods = [r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last]
+    specs = ([{"kind": "residual_origin", "name": "r1"}] + [ggnn.export_weights()] * 7
+             + [{"kind": "residual_concat", "name": "r1"}, last.export_weights()])
+    x = workloads.node_states(N, H, seed=5)
+    want, n_edges = O.gnn_forward(x, mb["adjacency_lists"], specs, True, True)
+    net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).cuda().eval()
+    with torch.no_grad():
+        out = net(node_data={"input": x.cuda()}, adjacency_lists=to_cuda_adj(mb["adjacency_lists"]),
+                  edge_feature_data=[], node_to_graph_idx=mb["node_to_graph_idx"].cuda(),
+                  reference_node_ids={k: v.cuda() for k, v in mb["reference_node_ids"].items()},
+                  reference_node_graph_idx={k: v.cuda() for k, v in mb["reference_node_graph_idx"].items()},
+                  num_graphs=mb["num_graphs"])
+    got = out.output_node_representations.cpu()
+    assert net.report_metrics()["num_edges"] == n_edges
+    err = float((got - want).abs().max())
+    assert err <= TOL, f"max |delta| after 8 GGNN layers = {err:.3e}"
+    np.testing.assert_array_equal(out.node_idx_references["supernodes"].cpu().numpy(),
+                                  mb["reference_node_ids"]["supernodes"].numpy())
+
+
+def test_full_size_properties_linearity_and_permutation():
+    """Size-independent properties at config-2 size (no CPU oracle needed):
+       (a) sum aggregation is linear in the message table: agg(Y1 + Y2) == agg(Y1) + agg(Y2) to fp32
+           rounding, and agg(2*Y) == 2*agg(Y) exactly;
+       (b) max aggregation is invariant to permuting the edge list (bit exact);
+       (c) column sums: sum_v agg_sum(Y)[v] == sum_e Y[src_e] (checksum of checksums, fp64)."""
+    from ptgnn_amd import ops, workloads
+    N, E, M = 200_000, 1_100_000, 128
+    adj = to_cuda_adj(workloads.random_graph(N, E))
+    y = workloads.node_states(N, M, seed=9).cuda()
+    plan = ops.build_plan(adj, N)
+    a1 = ops.gather_reduce(y, plan, M, "sum")
+    np.testing.assert_array_equal(ops.gather_reduce(2 * y, plan, M, "sum").cpu().numpy(), (2 * a1).cpu().numpy())
+    y2 = workloads.node_states(N, M, seed=10).cuda()
+    a12 = ops.gather_reduce(y + y2, plan, M, "sum")
+    a2 = ops.gather_reduce(y2, plan, M, "sum")
+    assert float((a12 - (a1 + a2)).abs().max()) < 1e-4
+    total = a1.double().sum(0).cpu()
+    want = y.double().index_select(0, adj[0][0]).sum(0).cpu()
+    np.testing.assert_allclose(total.numpy(), want.numpy(), rtol=1e-9, atol=1e-6)
+    perm = torch.randperm(E, device="cuda")
+    plan_p = ops.build_plan([(adj[0][0][perm], adj[0][1][perm])], N)
+    np.testing.assert_array_equal(ops.gather_reduce(y, plan, M, "max").cpu().numpy(),
+                                  ops.gather_reduce(y, plan_p, M, "max").cpu().numpy())
+    # empty segments are exactly 0 in every mode
+    deg = (plan.rowptr[1:] - plan.rowptr[:-1])
+    empty = (deg == 0).nonzero().flatten()
+    assert empty.numel() > 0
+    for r in ("sum", "mean", "max", "min"):
+        assert float(ops.gather_reduce(y, plan, M, r)[empty].abs().sum()) == 0.0
