@@ -9,7 +9,7 @@ import threading
 import torch  # noqa: F401  (must be imported first: the library binds to torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libptgnn_amd.so")
+LIB_PATH = os.environ.get("PTGNN_AMD_LIB") or os.path.join(_HERE, "csrc", "libptgnn_amd.so")
 
 _c = ctypes
 _i64, _i32, _vp, _f32 = _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_float

@@ -4,15 +4,24 @@
 //   ptgnn_amd_gru_cell_f32 : h' = GRUCell(a, h), gate GEMMs + gate math in one kernel
 // Contracts + reference lines: include/ptgnn_amd.h.
 //
-// Tiling (per 256-thread workgroup = 4 waves, one per SIMD):
-//   linear: 128 x 128 output tile, K in chunks of 32 through LDS (row stride 33 floats ->
-//           conflict-free ds_read_b32 for both MFMA operands), each wave owns 64 x 64 =
-//           2 x 2 MFMA tiles (64 accumulator VGPRs); next chunk's global loads are issued before
-//           the current chunk's MFMAs (register-staged software pipeline).
+// Both kernels are PERSISTENT: one 256-thread workgroup (4 waves = one per SIMD) per CU walks a
+// static, XCD-aware sequence of output tiles.  The K-chunks of consecutive tiles form ONE flat
+// software pipeline (global loads two chunks ahead in registers, LDS double-buffered one chunk
+// ahead, one barrier per chunk), so tile boundaries have no load bubble and a tile's epilogue
+// stores drain under the next tile's MFMAs.  Why: the r01a ablation (profiles/r01_notes.md)
+// showed a one-tile-per-block kernel serialises load / MFMA / store phases -- co-resident blocks
+// run in lockstep -- and reaches only ~75 TFLOP/s at K = 128.
+//   linear: 128 x 128 output tile, K chunks of 32 (LDS row stride 33 floats -> conflict-free
+//           ds_read_b32 for both MFMA operands); each wave owns 64 x 64 = 2 x 2 MFMA tiles.
 //   gru   : 128 rows x 32 state features; each wave owns 32 rows and FOUR 32x32 accumulators
 //           (r, z, i_n, h_n) whose C-fragment maps coincide, so the gate math is per-lane
-//           register arithmetic in the epilogue and the [n, 3H] gate matrices never exist.
+//           register arithmetic in the epilogue and the [n, 3H] gate matrices never exist; the
+//           previous state h needed by the epilogue is picked out of the LDS operand tile.
 // fp32 MFMA is 1/16 of the bf16 rate, so LDS/global traffic is far from limiting: MFMA-bound.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace ptgnn_amd {
@@ -23,102 +32,312 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 1;
 
-// Stage a [ROWS x 32] K-chunk of a row-major matrix into registers (ROWS*32/256 floats/thread).
-// RowMap maps tile row -> matrix row (or -1 for "zero row").
+// Stage a [ROWS x 32] K-chunk of a row-major matrix through registers into LDS, one float4 "part"
+// at a time so the traffic can be threaded between MFMAs.  RowMap maps tile row -> matrix row and
+// CLAMPS it into range: out-of-range tile rows read some valid row instead of being predicated,
+// because a branch around a load makes hipcc's waitcnt pass fall back to vmcnt(0) drains.  Such
+// rows only feed output rows/columns that are never stored.  The K tail must be exact, so chunk
+// columns >= K are zeroed on the way into LDS.
 template <int ROWS, bool ALIGNED, typename RowMap>
 struct Stager {
   static constexpr int NV4 = ROWS * BK / 4 / 256;  // float4 per thread
   float4 v[NV4];
+  int kvalid;  // how many of this thread's 4 chunk columns are < K (0..4)
 
-  __device__ __forceinline__ void load(const float *__restrict__ base, int64_t ld, int k0, int K,
-                                       RowMap rm) {
-#pragma unroll
-    for (int r = 0; r < NV4; ++r) {
-      const int f = threadIdx.x + r * 256;
-      const int row = f >> 3, c4 = (f & 7) * 4;
-      const int64_t mrow = rm(row);
-      const int kk = k0 + c4;
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mrow >= 0) {
-        const float *p = base + mrow * ld + kk;
-        if (ALIGNED) {
-          if (kk < K) t = *reinterpret_cast<const float4 *>(p);  // K % 4 == 0 => whole float4 valid
-        } else {
-          if (kk + 0 < K) t.x = p[0];
-          if (kk + 1 < K) t.y = p[1];
-          if (kk + 2 < K) t.z = p[2];
-          if (kk + 3 < K) t.w = p[3];
-        }
-      }
+  __device__ __forceinline__ void load_part(const float *__restrict__ base, int64_t ld, int k0, int K,
+                                            RowMap rm, int r) {
+    const int f = threadIdx.x + r * 256;
+    const int row = f >> 3, c4 = (f & 7) * 4;
+    const int64_t mrow = rm(row);
+    const int kk = k0 + c4;
+    kvalid = K - kk;
+    if (ALIGNED) {
+      // K % 4 == 0: a float4 is entirely valid or entirely past the end
+      const int kc = kk < K ? kk : 0;
+      v[r] = *reinterpret_cast<const float4 *>(base + mrow * ld + kc);
+    } else {
+      const float *p = base + mrow * ld;
+      float4 t;
+      t.x = p[kk + 0 < K ? kk + 0 : 0];
+      t.y = p[kk + 1 < K ? kk + 1 : 0];
+      t.z = p[kk + 2 < K ? kk + 2 : 0];
+      t.w = p[kk + 3 < K ? kk + 3 : 0];
       v[r] = t;
     }
   }
 
+  __device__ __forceinline__ void store_part(float *__restrict__ lds, int r) const {
+    const int f = threadIdx.x + r * 256;
+    const int row = f >> 3, c4 = (f & 7) * 4;
+    float *q = lds + row * LDS_LD + c4;
+    q[0] = kvalid > 0 ? v[r].x : 0.f;
+    q[1] = kvalid > 1 ? v[r].y : 0.f;
+    q[2] = kvalid > 2 ? v[r].z : 0.f;
+    q[3] = kvalid > 3 ? v[r].w : 0.f;
+  }
+
+  __device__ __forceinline__ void load(const float *__restrict__ base, int64_t ld, int k0, int K, RowMap rm) {
+#pragma unroll
+    for (int r = 0; r < NV4; ++r) load_part(base, ld, k0, K, rm, r);
+  }
+
   __device__ __forceinline__ void store(float *__restrict__ lds) const {
 #pragma unroll
-    for (int r = 0; r < NV4; ++r) {
-      const int f = threadIdx.x + r * 256;
-      const int row = f >> 3, c4 = (f & 7) * 4;
-      float *q = lds + row * LDS_LD + c4;
-      q[0] = v[r].x; q[1] = v[r].y; q[2] = v[r].z; q[3] = v[r].w;
-    }
+    for (int r = 0; r < NV4; ++r) store_part(lds, r);
   }
 };
 
-struct RowClamp {  // plain matrices: tile row -> base_row + row if < limit
+struct RowClamp {  // plain matrices: tile row -> min(base_row + row, limit - 1)
   int64_t base, limit;
   __device__ __forceinline__ int64_t operator()(int row) const {
     const int64_t r = base + row;
-    return r < limit ? r : -1;
+    return r < limit ? r : limit - 1;
   }
 };
 
-struct GateRows {  // GRU weights: tile row (gate*32 + jj) -> gate*H + j0 + jj
+struct GateRows {  // GRU weights: tile row (gate*32 + jj) -> gate*H + min(j0 + jj, H - 1)
   int j0, H;
   __device__ __forceinline__ int64_t operator()(int row) const {
     const int gate = row >> 5, j = j0 + (row & 31);
-    return j < H ? (int64_t)gate * H + j : -1;
+    return (int64_t)gate * H + (j < H ? j : H - 1);
   }
 };
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-  if (act == PTGNN_AMD_ACT_TANH) return tanhf(v);
-  if (act == PTGNN_AMD_ACT_RELU) return v > 0.f ? v : 0.f;
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would stall
+// every K-chunk on the prefetch loads still in flight and on the previous tile's epilogue stores
+// (cdna_hip_programming.md section 5: "the ~20% stall").  The staged global loads are ordered by
+// the register dependence of the ds_write that consumes them (compiler-counted vmcnt(N)).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_apply(float v) {
+  if constexpr (ACT == PTGNN_AMD_ACT_TANH) return tanhf(v);
+  if constexpr (ACT == PTGNN_AMD_ACT_RELU) return v > 0.f ? v : 0.f;
   return v;
 }
+
+// Epilogue staging: a wave parks a 32 x 64 slab of its C fragments in LDS (row stride 68 floats:
+// conflict-free ds_write_b32 in the MFMA C layout, 16-B aligned rows for ds_read_b128) and streams
+// it out as float4 rows -- 256 contiguous bytes per row.
+constexpr int TILE_FLOATS = 128 * LDS_LD;
+
+// Static tile schedule of a persistent grid: block b walks tiles first(b), first(b)+G, ... where
+// first() keeps consecutive tiles on one XCD (b % 8 is the XCD the dispatcher is observed to use).
+__constant__ int num_compute_units_dev = 256;
+
+struct TileWalk {
+  uint32_t first, stride, num_tiles;
+  __device__ __forceinline__ TileWalk(uint32_t ntiles) {
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    first = (G % kNumXcd == 0) ? (b % kNumXcd) * (G / kNumXcd) + b / kNumXcd : b;
+    stride = G;
+    num_tiles = ntiles;
+  }
+  __device__ __forceinline__ uint32_t count() const {
+    return first < num_tiles ? (num_tiles - first + stride - 1) / stride : 0;
+  }
+};
+
+// (row tile, col tile) of the i-th tile of this block, recomputed only when a cursor crosses a tile
+// boundary (one 32-bit division per tile instead of 64-bit divisions per K-chunk).
+struct TileCursor {
+  uint32_t tile, row_tile, col_tile;
+  int chunk;
+  __device__ __forceinline__ void set(uint32_t t, uint32_t col_tiles) {
+    tile = t;
+    row_tile = t / col_tiles;
+    col_tile = t - row_tile * col_tiles;
+  }
+  __device__ __forceinline__ void init(const TileWalk &w, uint32_t col_tiles) { set(w.first, col_tiles); chunk = 0; }
+  __device__ __forceinline__ bool advance(const TileWalk &w, uint32_t col_tiles, int nchunks) {
+    if (++chunk < nchunks) return false;
+    chunk = 0;
+    set(tile + w.stride, col_tiles);
+    return true;  // crossed into the next tile
+  }
+};
 
 // ---------------------------------------------------------------------------------------------
 // linear
 // ---------------------------------------------------------------------------------------------
-template <bool ALIGNED>
-__global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ x, int64_t rows, int K,
-                                                   int64_t ld_x, const float *__restrict__ w,
-                                                   int n_out, const float *__restrict__ bias,
-                                                   int act, float *__restrict__ y, int64_t ld_y,
-                                                   int64_t row_tiles, int col_tiles) {
-  __shared__ float As[128 * LDS_LD];
-  __shared__ float Bs[128 * LDS_LD];
+// Persistent variant: `BPC` workgroups per CU walk a static tile sequence; single LDS operand
+// buffer (two LDS-only barriers per K-chunk), the NEXT chunk -- also across tile boundaries -- is
+// prefetched into registers under the MFMAs, and epilogue stores are never drained (no vmcnt(0)
+// anywhere in the loop), so a finished tile's stores retire under the next tile's MFMAs.
+// NJ = MFMA tiles per wave along N: the workgroup tile is 128 x (64 * NJ).
+template <bool ALIGNED, int ACT, int NJ>
+__global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear(
+    const float *__restrict__ x, int64_t rows, int K, int64_t ld_x, const float *__restrict__ w,
+    int n_out, const float *__restrict__ bias, float *__restrict__ y, int64_t ld_y,
+    int64_t num_tiles, int col_tiles, int vec_store, int stagger_sleeps) {
+  constexpr int BN = 64 * NJ;
+  constexpr int B_FLOATS = BN * LDS_LD;
+  constexpr int SLAB_LD = 32 * NJ + 4;
+  constexpr int SLAB_FLOATS = 32 * SLAB_LD;
+  constexpr int OPER = TILE_FLOATS + B_FLOATS;
+  constexpr int kLds = OPER > 4 * SLAB_FLOATS ? OPER : 4 * SLAB_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[kLds];
+  float *const As = smem, *const Bs = smem + TILE_FLOATS;
+  float *const slab = smem + (threadIdx.x >> 6) * SLAB_FLOATS;  // aliases the operand buffer
 
-  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  if (tile >= row_tiles * col_tiles) return;
-  const int64_t rt = tile / col_tiles;
-  const int ct = (int)(tile % col_tiles);
-  const int64_t row0 = rt * 128;
-  const int col0 = ct * 128;
+  // De-phase the workgroups that share a CU.  Identical tiles keep a persistent grid in global
+  // lockstep (every CU loads, then multiplies, then stores at the same time), which serialises the
+  // HBM time behind the MFMA time; a one-off start offset of 1/BPC of a tile period per co-resident
+  // slot spreads the store bursts under other workgroups' MFMAs.
+  {
+    const int slot = blockIdx.x / num_compute_units_dev;
+    for (int i = 0; i < slot * stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
+  const TileWalk walk((uint32_t)num_tiles);
+  const int nchunks = (K + BK - 1) / BK;
+  const int64_t total = (int64_t)walk.count() * nchunks;
+  if (total == 0) return;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, hi = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Stager<128, ALIGNED, RowClamp> sa, sb;
+  Stager<128, ALIGNED, RowClamp> sa;
+  Stager<BN, ALIGNED, RowClamp> sb;
+  TileCursor ld, cp;  // load cursor runs one chunk ahead of the compute cursor
+  ld.init(walk, col_tiles);
+  cp.init(walk, col_tiles);
+  int64_t ld_left = total;
+  auto issue_load = [&]() {  // past the end the cursor parks on the last chunk (harmless re-load)
+    sa.load(x, ld_x, ld.chunk * BK, K, RowClamp{(int64_t)ld.row_tile * 128, rows});
+    sb.load(w, K, ld.chunk * BK, K, RowClamp{(int64_t)ld.col_tile * BN, n_out});
+    if (--ld_left > 0) ld.advance(walk, col_tiles, nchunks);
+  };
+
+  issue_load();
+  for (int64_t g = 0; g < total; ++g) {
+    lds_barrier();  // everyone is done with the previous chunk's operands / its own epilogue slab
+    sa.store(As);
+    sb.store(Bs);
+    lds_barrier();
+    issue_load();   // chunk g+1 (possibly the first chunk of the next tile) lands under the MFMAs
+
+    const float *ap = As + (wm * 64 + li) * LDS_LD + hi;
+    const float *bp = Bs + (wn * 32 * NJ + li) * LDS_LD + hi;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float a[2], b[NJ];
+      a[0] = ap[ks * 2];
+      a[1] = ap[32 * LDS_LD + ks * 2];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + ks * 2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+
+    const int64_t row0 = (int64_t)cp.row_tile * 128;
+    const int col0 = (int)cp.col_tile * BN;
+    if (!cp.advance(walk, col_tiles, nchunks)) continue;
+
+    // ---- tile finished: C fragments -> LDS slab -> float4 rows (bias + act on the way) ----
+    lds_barrier();  // the slab aliases the operand buffer other waves may still be reading
+    constexpr int LPRW = 8 * NJ;             // lanes per output row (float4 each)
+    constexpr int RPI = 64 / LPRW;           // rows per wave-instruction
+    const int c4 = (lane % LPRW) * 4;
+    const int rsub = lane / LPRW;
+    const int gcol = col0 + wn * 32 * NJ + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) {
+      if (gcol + 0 < n_out) bv.x = bias[gcol + 0];
+      if (gcol + 1 < n_out) bv.y = bias[gcol + 1];
+      if (gcol + 2 < n_out) bv.z = bias[gcol + 2];
+      if (gcol + 3 < n_out) bv.w = bias[gcol + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // C fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
+          acc[i][j][r] = 0.f;
+        }
+      __builtin_amdgcn_wave_barrier();  // slab is wave-private; DS ops of a wave execute in order
+      const int64_t rbase = row0 + wm * 64 + i * 32;
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int rl = it * RPI + rsub;
+        const int64_t grow = rbase + rl;
+        float4 v = *reinterpret_cast<const float4 *>(slab + rl * SLAB_LD + c4);
+        v.x = act_apply<ACT>(v.x + bv.x);
+        v.y = act_apply<ACT>(v.y + bv.y);
+        v.z = act_apply<ACT>(v.z + bv.z);
+        v.w = act_apply<ACT>(v.w + bv.w);
+        if (grow < rows) {
+          float *dst = y + grow * ld_y + gcol;
+          if (vec_store && gcol + 3 < n_out) {
+            *reinterpret_cast<float4 *>(dst) = v;
+          } else {
+            if (gcol + 0 < n_out) dst[0] = v.x;
+            if (gcol + 1 < n_out) dst[1] = v.y;
+            if (gcol + 2 < n_out) dst[2] = v.z;
+            if (gcol + 3 < n_out) dst[3] = v.w;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// linear, one tile per workgroup (occupancy-driven variant): single LDS buffer, two barriers per
+// K-chunk, next chunk prefetched into registers under the MFMAs; latency is hidden by 3-5
+// co-resident workgroups per CU and the hardware dispatcher balances the tail.
+// ---------------------------------------------------------------------------------------------
+template <bool ALIGNED, int ACT, int NJ>
+__global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
+    const float *__restrict__ x, int64_t rows, int K, int64_t ld_x, const float *__restrict__ w,
+    int n_out, const float *__restrict__ bias, float *__restrict__ y, int64_t ld_y,
+    int64_t num_tiles, int col_tiles, int vec_store) {
+  constexpr int BN = 64 * NJ;
+  constexpr int B_FLOATS = BN * LDS_LD;
+  constexpr int SLAB_LD = 32 * NJ + 4;
+  constexpr int SLAB_FLOATS = 32 * SLAB_LD;
+  constexpr int OPER = TILE_FLOATS + B_FLOATS;
+  constexpr int kLds = OPER > 4 * SLAB_FLOATS ? OPER : 4 * SLAB_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[kLds];
+  float *const As = smem, *const Bs = smem + TILE_FLOATS;
+
+  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile >= num_tiles) return;
+  const int64_t row0 = (tile / col_tiles) * 128;
+  const int col0 = (int)(tile % col_tiles) * BN;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hi = lane >> 5;
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Stager<128, ALIGNED, RowClamp> sa;
+  Stager<BN, ALIGNED, RowClamp> sb;
   const RowClamp ra{row0, rows}, rb{col0, n_out};
   const int nchunks = (K + BK - 1) / BK;
   sa.load(x, ld_x, 0, K, ra);
@@ -133,32 +352,215 @@ __global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ x, 
       sb.load(w, K, (c + 1) * BK, K, rb);
     }
     const float *ap = As + (wm * 64 + li) * LDS_LD + hi;
-    const float *bp = Bs + (wn * 64 + li) * LDS_LD + hi;
+    const float *bp = Bs + (wn * 32 * NJ + li) * LDS_LD + hi;
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      const float a0 = ap[ks * 2], a1 = ap[32 * LDS_LD + ks * 2];
-      const float b0 = bp[ks * 2], b1 = bp[32 * LDS_LD + ks * 2];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float a[2], b[NJ];
+      a[0] = ap[ks * 2];
+      a[1] = ap[32 * LDS_LD + ks * 2];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + ks * 2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
 
-  // C fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  __syncthreads();  // operand buffers are reused as the epilogue slabs
+  float *const slab = smem + wave * SLAB_FLOATS;
+  constexpr int LPRW = 8 * NJ;             // lanes per output row (float4 each)
+  constexpr int RPI = 64 / LPRW;           // rows per wave-instruction
+  const int c4 = (lane % LPRW) * 4;
+  const int rsub = lane / LPRW;
+  const int gcol = col0 + wn * 32 * NJ + c4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) {
+    if (gcol + 0 < n_out) bv.x = bias[gcol + 0];
+    if (gcol + 1 < n_out) bv.y = bias[gcol + 1];
+    if (gcol + 2 < n_out) bv.z = bias[gcol + 2];
+    if (gcol + 3 < n_out) bv.w = bias[gcol + 3];
+  }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = col0 + wn * 64 + j * 32 + li;
-    if (col >= n_out) continue;
-    const float bv = bias ? bias[col] : 0.f;
+  for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < rows) y[row * ld_y + col] = act_apply(acc[i][j][r] + bv, act);
+      for (int r = 0; r < 16; ++r)
+        slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+    const int64_t rbase = row0 + wm * 64 + i * 32;
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int rl = it * RPI + rsub;
+      const int64_t grow = rbase + rl;
+      float4 v = *reinterpret_cast<const float4 *>(slab + rl * SLAB_LD + c4);
+      v.x = act_apply<ACT>(v.x + bv.x);
+      v.y = act_apply<ACT>(v.y + bv.y);
+      v.z = act_apply<ACT>(v.z + bv.z);
+      v.w = act_apply<ACT>(v.w + bv.w);
+      if (grow < rows) {
+        float *dst = y + grow * ld_y + gcol;
+        if (vec_store && gcol + 3 < n_out) {
+          *reinterpret_cast<float4 *>(dst) = v;
+        } else {
+          if (gcol + 0 < n_out) dst[0] = v.x;
+          if (gcol + 1 < n_out) dst[1] = v.y;
+          if (gcol + 2 < n_out) dst[2] = v.z;
+          if (gcol + 3 < n_out) dst[3] = v.w;
+        }
       }
     }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// linear, barrier-free variant: every wave stages ITS OWN operands (A 64 x 32, B 32NJ x 32 per
+// K-chunk) into a wave-private LDS region, so there is no s_barrier anywhere and the waves of a CU
+// are fully decoupled pipelines (a wave's LDS ops execute in order, which is all the ordering the
+// write -> read -> overwrite cycle needs).  Costs 2x the L2->LDS staging traffic of the shared-tile
+// kernels (A is staged by both column-waves, B by both row-waves; the duplicate mostly hits the
+// CU's vector L1) in exchange for removing the barrier convoys that hold the shared-tile variants
+// at ~57 % MFMA-busy (profiles/r01_notes.md).
+// ---------------------------------------------------------------------------------------------
+template <bool ALIGNED, int ACT, int NJ>
+__global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void k_linear_wp(
+    const float *__restrict__ x, int64_t rows, int K, int64_t ld_x, const float *__restrict__ w,
+    int n_out, const float *__restrict__ bias, float *__restrict__ y, int64_t ld_y,
+    int64_t num_tiles, int col_tiles, int vec_store) {
+  constexpr int BN = 64 * NJ;                 // workgroup tile 128 x BN, wave tile 64 x 32NJ
+  constexpr int WA = 64 * LDS_LD, WB = 32 * NJ * LDS_LD;
+  constexpr int SLAB_LD = 32 * NJ + 4;
+  static_assert(32 * SLAB_LD <= WA + WB, "epilogue slab must fit the wave's operand region");
+  __shared__ __attribute__((aligned(16))) float smem[4 * (WA + WB)];
+
+  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile >= num_tiles) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hi = lane >> 5;
+  const int64_t row0 = (tile / col_tiles) * 128 + wm * 64;      // this WAVE's tile origin
+  const int col0 = (int)(tile % col_tiles) * BN + wn * 32 * NJ;
+  float *const As = smem + wave * (WA + WB), *const Bs = As + WA;
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane staging: part r covers tile row (lane + 64 r) >> 3, columns ((lane & 7) * 4 ..+3)
+  constexpr int PA = 8, PB = 4 * NJ;
+  float4 ra[PA], rb[PB];
+  const int srow = lane >> 3, sc4 = (lane & 7) * 4;
+  auto load_chunk = [&](int k0) {
+    const int kk = k0 + sc4;
+    const int kc = kk < K ? kk : 0;  // ALIGNED: a float4 is entirely inside or outside K
+#pragma unroll
+    for (int r = 0; r < PA; ++r) {
+      int64_t gr = row0 + srow + r * 8;
+      gr = gr < rows ? gr : rows - 1;
+      const float *p = x + gr * ld_x;
+      if (ALIGNED) ra[r] = *reinterpret_cast<const float4 *>(p + kc);
+      else ra[r] = make_float4(p[kk + 0 < K ? kk + 0 : 0], p[kk + 1 < K ? kk + 1 : 0],
+                               p[kk + 2 < K ? kk + 2 : 0], p[kk + 3 < K ? kk + 3 : 0]);
+    }
+#pragma unroll
+    for (int r = 0; r < PB; ++r) {
+      int gc = col0 + srow + r * 8;
+      gc = gc < n_out ? gc : n_out - 1;
+      const float *p = w + (int64_t)gc * K;
+      if (ALIGNED) rb[r] = *reinterpret_cast<const float4 *>(p + kc);
+      else rb[r] = make_float4(p[kk + 0 < K ? kk + 0 : 0], p[kk + 1 < K ? kk + 1 : 0],
+                               p[kk + 2 < K ? kk + 2 : 0], p[kk + 3 < K ? kk + 3 : 0]);
+    }
+  };
+  auto store_chunk = [&](int k0) {
+    const int kv = K - (k0 + sc4);  // zero the K tail exactly
+#pragma unroll
+    for (int r = 0; r < PA; ++r) {
+      float *q = As + (srow + r * 8) * LDS_LD + sc4;
+      q[0] = kv > 0 ? ra[r].x : 0.f; q[1] = kv > 1 ? ra[r].y : 0.f;
+      q[2] = kv > 2 ? ra[r].z : 0.f; q[3] = kv > 3 ? ra[r].w : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < PB; ++r) {
+      float *q = Bs + (srow + r * 8) * LDS_LD + sc4;
+      q[0] = kv > 0 ? rb[r].x : 0.f; q[1] = kv > 1 ? rb[r].y : 0.f;
+      q[2] = kv > 2 ? rb[r].z : 0.f; q[3] = kv > 3 ? rb[r].w : 0.f;
+    }
+  };
+
+  const int nchunks = (K + BK - 1) / BK;
+  load_chunk(0);
+  const float *ap = As + li * LDS_LD + hi;
+  const float *bp = Bs + li * LDS_LD + hi;
+  for (int c = 0; c < nchunks; ++c) {
+    store_chunk(c * BK);                       // in-order LDS: lands after the previous chunk's reads
+    __builtin_amdgcn_wave_barrier();
+    load_chunk((c + 1 < nchunks ? c + 1 : c) * BK);   // next chunk in flight under the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float a[2], b[NJ];
+      a[0] = ap[ks * 2];
+      a[1] = ap[32 * LDS_LD + ks * 2];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + ks * 2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- epilogue through the wave's own LDS region (no barrier) ----
+  float *const slab = As;
+  constexpr int LPRW = 8 * NJ, RPI = 64 / LPRW;
+  const int c4 = (lane % LPRW) * 4, rsub = lane / LPRW;
+  const int gcol = col0 + c4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) {
+    if (gcol + 0 < n_out) bv.x = bias[gcol + 0];
+    if (gcol + 1 < n_out) bv.y = bias[gcol + 1];
+    if (gcol + 2 < n_out) bv.z = bias[gcol + 2];
+    if (gcol + 3 < n_out) bv.w = bias[gcol + 3];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int rl = it * RPI + rsub;
+      const int64_t grow = row0 + i * 32 + rl;
+      float4 v = *reinterpret_cast<const float4 *>(slab + rl * SLAB_LD + c4);
+      v.x = act_apply<ACT>(v.x + bv.x);
+      v.y = act_apply<ACT>(v.y + bv.y);
+      v.z = act_apply<ACT>(v.z + bv.z);
+      v.w = act_apply<ACT>(v.w + bv.w);
+      if (grow < rows) {
+        float *dst = y + grow * ld_y + gcol;
+        if (vec_store && gcol + 3 < n_out) {
+          *reinterpret_cast<float4 *>(dst) = v;
+        } else {
+          if (gcol + 0 < n_out) dst[0] = v.x;
+          if (gcol + 1 < n_out) dst[1] = v.y;
+          if (gcol + 2 < n_out) dst[2] = v.z;
+          if (gcol + 3 < n_out) dst[3] = v.w;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -175,29 +577,28 @@ __global__ __launch_bounds__(256, 2) void k_gru(const float *__restrict__ a, int
                                                 const float *__restrict__ b_ih,
                                                 const float *__restrict__ b_hh, int64_t n, int M,
                                                 int H, float *__restrict__ out, int64_t ld_out,
-                                                int64_t row_tiles, int col_tiles) {
-  __shared__ float As[128 * LDS_LD];
-  __shared__ float Bs[96 * LDS_LD];
+                                                int64_t num_tiles, int col_tiles) {
+  constexpr int B_FLOATS = 96 * LDS_LD;
+  __shared__ __attribute__((aligned(16))) float smem[TILE_FLOATS + B_FLOATS];
+  float *const As = smem, *const Bs = smem + TILE_FLOATS;
 
   const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  if (tile >= row_tiles * col_tiles) return;
-  const int64_t rt = tile / col_tiles;
-  const int ct = (int)(tile % col_tiles);
-  const int64_t row0 = rt * 128;
-  const int j0 = ct * 32;
+  if (tile >= num_tiles) return;
+  const int64_t row0 = (tile / col_tiles) * 128;
+  const int j0 = (int)(tile % col_tiles) * 32;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, hi = lane >> 5;
 
   f32x16 acc_r, acc_z, acc_in, acc_hn;
+  float hprev[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_in[r] = 0.f; acc_hn[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_in[r] = 0.f; acc_hn[r] = 0.f; hprev[r] = 0.f; }
 
   Stager<128, ALIGNED, RowClamp> sa;
   Stager<96, ALIGNED, GateRows> sb;
   const RowClamp ra{row0, n};
   const GateRows rg{j0, H};
-
   // phase 0: K over the aggregated messages (a, W_ih) -> r, z, i_n
   // phase 1: K over the previous state     (h, W_hh) -> r, z, h_n
   const int chunks0 = (M + BK - 1) / BK, chunks1 = (H + BK - 1) / BK;
@@ -218,7 +619,8 @@ __global__ __launch_bounds__(256, 2) void k_gru(const float *__restrict__ a, int
     sb.store(Bs);
     __syncthreads();
     if (c + 1 < total) issue(c + 1);
-    const float *ap = As + (wave * 32 + li) * LDS_LD + hi;
+    const float *arow = As + (wave * 32) * LDS_LD;
+    const float *ap = arow + li * LDS_LD + hi;
     const float *bp = Bs + li * LDS_LD + hi;
     if (c < chunks0) {
 #pragma unroll
@@ -230,6 +632,12 @@ __global__ __launch_bounds__(256, 2) void k_gru(const float *__restrict__ a, int
         acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bn, acc_in, 0, 0, 0);
       }
     } else {
+      if ((c - chunks0) * BK == j0) {
+        // this K-chunk of h IS h[rows, j0 .. j0+31]: keep the epilogue's h values (C layout)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          hprev[r] = arow[((r & 3) + 8 * (r >> 2) + 4 * hi) * LDS_LD + li];
+      }
 #pragma unroll
       for (int ks = 0; ks < BK / 2; ++ks) {
         const float av = ap[ks * 2];
@@ -241,6 +649,7 @@ __global__ __launch_bounds__(256, 2) void k_gru(const float *__restrict__ a, int
     }
   }
 
+  // ---- gate math in registers (the four C fragments share one lane->element map) ----
   const int j = j0 + li;
   if (j >= H) return;
   const float bir = b_ih[j], biz = b_ih[H + j], bin = b_ih[2 * H + j];
@@ -248,17 +657,68 @@ __global__ __launch_bounds__(256, 2) void k_gru(const float *__restrict__ a, int
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-    if (row >= n) continue;
     // torch.nn.GRUCell: gi = W_ih x + b_ih, gh = W_hh h + b_hh
     const float rg_ = sigmoidf_((acc_r[r] + bir) + bhr);
     const float zg = sigmoidf_((acc_z[r] + biz) + bhz);
     const float ng = tanhf((acc_in[r] + bin) + rg_ * (acc_hn[r] + bhn));
-    const float hv = h[row * ld_h + j];
-    out[row * ld_out + j] = (1.0f - zg) * ng + zg * hv;
+    if (row < n) out[row * ld_out + j] = (1.0f - zg) * ng + zg * hprev[r];
   }
 }
 
 }  // namespace
+
+int num_compute_units() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// tuning knobs (developer experiments; defaults are what profiles/ measured best):
+//   PTGNN_AMD_LINEAR_NJ=1|2   tile 128x64 | 128x128          (default: by n_out)
+//   PTGNN_AMD_LINEAR_MODE=0|1|2  one-shot shared tile | persistent | wave-private staging
+static int linear_nj() {  // 0 = heuristic
+  static int nj = -1;
+  if (nj < 0) {
+    const char *e = getenv("PTGNN_AMD_LINEAR_NJ");
+    nj = e ? atoi(e) : 0;
+    if (nj < 0 || nj > 2) nj = 0;
+  }
+  return nj;
+}
+
+static int linear_bpc(int nj) {
+  static int v = 0;
+  if (v == 0) {
+    const char *e = getenv("PTGNN_AMD_LINEAR_BPC");
+    v = e ? atoi(e) : 0;
+    if (v <= 0) v = -1;
+  }
+  return v > 0 ? v : (nj == 1 ? 4 : 3);
+}
+
+static int linear_mode() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("PTGNN_AMD_LINEAR_MODE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+// persistent grid: `per_cu` workgroups per CU (LDS-limited), a multiple of the XCD count
+static unsigned persistent_grid(int64_t num_tiles, int per_cu = 1) {
+  int64_t g = (int64_t)num_compute_units() * per_cu;
+  if (num_tiles < g) g = num_tiles;
+  g = (g + kNumXcd - 1) / kNumXcd * kNumXcd;
+  return (unsigned)g;
+}
+
 }  // namespace ptgnn_amd
 
 using namespace ptgnn_amd;
@@ -270,17 +730,46 @@ extern "C" int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int
   PTGNN_REQUIRE(act >= 0 && act <= PTGNN_AMD_ACT_RELU, PTGNN_AMD_EINVAL, "linear: bad act");
   if (rows == 0) return PTGNN_AMD_OK;
   PTGNN_REQUIRE(x && w && y && ld_x >= k && ld_y >= n_out, PTGNN_AMD_EINVAL, "linear: null/ld");
+  int nj = linear_nj();
+  if (nj == 0) nj = n_out <= 128 ? 1 : 2;  // narrow outputs: finer tiles, more workgroups per CU
+  const int bn = 64 * nj;
   const int64_t row_tiles = (rows + 127) / 128;
-  const int col_tiles = (n_out + 127) / 128;
-  const int64_t nblk = xcd_padded_blocks(row_tiles * col_tiles);
-  PTGNN_REQUIRE(nblk < ((int64_t)1 << 31), PTGNN_AMD_EUNSUPPORTED, "linear: grid too large");
+  const int col_tiles = (n_out + bn - 1) / bn;
+  const int64_t num_tiles = row_tiles * col_tiles;
+  PTGNN_REQUIRE(num_tiles < ((int64_t)1 << 31), PTGNN_AMD_EUNSUPPORTED, "linear: too many tiles");
+  const int mode = linear_mode();  // 0 shared-tile one-shot, 1 persistent, 2 wave-private staging
+  const bool persistent = mode == 1;
+  const unsigned grid = persistent ? persistent_grid(num_tiles, linear_bpc(nj))
+                                   : (unsigned)xcd_padded_blocks(num_tiles);
   const bool al = (k % 4 == 0) && (ld_x % 4 == 0) && aligned16(x) && aligned16(w);
-  if (al)
-    k_linear<true><<<(unsigned)nblk, 256, 0, (hipStream_t)stream_>>>(x, rows, k, ld_x, w, n_out, bias,
-                                                                     act, y, ld_y, row_tiles, col_tiles);
-  else
-    k_linear<false><<<(unsigned)nblk, 256, 0, (hipStream_t)stream_>>>(x, rows, k, ld_x, w, n_out, bias,
-                                                                      act, y, ld_y, row_tiles, col_tiles);
+  const int vec_store = (ld_y % 4 == 0) && aligned16(y);
+  hipStream_t st = (hipStream_t)stream_;
+  // start offset per co-resident slot: one tile's own MFMA time, in s_sleep(127) units (8128 clk)
+  const char *sg = getenv("PTGNN_AMD_LINEAR_STAGGER");
+  const int chunk_clk = nj == 1 ? 2048 : 4096;
+  const int stagger = (sg && atoi(sg) == 0) ? 0 : (int)(((int64_t)((k + 31) / 32) * chunk_clk + 4064) / 8128);
+#define PTGNN_LINEAR_LAUNCH(AL, ACT, NJ)                                                       \
+  do {                                                                                         \
+    if (persistent)                                                                            \
+      k_linear<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y, ld_y,   \
+                                                  num_tiles, col_tiles, vec_store, stagger);   \
+    else if (mode == 2)                                                                        \
+      k_linear_wp<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y,      \
+                                                     ld_y, num_tiles, col_tiles, vec_store);   \
+    else                                                                                       \
+      k_linear_tlp<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y,     \
+                                                      ld_y, num_tiles, col_tiles, vec_store);  \
+  } while (0)
+#define PTGNN_LINEAR_ACT(AL, NJ)                                                          \
+  do {                                                                                    \
+    if (act == PTGNN_AMD_ACT_TANH) PTGNN_LINEAR_LAUNCH(AL, PTGNN_AMD_ACT_TANH, NJ);       \
+    else if (act == PTGNN_AMD_ACT_RELU) PTGNN_LINEAR_LAUNCH(AL, PTGNN_AMD_ACT_RELU, NJ);  \
+    else PTGNN_LINEAR_LAUNCH(AL, PTGNN_AMD_ACT_NONE, NJ);                                 \
+  } while (0)
+  if (al) { if (nj == 1) PTGNN_LINEAR_ACT(true, 1); else PTGNN_LINEAR_ACT(true, 2); }
+  else    { if (nj == 1) PTGNN_LINEAR_ACT(false, 1); else PTGNN_LINEAR_ACT(false, 2); }
+#undef PTGNN_LINEAR_ACT
+#undef PTGNN_LINEAR_LAUNCH
   PTGNN_LAUNCH_CHECK();
   return PTGNN_AMD_OK;
 }
@@ -296,16 +785,17 @@ extern "C" int ptgnn_amd_gru_cell_f32(const float *a, int64_t ld_a, const float 
   PTGNN_REQUIRE(out != h, PTGNN_AMD_EINVAL, "gru_cell: in-place update is not supported");
   const int64_t row_tiles = (n + 127) / 128;
   const int col_tiles = (hd + 31) / 32;
-  const int64_t nblk = xcd_padded_blocks(row_tiles * col_tiles);
-  PTGNN_REQUIRE(nblk < ((int64_t)1 << 31), PTGNN_AMD_EUNSUPPORTED, "gru_cell: grid too large");
+  const int64_t num_tiles = row_tiles * col_tiles;
+  PTGNN_REQUIRE(num_tiles < ((int64_t)1 << 31), PTGNN_AMD_EUNSUPPORTED, "gru_cell: too many tiles");
+  const unsigned grid = (unsigned)xcd_padded_blocks(num_tiles);
   const bool al = (m % 4 == 0) && (hd % 4 == 0) && (ld_a % 4 == 0) && (ld_h % 4 == 0) &&
                   aligned16(a) && aligned16(h) && aligned16(w_ih) && aligned16(w_hh);
   if (al)
-    k_gru<true><<<(unsigned)nblk, 256, 0, (hipStream_t)stream_>>>(a, ld_a, h, ld_h, w_ih, w_hh, b_ih, b_hh,
-                                                                  n, m, hd, out, ld_out, row_tiles, col_tiles);
+    k_gru<true><<<grid, 256, 0, (hipStream_t)stream_>>>(a, ld_a, h, ld_h, w_ih, w_hh, b_ih, b_hh, n, m, hd,
+                                                        out, ld_out, num_tiles, col_tiles);
   else
-    k_gru<false><<<(unsigned)nblk, 256, 0, (hipStream_t)stream_>>>(a, ld_a, h, ld_h, w_ih, w_hh, b_ih, b_hh,
-                                                                   n, m, hd, out, ld_out, row_tiles, col_tiles);
+    k_gru<false><<<grid, 256, 0, (hipStream_t)stream_>>>(a, ld_a, h, ld_h, w_ih, w_hh, b_ih, b_hh, n, m, hd,
+                                                         out, ld_out, num_tiles, col_tiles);
   PTGNN_LAUNCH_CHECK();
   return PTGNN_AMD_OK;
 }
