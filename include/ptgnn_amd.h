@@ -72,14 +72,16 @@ const char *ptgnn_amd_last_error(void);
  *         order, i.e. the sort is STABLE so fp32 sums fold in the same order as the CPU path):
  *           col[i]  = (src << type_bits) | edge_type     (type_bits = ceil(log2(num_types)))
  *           perm[i] = position of the edge in the type-major concatenation (nullable)
- * Requires num_nodes << type_bits < 2^31 and num_edges < 2^31, else EUNSUPPORTED.
+ * `num_src_rows` = number of rows of the table the sources index (0 = num_nodes); it exceeds
+ * num_nodes for a dst-range shard whose sources include halo rows (ptgnn_amd/sharded.py).
+ * Requires num_src_rows << type_bits < 2^31 and num_edges < 2^31, else EUNSUPPORTED.
  * ---------------------------------------------------------------------------------------- */
 size_t ptgnn_amd_csr_workspace_bytes(int64_t num_edges, int64_t num_nodes);
 int ptgnn_amd_type_bits(int32_t num_types);
 int ptgnn_amd_csr_build(const int64_t *const *src_per_type, /* host [num_types] of device ptrs */
                         const int64_t *const *dst_per_type, /* host [num_types] of device ptrs */
                         const int64_t *edges_per_type,      /* host [num_types]                */
-                        int32_t num_types, int64_t num_nodes,
+                        int32_t num_types, int64_t num_nodes, int64_t num_src_rows,
                         int swap_src_dst, /* 1: build the transposed plan (rows = sources)     */
                         int32_t *rowptr, int32_t *col, int32_t *perm /* nullable */,
                         void *workspace, size_t workspace_bytes, void *stream);
@@ -105,13 +107,15 @@ int ptgnn_amd_validate_indices(const int64_t *idx, int64_t n, int64_t num_nodes,
  *   ysrc : [num_src_rows, ld_y] ; block t of M columns holds X W_t^T.  With type_bits == 0 and
  *          ld_y == M this is also the plain segment reduce of a materialised message matrix
  *          (col = perm), i.e. the torch_scatter seam itself.
- *   ydst : nullable, same layout, indexed by the DESTINATION node.
+ *   ydst : nullable, same column layout with its own leading dimension, indexed by the
+ *          DESTINATION node.
  *   argout: nullable int32 [num_nodes, M]; for max/min the winning CSR slot, -1 if empty
  *          (backward routing; torch_scatter's arg_out).
  *   ln_gamma/ln_beta: LayerNorm affine parameters (EPI_*LAYERNORM only).
  * ---------------------------------------------------------------------------------------- */
-int ptgnn_amd_gather_reduce_f32(const float *ysrc, const float *ydst /* nullable */,
-                                int64_t ld_y, const int32_t *rowptr, const int32_t *col,
+int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_ysrc,
+                                const float *ydst /* nullable */, int64_t ld_ydst,
+                                const int32_t *rowptr, const int32_t *col,
                                 int32_t type_bits, int64_t num_nodes, int32_t msg_dim,
                                 int reduce, int epilogue, const float *ln_gamma,
                                 const float *ln_beta, float ln_eps, float *out, int64_t ld_out,

@@ -141,7 +141,8 @@ extern "C" size_t ptgnn_amd_csr_workspace_bytes(int64_t num_edges, int64_t num_n
 extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
                                    const int64_t *const *dst_per_type,
                                    const int64_t *edges_per_type, int32_t num_types,
-                                   int64_t num_nodes, int swap_src_dst, int32_t *rowptr,
+                                   int64_t num_nodes, int64_t num_src_rows, int swap_src_dst,
+                                   int32_t *rowptr,
                                    int32_t *col, int32_t *perm, void *workspace,
                                    size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -157,10 +158,11 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
     num_edges += edges_per_type[t];
   }
   const int type_bits = ptgnn_amd_type_bits(num_types);
-  PTGNN_REQUIRE(num_edges < ((int64_t)1 << 31) && (num_nodes << type_bits) < ((int64_t)1 << 31),
+  const int64_t src_rows = num_src_rows > num_nodes ? num_src_rows : num_nodes;
+  PTGNN_REQUIRE(num_edges < ((int64_t)1 << 31) && (src_rows << type_bits) < ((int64_t)1 << 31),
                 PTGNN_AMD_EUNSUPPORTED,
-                "csr_build: num_edges=%lld / num_nodes=%lld x 2^%d exceed the int32 plan format",
-                (long long)num_edges, (long long)num_nodes, type_bits);
+                "csr_build: num_edges=%lld / source rows=%lld x 2^%d exceed the int32 plan format",
+                (long long)num_edges, (long long)src_rows, type_bits);
   PTGNN_REQUIRE(num_edges == 0 || col != nullptr, PTGNN_AMD_EINVAL, "csr_build: col is null");
   WsLayout L;
   PTGNN_REQUIRE(layout(num_edges, num_nodes, &L), PTGNN_AMD_EHIP, "csr_build: sort size query failed");

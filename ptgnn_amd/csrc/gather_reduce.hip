@@ -34,6 +34,7 @@ struct Args {
   const float *ysrc;
   const float *ydst;
   int64_t ld_y;
+  int64_t ld_yd;
   const int32_t *rowptr;
   const int32_t *col;
   int32_t type_bits;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
       }
   };
 
-  const float *dst_base = HAS_DST ? a.ydst + row * a.ld_y : nullptr;
+  const float *dst_base = HAS_DST ? a.ydst + row * a.ld_yd : nullptr;
 
   constexpr int U = 4;
   int i = beg;
@@ -258,8 +259,8 @@ int launch1(const Args &a, int reduce, int epi, int col_blocks, hipStream_t s) {
 
 using namespace ptgnn_amd;
 
-extern "C" int ptgnn_amd_gather_reduce_f32(const float *ysrc, const float *ydst, int64_t ld_y,
-                                           const int32_t *rowptr, const int32_t *col,
+extern "C" int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_y, const float *ydst,
+                                           int64_t ld_yd, const int32_t *rowptr, const int32_t *col,
                                            int32_t type_bits, int64_t num_nodes, int32_t msg_dim,
                                            int reduce, int epilogue, const float *ln_gamma,
                                            const float *ln_beta, float ln_eps, float *out,
@@ -278,9 +279,9 @@ extern "C" int ptgnn_amd_gather_reduce_f32(const float *ysrc, const float *ydst,
   PTGNN_REQUIRE(argout == nullptr || reduce >= PTGNN_AMD_MAX, PTGNN_AMD_EINVAL,
                 "gather_reduce: argout only with max/min");
 
-  Args a{ysrc, ydst, ld_y, rowptr, col, type_bits, num_nodes, msg_dim, ln_gamma, ln_beta, ln_eps,
+  Args a{ysrc, ydst, ld_y, ydst ? ld_yd : ld_y, rowptr, col, type_bits, num_nodes, msg_dim, ln_gamma, ln_beta, ln_eps,
          out, ld_out, argout, 0, 0};
-  const bool vec4 = (msg_dim % 4 == 0) && (ld_y % 4 == 0) && (ld_out % 4 == 0) && aligned16(ysrc) &&
+  const bool vec4 = (msg_dim % 4 == 0) && (ld_y % 4 == 0) && (!ydst || ld_yd % 4 == 0) && (ld_out % 4 == 0) && aligned16(ysrc) &&
                     aligned16(out) && (!ydst || aligned16(ydst)) && (!argout || aligned16(argout));
   const bool row_epi = (epilogue & PTGNN_AMD_EPI_LAYERNORM) != 0;
   if (vec4) {

@@ -191,6 +191,27 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
         agg = segment_reduce(messages.to(torch.float32), plan, self.__aggregation_fn).to(messages.dtype)
         return gru(agg, node_states)
 
+    def forward_sharded(self, node_states: torch.Tensor, shard) -> torch.Tensor:
+        """One layer over a dst-range shard (ptgnn_amd/sharded.py): `node_states` are this rank's
+        rows; one all-to-all of halo rows, then the same fused kernels as `forward`."""
+        _check_device(node_states)
+        feats = [None] * len(shard.local_adj)
+        if not self._fused_ok(node_states, feats):
+            raise _lib.PtgnnAmdError("forward_sharded supports the fused inference path only "
+                                     "(no grad, no active dropout, no edge features)")
+        assert len(shard.local_adj) == len(self.__edge_message_transformation_layers)
+        w = self._stacked_edge_weights()
+        TM, H = w.shape
+        if TM <= H:   # ship message-table rows: no wider than the state, and no duplicated GEMM work
+            y = shard.new_table(TM, node_states)
+            ops.linear(node_states, w, out=y[: shard.n_local])
+            shard.exchange_into(y)
+        else:         # ship node states, pre-transform own + halo rows locally (weights are replicated)
+            y = ops.linear(shard.exchange(node_states), w)
+        agg = ops.gather_reduce(y, shard.plan, self._message_dimension, self.__aggregation_fn)
+        gru = self.__state_update
+        return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
+
     @property
     def input_state_dimension(self) -> int:
         return self.__state_dimension
@@ -284,6 +305,45 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             return False
         return _no_grad_needed(node_states, *self.parameters())
 
+    def _aggregate_and_update(self, ysrc, ydst, plan) -> torch.Tensor:
+        """Fused gather/reduce with GELU + LayerNorm folded into the kernel epilogue when the
+        layer's activation/normalisation are the stock ones, then the dense update."""
+        M = self._message_dimension
+        act = self.__message_activation
+        gelu_ok = act is None or (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none")
+        ln_ok = self._ln is None or (M <= 512 and self._ln.elementwise_affine and self._ln.bias is not None)
+        if gelu_ok and ln_ok:
+            epi = (ops.EPI_GELU if act is not None else 0) | (ops.EPI_LAYERNORM if self._ln is not None else 0)
+            agg = ops.gather_reduce(
+                ysrc, plan, M, self.__aggregation_fn, ydst=ydst, epilogue=epi,
+                ln_weight=self._ln.weight if self._ln is not None else None,
+                ln_bias=self._ln.bias if self._ln is not None else None,
+                ln_eps=self._ln.eps if self._ln is not None else 1e-5)
+            return self._update(agg, True)
+        agg = ops.gather_reduce(ysrc, plan, M, self.__aggregation_fn, ydst=ydst)
+        return self._update(agg, False)
+
+    def forward_sharded(self, node_states: torch.Tensor, shard) -> torch.Tensor:
+        """One layer over a dst-range shard (ptgnn_amd/sharded.py): the source term rides the halo
+        all-to-all, the destination term W_t^d x_v is purely local."""
+        _check_device(node_states)
+        feats = [None] * len(shard.local_adj)
+        if not self._fused_ok(node_states, feats):
+            raise _lib.PtgnnAmdError("forward_sharded supports the fused inference path only "
+                                     "(no grad, string aggregation, single-Linear edge transform)")
+        assert len(shard.local_adj) == len(self.__edge_message_transformation_layers)
+        T, M, H = len(shard.local_adj), self._message_dimension, self.__input_state_dim
+        w = self._stacked_edge_weights()
+        w_src = w[: T * M]
+        if T * M <= H:
+            ysrc = shard.new_table(T * M, node_states)
+            ops.linear(node_states, w_src, out=ysrc[: shard.n_local])
+            shard.exchange_into(ysrc)
+        else:
+            ysrc = ops.linear(shard.exchange(node_states), w_src)
+        ydst = ops.linear(node_states, w[T * M:]) if self.__use_target_state_as_message_input else None
+        return self._aggregate_and_update(ysrc, ydst, shard.plan)
+
     def _update(self, agg: torch.Tensor, fused_epilogue_done: bool) -> torch.Tensor:
         x = agg
         if not fused_epilogue_done:
@@ -318,20 +378,7 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             y = ops.linear(node_states, self._stacked_edge_weights())
             ysrc = y[:, :T * M]
             ydst = y[:, T * M:] if self.__use_target_state_as_message_input else None
-            act = self.__message_activation
-            gelu_ok = act is None or (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none")
-            ln_ok = self._ln is None or (M <= 512 and self._ln.elementwise_affine
-                                         and self._ln.bias is not None)
-            if gelu_ok and ln_ok:
-                epi = (ops.EPI_GELU if act is not None else 0) | (ops.EPI_LAYERNORM if self._ln is not None else 0)
-                agg = ops.gather_reduce(
-                    ysrc, plan, M, self.__aggregation_fn, ydst=ydst, epilogue=epi,
-                    ln_weight=self._ln.weight if self._ln is not None else None,
-                    ln_bias=self._ln.bias if self._ln is not None else None,
-                    ln_eps=self._ln.eps if self._ln is not None else 1e-5)
-                return self._update(agg, True)
-            agg = ops.gather_reduce(ysrc, plan, M, self.__aggregation_fn, ydst=ydst)
-            return self._update(agg, False)
+            return self._aggregate_and_update(ysrc, ydst, plan)
 
         # general per-edge path
         all_targets, all_messages = [], []

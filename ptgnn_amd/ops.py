@@ -114,7 +114,8 @@ class GraphPlan:
 
 
 def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num_nodes: int,
-               transposed: bool = False, want_perm: bool = True) -> GraphPlan:
+               transposed: bool = False, want_perm: bool = True,
+               num_src_rows: Optional[int] = None) -> GraphPlan:
     """One stable sort per minibatch; reused by every layer of the forward."""
     lib = _lib.load()
     T = len(adjacency_lists)
@@ -151,6 +152,7 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
         rc = lib.ptgnn_amd_csr_build(ctypes.cast(src_ptrs, ctypes.c_void_p),
                                      ctypes.cast(dst_ptrs, ctypes.c_void_p),
                                      ctypes.cast(cnts, ctypes.c_void_p), T, num_nodes,
+                                     int(num_src_rows or 0),
                                      1 if transposed else 0, rowptr.data_ptr(), col.data_ptr(),
                                      perm.data_ptr() if perm is not None else None, ws.data_ptr(),
                                      ws_bytes, _stream(rowptr))
@@ -205,11 +207,11 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
     _require_cuda_f32("ysrc", ysrc)
     ysrc = _rowmajor(ysrc)
     ld_y = _ld(ysrc)
+    ld_yd = ld_y
     if ydst is not None:
         _require_cuda_f32("ydst", ydst)
         ydst = _rowmajor(ydst)
-        if _ld(ydst) != ld_y:
-            raise _lib.PtgnnAmdError("gather_reduce: ysrc and ydst must share a leading dimension")
+        ld_yd = _ld(ydst)
     if reduce not in REDUCE_IDS:
         raise ValueError(f"unknown aggregation function {reduce!r}")
     N = plan.num_nodes
@@ -228,7 +230,7 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
               + (N * 4.0 * msg_dim if arg is not None else 0.0))
     with _timed("gather_reduce", bytes=nbytes):
         rc = lib.ptgnn_amd_gather_reduce_f32(
-            ysrc.data_ptr(), ydst.data_ptr() if ydst is not None else None, ld_y,
+            ysrc.data_ptr(), ld_y, ydst.data_ptr() if ydst is not None else None, ld_yd,
             plan.rowptr.data_ptr(), colt.data_ptr(), tb, N, msg_dim,
             REDUCE_IDS[reduce], epilogue,
             ln_weight.data_ptr() if ln_weight is not None else None,

@@ -1,0 +1,177 @@
+"""Destination-range sharding of ONE large batched graph across the GPUs of a node
+(BASELINE.json north_star).  The reference has no counterpart: its only multi-GPU
+mode is whole-batch data parallelism (ptgnn/baseneuralmodel/distributedtrainer.py:250-297), which on
+ROCm runs unchanged over RCCL.  This module is the new exchange step the north star asks for.
+
+Layout, one process per GPU:
+  * rank p owns the contiguous node range [lo_p, hi_p) and ALL in-edges of those nodes (so every
+    destination row is reduced on exactly one GPU, in the single-GPU message order => results equal
+    the unsharded kernel's);
+  * per minibatch (plan time) every rank de-duplicates the remote source ids it needs per peer and
+    tells each peer which of ITS rows to send (two small all-to-alls of counts and ids);
+  * per layer ONE all-to-all(v) of halo rows (RCCL over xGMI: a dedicated link per peer pair, so an
+    all-to-all uses all 7 links at once, unlike a ring).  The rows exchanged are the
+    message-table rows when that is no wider than the state (T*M <= H, e.g. T = 1), else the node
+    states, which are then pre-transformed locally (weights are replicated).
+  * local table = [own rows | halo rows from peer 0 | halo rows from peer 1 | ...]; edge sources are
+    remapped into that table once per minibatch and one dst-sorted plan is built over it.
+
+The index bookkeeping and the exchange are device-agnostic `torch`/`torch.distributed` plumbing
+(they also run under gloo on CPU, which is how tests/test_sharded_cpu.py covers the N > 1 logic);
+the compute stays in the HIP kernels and refuses CPU tensors.
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from ptgnn_amd import ops
+
+Adj = List[Tuple[torch.Tensor, torch.Tensor]]
+
+
+def balanced_node_ranges(in_degree: torch.Tensor, world: int) -> List[Tuple[int, int]]:
+    """Contiguous ranges with ~equal numbers of in-edges (+1 per node so empty rows count a bit):
+    the balance criterion that matters for power-law graphs."""
+    w = in_degree.to(torch.float64) + 1.0
+    c = torch.cumsum(w, 0)
+    total = float(c[-1]) if c.numel() else 0.0
+    cuts = [0]
+    for p in range(1, world):
+        cuts.append(int(torch.searchsorted(c, torch.tensor(total * p / world, dtype=c.dtype))))
+    cuts.append(int(in_degree.shape[0]))
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return [(cuts[i], cuts[i + 1]) for i in range(world)]
+
+
+class ShardedGraph:
+    """Per-rank view of a dst-range-sharded minibatch."""
+
+    def __init__(self):
+        self.rank = self.world = 0
+        self.lo = self.hi = 0
+        self.n_local = self.n_halo = 0
+        self.bounds: Optional[torch.Tensor] = None       # int64 [world + 1] on device
+        self.need_ids: Optional[torch.Tensor] = None      # global ids of halo rows, sorted
+        self.send_ids: Optional[torch.Tensor] = None      # local row ids to send, grouped by peer
+        self.send_splits: List[int] = []
+        self.recv_splits: List[int] = []
+        self.local_adj: Adj = []
+        self.plan: Optional["ops.GraphPlan"] = None
+        self.group = None
+
+    # -- construction ---------------------------------------------------------------------------
+    @staticmethod
+    def build(adjacency_lists: Adj, node_range: Tuple[int, int], group=None,
+              build_plan: bool = True) -> "ShardedGraph":
+        """adjacency_lists: int64 (src, dst) per edge type in GLOBAL node ids, holding exactly the
+        edges whose dst lies in this rank's `node_range`."""
+        g = ShardedGraph()
+        g.group = group
+        g.rank, g.world = dist.get_rank(group), dist.get_world_size(group)
+        g.lo, g.hi = int(node_range[0]), int(node_range[1])
+        g.n_local = g.hi - g.lo
+        dev = adjacency_lists[0][0].device
+        # every rank learns all range boundaries
+        mine = torch.tensor([g.lo, g.hi], dtype=torch.int64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(g.world)]
+        dist.all_gather(allr, mine, group=group)
+        los = torch.stack([r[0] for r in allr])
+        his = torch.stack([r[1] for r in allr])
+        if not bool((los[1:] == his[:-1]).all()) :
+            raise ValueError("node ranges must be contiguous and ordered by rank")
+        g.bounds = torch.cat([los, his[-1:]])
+
+        g.index_locally(adjacency_lists)
+        got_counts = torch.empty(g.world, dtype=torch.int64, device=dev)
+        need_counts = torch.tensor(g.recv_splits, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(got_counts, need_counts, group=group)
+        g.send_splits = [int(v) for v in got_counts.tolist()]        # rows I send per peer
+        wanted = torch.empty(sum(g.send_splits), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(wanted, g.need_ids, g.send_splits, g.recv_splits, group=group)
+        if wanted.numel() and (int(wanted.min()) < g.lo or int(wanted.max()) >= g.hi):
+            raise RuntimeError("a peer requested rows this rank does not own")
+        g.send_ids = wanted - g.lo
+        if build_plan:
+            g.build_plan()
+        return g
+
+    def index_locally(self, adjacency_lists: Adj) -> None:
+        """The collective-free part of `build`: which halo rows this rank needs (de-duplicated, sorted,
+        hence grouped by owner because the ranges are ordered) and the remapping of edge endpoints
+        into the local table [own rows | halo rows]."""
+        dev = adjacency_lists[0][0].device
+        srcs = [a[0] for a in adjacency_lists]
+        all_src = torch.cat(srcs) if srcs else torch.zeros(0, dtype=torch.int64, device=dev)
+        remote = (all_src < self.lo) | (all_src >= self.hi)
+        self.need_ids = torch.unique(all_src[remote], sorted=True)
+        self.n_halo = int(self.need_ids.shape[0])
+        edges = torch.searchsorted(self.need_ids, self.bounds)       # [world + 1] positions
+        self.recv_splits = [int(v) for v in (edges[1:] - edges[:-1]).tolist()]  # rows I receive per peer
+        self.local_adj = []
+        for s, d in adjacency_lists:
+            rem = (s < self.lo) | (s >= self.hi)
+            pos = torch.searchsorted(self.need_ids, s) if self.n_halo else torch.zeros_like(s)
+            ls = torch.where(rem, pos + self.n_local, s - self.lo)
+            self.local_adj.append((ls.contiguous(), (d - self.lo).contiguous()))
+
+    def build_plan(self) -> None:
+        self.plan = ops.build_plan(self.local_adj, self.n_local, num_src_rows=self.n_local + self.n_halo)
+
+    # -- per-layer exchange -----------------------------------------------------------------------
+    def new_table(self, dim: int, like: torch.Tensor) -> torch.Tensor:
+        return torch.empty(self.n_local + self.n_halo, dim, dtype=like.dtype, device=like.device)
+
+    def exchange_into(self, table: torch.Tensor) -> torch.Tensor:
+        """table[:n_local] holds this rank's rows; fills table[n_local:] with the halo rows."""
+        own = table[: self.n_local]
+        if own.is_cuda:
+            send = ops.gather_rows(own, self.send_ids)
+        else:
+            send = own.index_select(0, self.send_ids)
+        dist.all_to_all_single(table[self.n_local:], send, self.recv_splits, self.send_splits,
+                               group=self.group)
+        return table
+
+    def exchange(self, rows_local: torch.Tensor) -> torch.Tensor:
+        table = self.new_table(rows_local.shape[1], rows_local)
+        table[: self.n_local].copy_(rows_local)
+        return self.exchange_into(table)
+
+    @property
+    def halo_bytes_per_row_exchange(self) -> int:
+        return 4 * sum(self.recv_splits)
+
+
+# ------------------------------------------------------------------------------------------------
+# bench / test helpers
+# ------------------------------------------------------------------------------------------------
+def make_weak_scaling_shard(nodes_per_rank: int, edges_per_rank: int, hidden: int, rank: int,
+                            world: int, device, seed: int = 1234) -> Dict:
+    """Weak-scaling version of BASELINE config 2: ONE random graph of world * N nodes; rank p owns
+    nodes [p N, (p+1) N) and their E in-edges, whose sources are uniform over ALL world * N nodes
+    (so (world-1)/world of the edges are cut)."""
+    g = torch.Generator().manual_seed(seed + 7919 * rank)
+    lo = rank * nodes_per_rank
+    src = torch.randint(0, world * nodes_per_rank, (edges_per_rank,), generator=g, dtype=torch.int64)
+    dst = torch.randint(0, nodes_per_rank, (edges_per_rank,), generator=g, dtype=torch.int64) + lo
+    x = torch.randn(nodes_per_rank, hidden, generator=g, dtype=torch.float32)
+    adj = [(src.to(device), dst.to(device))]
+    return {"adj_global": adj, "range": (lo, lo + nodes_per_rank), "x": x.to(device)}
+
+
+def layer_forward(layer, state: Dict) -> torch.Tensor:
+    """One sharded message-passing layer: (re)build the shard plan for the minibatch, exchange halo
+    rows, aggregate, update.  Nothing is cached across calls (bench.py times the whole thing)."""
+    shard = ShardedGraph.build(state["adj_global"], state["range"])
+    return layer.forward_sharded(state["x"], shard)
+
+
+def run_stack(layers: Sequence, x_local: torch.Tensor, shard: ShardedGraph) -> torch.Tensor:
+    for layer in layers:
+        if hasattr(layer, "forward_sharded"):
+            x_local = layer.forward_sharded(x_local, shard)
+        else:  # residual glue etc.: purely node-local
+            x_local = layer(x_local, shard.local_adj, None, {}, {}, [None] * len(shard.local_adj))
+    return x_local
