@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true")
+    p.add_argument("--force-sharded", action="store_true",
+                   help="run the dst-range-sharded code path (process group, halo all-to-all) even at N=1")
     return p.parse_args()
 
 
@@ -48,7 +50,7 @@ def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -81,13 +83,13 @@ def max_over_ranks(seconds, world, dev):
 # ------------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------------
-def make_cfg2(dev, rank, world):
+def make_cfg2(dev, rank, world, force_sharded=False):
     """configs[1]; for world > 1 every rank owns its own 200k-node destination range."""
     from ptgnn_amd import layers as L, workloads
     N, E, H = 200_000, 1_100_000, 128
     torch.manual_seed(1234)
     layer = L.MlpMessagePassingLayer(H, H, H, 1, "sum").to(dev).eval()
-    if world == 1:
+    if world == 1 and not force_sharded:
         adj = workloads.random_graph(N, E)
         x = workloads.node_states(N, H)
         state = {"adj": [(s.to(dev), d.to(dev)) for s, d in adj], "x": x.to(dev), "cpu_adj": adj, "cpu_x": x}
@@ -103,7 +105,7 @@ def step_cfg2(st, world):
     from ptgnn_amd import ops
     ops.clear_plan_cache()
     with torch.no_grad():
-        if world == 1:
+        if "adj" in st:
             adj = st["adj"]
             feats = [None]
             return st["layer"](st["x"], adj, None, {}, {}, feats)
@@ -210,7 +212,7 @@ def main():
     _lib.load()
 
     if args.workload == "cfg2":
-        st = make_cfg2(dev, rank, world)
+        st = make_cfg2(dev, rank, world, args.force_sharded)
         step = lambda: step_cfg2(st, world)  # noqa: E731
     else:
         if world > 1:
@@ -236,13 +238,13 @@ def main():
         "config": {"workload": st["desc"], "nodes_per_gpu": st["N"], "edges_per_gpu": st["E"],
                    "hidden": st["H"], "mp_layers_per_step": layers, "mode": "forward (inference), fp32",
                    "plan_build_in_step": True,
-                   "parallelism": "single GPU" if world == 1 else f"dst-range shard x{world} + halo all-to-all"},
+                   "parallelism": "single GPU" if "adj" in st else f"dst-range shard x{world} + halo all-to-all"},
         "nodes_per_sec_per_layer": round(st["N"] * world / (seconds / args.steps / layers), 1),
         "edges_per_sec_readme_convention": round(edges_all_ranks / (seconds / args.steps), 1),
         "roofline": roof, "kernels": ktab,
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.force_sharded:
         if args.workload == "cfg2" and not args.no_secondary:
             st3 = make_cfg3(dev)
             sec3, sum3 = timed_region(lambda: step_cfg3(st3), max(5, args.steps // 2), 2, 1, dev)
@@ -257,11 +259,13 @@ def main():
             del st3
         if args.workload == "cfg2" and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_cfg2(st)
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

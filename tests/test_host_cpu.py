@@ -1,0 +1,136 @@
+"""CPU-side checks (no GPU): the C-ABI library builds, loads and exports every symbol the header
+declares; the host mirror of the reference interface behaves (constructors, state_dict keys,
+properties, loud failure on CPU tensors)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ptgnn_amd import build
+    path = build.build()
+    assert os.path.exists(path)
+    from ptgnn_amd import _lib
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ptgnn_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptgnn_amd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from ptgnn_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/ptgnn_amd.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in ptgnn_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_version_and_pure_host_entry_points(lib):
+    assert lib.ptgnn_amd_version() == 100
+    assert [lib.ptgnn_amd_type_bits(t) for t in (1, 2, 3, 4, 5, 17, 32, 33)] == [0, 1, 2, 2, 3, 5, 5, 6]
+    assert lib.ptgnn_amd_last_error() is not None
+
+
+def test_argument_validation_without_a_gpu(lib):
+    # bad arguments are rejected before any HIP call is made
+    from ptgnn_amd import PtgnnAmdError, _lib
+    rc = lib.ptgnn_amd_linear_f32(None, 4, 0, 4, None, 4, None, 0, None, 4, None)
+    assert rc == -1 and b"linear" in lib.ptgnn_amd_last_error()
+    rc = lib.ptgnn_amd_gather_reduce_f32(None, 4, None, 4, None, None, 0, 4, 4, 9, 0, None, None, 1e-5,
+                                         None, 4, None, None)
+    assert rc == -1 and b"reduce" in lib.ptgnn_amd_last_error()
+    with pytest.raises(PtgnnAmdError):
+        _lib.check(rc, "gather_reduce")
+    rc = lib.ptgnn_amd_gru_cell_f32(None, 1, None, 1, None, None, None, None, 3, 4, 4, None, 4, None)
+    assert rc == -1
+
+
+def test_layers_mirror_reference_interface_and_refuse_cpu():
+    from ptgnn_amd import PtgnnAmdError, layers as L
+    g = L.GatedMessagePassingLayer(state_dimension=8, message_dimension=12, num_edge_types=3,
+                                   message_aggregation_function="max", dropout_rate=0.1,
+                                   edge_feature_dimension=0)
+    assert g.input_state_dimension == 8 and g.output_state_dimension == 8
+    assert list(g.state_dict()) == [
+        "_GatedMessagePassingLayer__edge_message_transformation_layers.0.weight",
+        "_GatedMessagePassingLayer__edge_message_transformation_layers.1.weight",
+        "_GatedMessagePassingLayer__edge_message_transformation_layers.2.weight",
+        "_GatedMessagePassingLayer__state_update.weight_ih",
+        "_GatedMessagePassingLayer__state_update.weight_hh",
+        "_GatedMessagePassingLayer__state_update.bias_ih",
+        "_GatedMessagePassingLayer__state_update.bias_hh"]
+    m = L.MlpMessagePassingLayer(input_state_dimension=8, output_state_dimension=6, message_dimension=10,
+                                 num_edge_types=2, message_aggregation_function="sum")
+    assert m.input_state_dimension == 8 and m.output_state_dimension == 6
+    assert list(m.state_dict()) == [
+        "_MlpMessagePassingLayer__edge_message_transformation_layers.0._MLP__mlp_modules.1.weight",
+        "_MlpMessagePassingLayer__edge_message_transformation_layers.1._MLP__mlp_modules.1.weight",
+        "_MlpMessagePassingLayer__state_update.0.weight", "_MlpMessagePassingLayer__state_update.0.bias",
+        "_MlpMessagePassingLayer__state_update.1.weight", "_MlpMessagePassingLayer__state_update.1.bias"]
+    assert tuple(m.state_dict()["_MlpMessagePassingLayer__edge_message_transformation_layers.0."
+                                "_MLP__mlp_modules.1.weight"].shape) == (10, 16)
+    adj = [(torch.tensor([0]), torch.tensor([1]))] * 3
+    with pytest.raises(PtgnnAmdError):
+        g(torch.randn(4, 8), adj, None, {}, {}, [torch.empty(1, 0)] * 3)
+    with pytest.raises(AssertionError):          # wrong number of edge types: the reference's assert
+        g(torch.randn(4, 8), adj[:2], None, {}, {}, [torch.empty(1, 0)] * 2)
+    r = L.ConcatResidualLayer(8)
+    o = r.pass_through_dummy_layer()
+    x = torch.randn(4, 8)
+    assert o(x, adj, None, {}, {}, []) is x
+    assert tuple(r(2 * x, adj, None, {}, {}, []).shape) == (4, 16) and r.output_state_dimension == 16
+    with pytest.raises(AssertionError):          # residual used without its origin layer
+        r(x, adj, None, {}, {}, [])
+    mean = L.MeanResidualLayer(8)
+    mean.pass_through_dummy_layer()(x, adj, None, {}, {}, [])
+    torch.testing.assert_close(mean(3 * x, adj, None, {}, {}, []),
+                               torch.stack((x, 3 * x), dim=-1).mean(dim=-1), rtol=0, atol=0)
+
+
+def test_golden_fixture_weights_load_into_layers():
+    from conftest import load_golden
+    from helpers import layer_from_spec
+    from oracle.fixtures import unpack_specs
+    for name in ("ggnn_layer_max", "mlp_layer_sum_target", "mlp_layer_sum_hidden1", "mlp_layer_max_noln_nodense"):
+        (spec,) = unpack_specs(load_golden(name))
+        layer = layer_from_spec(spec)
+        back = layer.export_weights()
+        assert back["kind"] == spec["kind"] and back["agg"] == spec["agg"]
+        if spec["kind"] == "ggnn":
+            for a, b in zip(back["edge_w"], spec["edge_w"]):
+                assert torch.equal(a, b)
+        else:
+            for la, lb in zip(back["edge_mlp"], spec["edge_mlp"]):
+                for a, b in zip(la, lb):
+                    assert torch.equal(a, b)
+
+
+def test_scatter_facade_rejects_unsupported_layouts():
+    from ptgnn_amd import PtgnnAmdError
+    from ptgnn_amd.scatter import scatter
+    with pytest.raises(PtgnnAmdError):
+        scatter(torch.randn(4, 3, 2), torch.tensor([0, 1, 0, 1]), dim=0)
+    with pytest.raises(PtgnnAmdError):
+        scatter(torch.randn(4, 3), torch.tensor([0, 1, 0, 1]), dim=0, out=torch.zeros(2, 3))
+    with pytest.raises(ValueError):
+        from ptgnn_amd.scatter import segment_reduce
+        segment_reduce(torch.randn(2, 2), None, "mul")
+
+
+def test_product_package_never_imports_the_oracle():
+    import pathlib
+    for f in pathlib.Path(ROOT, "ptgnn_amd").rglob("*.py"):
+        src = f.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, f
