@@ -148,19 +148,34 @@ def step_cfg3(st):
 
 # ------------------------------------------------------------------------------------------------
 def timed_region(step_fn, steps, warmup, world, dev):
-    from ptgnn_amd import ops
+    """The contract's timed region: W untimed warm-up steps, then EXACTLY K steps bracketed by
+    barrier + synchronize on both sides, max over ranks.  No per-kernel instrumentation runs here:
+    a HIP event pair around every launch costs ~0.1 ms of queue serialisation per kernel on this
+    stack and would be charged to `value`.  The per-kernel HIP-event pass runs right after, over the
+    same K steps of the same inputs (`kernel_pass`)."""
     for _ in range(warmup):
         step_fn()
-    timer = ops.KernelTimer()
     barrier_sync(world)
-    ops.set_kernel_timer(timer)
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
     barrier_sync(world)
     dt = time.perf_counter() - t0
+    return max_over_ranks(dt, world, dev), kernel_pass(step_fn, steps, world)
+
+
+def kernel_pass(step_fn, steps, world):
+    """K more steps with a HIP-event bracket around every C-ABI launch (events are recorded on the
+    stream the kernels are launched on); feeds `roofline` and `kernels`."""
+    from ptgnn_amd import ops
+    timer = ops.KernelTimer()
+    barrier_sync(world)
+    ops.set_kernel_timer(timer)
+    for _ in range(steps):
+        step_fn()
+    barrier_sync(world)
     ops.set_kernel_timer(None)
-    return max_over_ranks(dt, world, dev), timer.summary()
+    return timer.summary()
 
 
 def kernel_table(summary):
@@ -168,7 +183,7 @@ def kernel_table(summary):
     for name, d in summary.items():
         ms = d["ms"] / d["calls"]
         row = {"calls": d["calls"], "avg_ms": round(ms, 5)}
-        if name in ("linear", "gru_cell"):
+        if name in ("linear", "gru_cell", "edge_linear"):
             tf = d["flops"] / d["calls"] / (ms * 1e-3) / 1e12
             row.update(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                        frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
@@ -247,8 +262,8 @@ def main():
     if rank == 0 and world == 1 and not args.force_sharded:
         if args.workload == "cfg2" and not args.no_secondary:
             st3 = make_cfg3(dev)
-            sec3, sum3 = timed_region(lambda: step_cfg3(st3), max(5, args.steps // 2), 2, 1, dev)
-            k3 = max(5, args.steps // 2)
+            k3 = max(10, args.steps // 2)
+            sec3, sum3 = timed_region(lambda: step_cfg3(st3), k3, 3, 1, dev)
             result["graph2class"] = {
                 "workload": st3["desc"], "ms_per_forward": round(sec3 / k3 * 1e3, 4),
                 "edges_per_sec_per_layer": round(st3["E"] / (sec3 / k3 / 8), 1),

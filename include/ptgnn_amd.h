@@ -133,6 +133,26 @@ int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int64_t ld_x, 
                          void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-edge message GEMM, every edge type in ONE launch (grouped GEMM with gathered A rows):
+ *   msg[off_t + e, :] = act( [ x[src_t[e], :] ; x[dst_t[e], :] (if dst_per_type) ] W_t^T ),  e < E_t
+ * rows in the reference's message order (type-major, then edge order) = the matrix
+ * `torch.cat(all_messages)` of gatedmessagepassing.py:50-64 / mlpmessagepassing.py:81-108, without the
+ * F.embedding outputs, the torch.cat copies and the T per-type launches.  Cheaper than the per-node
+ * pre-transform when E < N*T (many sparse edge types).  Feed the result to
+ * ptgnn_amd_gather_reduce_f32 with col = perm, type_bits = 0.
+ *   src/dst_per_type: HOST arrays of int64 device arrays (ptgnn's adjacency tensors); dst nullable.
+ *   w_per_type: HOST array of device pointers to the per-type nn.Linear weights
+ *               [msg_dim, state_dim * (dst ? 2 : 1)], row-major contiguous.
+ * Requires state_dim % 32 == 0, msg_dim % 4 == 0, 16-byte aligned rows (else EUNSUPPORTED).
+ * ---------------------------------------------------------------------------------------- */
+int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int32_t state_dim,
+                              const int64_t *const *src_per_type,
+                              const int64_t *const *dst_per_type /* nullable */,
+                              const int64_t *edges_per_type, const float *const *w_per_type,
+                              int32_t num_types, int32_t msg_dim, int act, float *msg,
+                              int64_t ld_msg, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * h' = GRUCell(a, h)  (gate order r, z, n), gatedmessagepassing.py:25,69.
  *   a [n, m], h [n, hd], w_ih [3hd, m], w_hh [3hd, hd], b_ih/b_hh [3hd], out [n, hd].
  *   Gate GEMMs run on fp32 MFMA with the gate non-linearities fused in the epilogue; no

@@ -27,6 +27,8 @@ SIGNATURES = {
                                                _c.c_int, _vp, _vp, _f32, _vp, _i64, _vp, _vp]),
     "ptgnn_amd_linear_f32": (_c.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _c.c_int, _vp, _i64,
                                         _vp]),
+    "ptgnn_amd_edge_linear_f32": (_c.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _c.c_int, _vp,
+                                             _i64, _vp]),
     "ptgnn_amd_gru_cell_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                           _vp, _i64, _vp]),
     "ptgnn_amd_gather_rows_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),

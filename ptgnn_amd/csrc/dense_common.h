@@ -1,0 +1,107 @@
+// Shared device helpers of the fp32-MFMA kernels (dense_f32.hip, edge_gemm.hip).
+#pragma once
+#include "common.h"
+
+namespace ptgnn_amd {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 1;
+
+// Stage a [ROWS x 32] K-chunk of a row-major matrix through registers into LDS, one float4 "part"
+// at a time so the traffic can be threaded between MFMAs.  RowMap maps tile row -> matrix row and
+// CLAMPS it into range: out-of-range tile rows read some valid row instead of being predicated,
+// because a branch around a load makes hipcc's waitcnt pass fall back to vmcnt(0) drains.  Such
+// rows only feed output rows/columns that are never stored.  The K tail must be exact, so chunk
+// columns >= K are zeroed on the way into LDS.
+template <int ROWS, bool ALIGNED, typename RowMap>
+struct Stager {
+  static constexpr int NV4 = ROWS * BK / 4 / 256;  // float4 per thread
+  float4 v[NV4];
+  int kvalid;  // how many of this thread's 4 chunk columns are < K (0..4)
+
+  __device__ __forceinline__ void load_part(const float *__restrict__ base, int64_t ld, int k0, int K,
+                                            RowMap rm, int r) {
+    const int f = threadIdx.x + r * 256;
+    const int row = f >> 3, c4 = (f & 7) * 4;
+    const int64_t mrow = rm(row);
+    const int kk = k0 + c4;
+    kvalid = K - kk;
+    if (ALIGNED) {
+      // K % 4 == 0: a float4 is entirely valid or entirely past the end
+      const int kc = kk < K ? kk : 0;
+      v[r] = *reinterpret_cast<const float4 *>(base + mrow * ld + kc);
+    } else {
+      const float *p = base + mrow * ld;
+      float4 t;
+      t.x = p[kk + 0 < K ? kk + 0 : 0];
+      t.y = p[kk + 1 < K ? kk + 1 : 0];
+      t.z = p[kk + 2 < K ? kk + 2 : 0];
+      t.w = p[kk + 3 < K ? kk + 3 : 0];
+      v[r] = t;
+    }
+  }
+
+  __device__ __forceinline__ void store_part(float *__restrict__ lds, int r) const {
+    const int f = threadIdx.x + r * 256;
+    const int row = f >> 3, c4 = (f & 7) * 4;
+    float *q = lds + row * LDS_LD + c4;
+    q[0] = kvalid > 0 ? v[r].x : 0.f;
+    q[1] = kvalid > 1 ? v[r].y : 0.f;
+    q[2] = kvalid > 2 ? v[r].z : 0.f;
+    q[3] = kvalid > 3 ? v[r].w : 0.f;
+  }
+
+  __device__ __forceinline__ void load(const float *__restrict__ base, int64_t ld, int k0, int K, RowMap rm) {
+#pragma unroll
+    for (int r = 0; r < NV4; ++r) load_part(base, ld, k0, K, rm, r);
+  }
+
+  __device__ __forceinline__ void store(float *__restrict__ lds) const {
+#pragma unroll
+    for (int r = 0; r < NV4; ++r) store_part(lds, r);
+  }
+};
+
+struct RowClamp {  // plain matrices: tile row -> min(base_row + row, limit - 1)
+  int64_t base, limit;
+  __device__ __forceinline__ int64_t operator()(int row) const {
+    const int64_t r = base + row;
+    return r < limit ? r : limit - 1;
+  }
+};
+
+struct GateRows {  // GRU weights: tile row (gate*32 + jj) -> gate*H + min(j0 + jj, H - 1)
+  int j0, H;
+  __device__ __forceinline__ int64_t operator()(int row) const {
+    const int gate = row >> 5, j = j0 + (row & 31);
+    return (int64_t)gate * H + (j < H ? j : H - 1);
+  }
+};
+
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would stall
+// every K-chunk on the prefetch loads still in flight and on the previous tile's epilogue stores
+// (cdna_hip_programming.md section 5: "the ~20% stall").  The staged global loads are ordered by
+// the register dependence of the ds_write that consumes them (compiler-counted vmcnt(N)).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_apply(float v) {
+  if constexpr (ACT == PTGNN_AMD_ACT_TANH) return tanhf(v);
+  if constexpr (ACT == PTGNN_AMD_ACT_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+
+// Epilogue staging: a wave parks a 32 x 64 slab of its C fragments in LDS (row stride 68 floats:
+// conflict-free ds_write_b32 in the MFMA C layout, 16-B aligned rows for ds_read_b128) and streams
+// it out as float4 rows -- 256 contiguous bytes per row.
+constexpr int TILE_FLOATS = 128 * LDS_LD;
+
+// Static tile schedule of a persistent grid: block b walks tiles first(b), first(b)+G, ... where
+// first() keeps consecutive tiles on one XCD (b % 8 is the XCD the dispatcher is observed to use).
+}  // namespace
+}  // namespace ptgnn_amd

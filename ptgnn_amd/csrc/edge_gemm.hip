@@ -1,0 +1,226 @@
+// Per-edge message GEMM for ALL edge types in one launch (grouped GEMM with gathered A rows):
+//
+//     msg[off_t + e, :] = [ X[src_t[e], :] ; X[dst_t[e], :] (optional) ] . W_t^T          e < E_t
+//
+// written in the reference's message order (type-major, then edge order), i.e. exactly the matrix
+// `torch.cat(all_messages)` of gatedmessagepassing.py:50-64 / mlpmessagepassing.py:81-108 -- minus the
+// F.embedding outputs, the torch.cat copies and the T small launches.  The segment reduce then reads
+// these rows through the plan's `perm`.
+//
+// Why it exists next to the per-node pre-transform (ptgnn_amd_linear_f32 on [W_0; ...; W_{T-1}]):
+// the pre-transform costs 2 N T H M FLOP and writes an [N, T M] table; with many sparse edge types
+// (program graphs: T ~ 17-23, E/N ~ 5.4) this kernel needs 2 E H M FLOP (3x less) and writes [E, M].
+// The host picks per minibatch (ptgnn_amd/layers.py).
+//
+// Structure: the occupancy-driven one-tile-per-workgroup fp32-MFMA kernel of dense_f32.hip with
+//   * a tile -> (edge type, first edge) decode through a small table in the kernel arguments,
+//   * the A-operand row map replaced by the int64 source (and destination) indices of the tile's
+//     128 edges, read straight from ptgnn's adjacency tensors once per tile,
+//   * the B operand = that type's own nn.Linear weight (no stacked copy needed).
+// Bound: MFMA fp32 for the math; the gather reads E*H*4 bytes of L2/MALL-resident node states.
+#include "dense_common.h"
+
+namespace ptgnn_amd {
+namespace {
+
+constexpr int kMaxTypes = 64;
+
+struct EdgeTypeTable {
+  const int64_t *src[kMaxTypes];
+  const int64_t *dst[kMaxTypes];     // null entries when the message has no target-state half
+  const float *w[kMaxTypes];
+  int64_t edge_off[kMaxTypes + 1];   // prefix of edges (global message row of the type's edge 0)
+  int32_t tile_off[kMaxTypes + 1];   // prefix of 128-edge tiles
+  int32_t num_types;
+};
+
+struct GatherRows {  // tile row r -> node id of edge (e0 + r); rows past the type's end repeat its last edge
+  int64_t idx[4];
+  __device__ __forceinline__ int64_t operator()(int row) const { return idx[row >> 5]; }
+};
+
+template <int ACT, int NJ>
+__global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
+    EdgeTypeTable tab, const float *__restrict__ x, int64_t ld_x, int H, int use_dst, int n_out,
+    float *__restrict__ msg, int64_t ld_msg, int64_t msg_row_base, int col_tiles) {
+  constexpr int BN = 64 * NJ;
+  constexpr int B_FLOATS = BN * LDS_LD;
+  constexpr int SLAB_LD = 32 * NJ + 4;
+  constexpr int SLAB_FLOATS = 32 * SLAB_LD;
+  constexpr int OPER = TILE_FLOATS + B_FLOATS;
+  constexpr int kLds = OPER > 4 * SLAB_FLOATS ? OPER : 4 * SLAB_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[kLds];
+  float *const As = smem, *const Bs = smem + TILE_FLOATS;
+
+  const int64_t total_tiles = (int64_t)tab.tile_off[tab.num_types] * col_tiles;
+  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile >= total_tiles) return;
+  const int etile = (int)(tile / col_tiles);
+  const int col0 = (int)(tile % col_tiles) * BN;
+  // which edge type owns this tile (<= 6 steps over a table that lives in SGPRs)
+  int lo = 0, hi_t = tab.num_types;
+  while (hi_t - lo > 1) {
+    const int mid = (lo + hi_t) >> 1;
+    if (tab.tile_off[mid] <= etile) lo = mid; else hi_t = mid;
+  }
+  const int t = lo;
+  const int64_t e0 = (int64_t)(etile - tab.tile_off[t]) * 128;
+  const int64_t n_edges = tab.edge_off[t + 1] - tab.edge_off[t];   // > 0: empty types own no tiles
+  const int64_t out_row0 = msg_row_base + tab.edge_off[t] + e0;
+  const int K = use_dst ? 2 * H : H;
+  const float *__restrict__ w = tab.w[t];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hi = lane >> 5;
+
+  // the node ids of this thread's four staging rows, read once per tile
+  GatherRows gs, gd;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int64_t e = e0 + (threadIdx.x >> 3) + r * 32;
+    e = e < n_edges ? e : n_edges - 1;
+    gs.idx[r] = tab.src[t][e];
+    gd.idx[r] = use_dst ? tab.dst[t][e] : 0;
+  }
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Stager<128, true, GatherRows> sa;
+  Stager<BN, true, RowClamp> sb;
+  const RowClamp rb{col0, n_out};
+  const int hchunks = H / BK;               // host guarantees H % 32 == 0
+  const int nchunks = K / BK;
+  auto issue = [&](int c) {
+    if (c < hchunks) sa.load(x, ld_x, c * BK, H, gs);
+    else sa.load(x, ld_x, (c - hchunks) * BK, H, gd);
+    sb.load(w, K, c * BK, K, rb);
+  };
+  issue(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+    sa.store(As);
+    sb.store(Bs);
+    __syncthreads();
+    if (c + 1 < nchunks) issue(c + 1);
+    const float *ap = As + (wm * 64 + li) * LDS_LD + hi;
+    const float *bp = Bs + (wn * 32 * NJ + li) * LDS_LD + hi;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float a[2], b[NJ];
+      a[0] = ap[ks * 2];
+      a[1] = ap[32 * LDS_LD + ks * 2];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + ks * 2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  __syncthreads();  // operand buffers are reused as the epilogue slabs
+  float *const slab = smem + wave * SLAB_FLOATS;
+  constexpr int LPRW = 8 * NJ, RPI = 64 / LPRW;
+  const int c4 = (lane % LPRW) * 4, rsub = lane / LPRW;
+  const int gcol = col0 + wn * 32 * NJ + c4;
+  const int64_t rows_left = n_edges - e0;   // valid rows of this tile
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int rl = it * RPI + rsub;
+      const int trow = wm * 64 + i * 32 + rl;
+      float4 v = *reinterpret_cast<const float4 *>(slab + rl * SLAB_LD + c4);
+      v.x = act_apply<ACT>(v.x); v.y = act_apply<ACT>(v.y);
+      v.z = act_apply<ACT>(v.z); v.w = act_apply<ACT>(v.w);
+      if (trow < rows_left && gcol < n_out)   // host guarantees n_out % 4 == 0 and 16-B aligned rows
+        *reinterpret_cast<float4 *>(msg + (out_row0 + trow) * ld_msg + gcol) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace
+}  // namespace ptgnn_amd
+
+using namespace ptgnn_amd;
+
+extern "C" int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int32_t state_dim,
+                                         const int64_t *const *src_per_type,
+                                         const int64_t *const *dst_per_type,
+                                         const int64_t *edges_per_type,
+                                         const float *const *w_per_type, int32_t num_types,
+                                         int32_t msg_dim, int act, float *msg, int64_t ld_msg,
+                                         void *stream_) {
+  PTGNN_REQUIRE(num_types >= 0 && state_dim > 0 && msg_dim > 0, PTGNN_AMD_EINVAL, "edge_linear: bad sizes");
+  PTGNN_REQUIRE(act >= 0 && act <= PTGNN_AMD_ACT_RELU, PTGNN_AMD_EINVAL, "edge_linear: bad act");
+  PTGNN_REQUIRE(state_dim % 32 == 0 && msg_dim % 4 == 0, PTGNN_AMD_EUNSUPPORTED,
+                "edge_linear: needs state_dim %% 32 == 0 and msg_dim %% 4 == 0 (got %d, %d)", state_dim,
+                msg_dim);
+  if (num_types == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(x && src_per_type && edges_per_type && w_per_type && msg, PTGNN_AMD_EINVAL,
+                "edge_linear: null pointer");
+  PTGNN_REQUIRE(ld_x % 4 == 0 && ld_msg % 4 == 0 && ld_msg >= msg_dim && aligned16(x) && aligned16(msg),
+                PTGNN_AMD_EUNSUPPORTED, "edge_linear: x/msg rows must be 16-byte aligned");
+  const int use_dst = dst_per_type != nullptr;
+  const int nj = msg_dim <= 64 ? 1 : 2;
+  const int col_tiles = (msg_dim + 64 * nj - 1) / (64 * nj);
+  hipStream_t st = (hipStream_t)stream_;
+  int64_t row_base = 0;
+  for (int t0 = 0; t0 < num_types; t0 += kMaxTypes) {
+    EdgeTypeTable tab;
+    tab.num_types = (num_types - t0 < kMaxTypes) ? (num_types - t0) : kMaxTypes;
+    tab.edge_off[0] = 0;
+    tab.tile_off[0] = 0;
+    for (int t = 0; t < tab.num_types; ++t) {
+      const int64_t n = edges_per_type[t0 + t];
+      PTGNN_REQUIRE(n >= 0, PTGNN_AMD_EINVAL, "edge_linear: negative edge count");
+      PTGNN_REQUIRE(n == 0 || (src_per_type[t0 + t] && w_per_type[t0 + t] &&
+                               (!use_dst || dst_per_type[t0 + t])),
+                    PTGNN_AMD_EINVAL, "edge_linear: null table entry for type %d", t0 + t);
+      PTGNN_REQUIRE(n == 0 || aligned16(w_per_type[t0 + t]), PTGNN_AMD_EUNSUPPORTED,
+                    "edge_linear: weight of type %d is not 16-byte aligned", t0 + t);
+      tab.src[t] = src_per_type[t0 + t];
+      tab.dst[t] = use_dst ? dst_per_type[t0 + t] : nullptr;
+      tab.w[t] = w_per_type[t0 + t];
+      tab.edge_off[t + 1] = tab.edge_off[t] + n;
+      const int64_t tiles = tab.tile_off[t] + (n + 127) / 128;
+      PTGNN_REQUIRE(tiles < ((int64_t)1 << 30), PTGNN_AMD_EUNSUPPORTED, "edge_linear: too many tiles");
+      tab.tile_off[t + 1] = (int32_t)tiles;
+    }
+    const int64_t total_tiles = (int64_t)tab.tile_off[tab.num_types] * col_tiles;
+    if (total_tiles > 0) {
+      const unsigned grid = (unsigned)xcd_padded_blocks(total_tiles);
+#define PTGNN_EDGE_LAUNCH(ACT, NJ)                                                               \
+  k_edge_linear<ACT, NJ><<<grid, 256, 0, st>>>(tab, x, ld_x, state_dim, use_dst, msg_dim, msg,   \
+                                               ld_msg, row_base, col_tiles)
+      if (nj == 1) {
+        if (act == PTGNN_AMD_ACT_TANH) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_TANH, 1);
+        else if (act == PTGNN_AMD_ACT_RELU) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_RELU, 1);
+        else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 1);
+      } else {
+        if (act == PTGNN_AMD_ACT_TANH) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_TANH, 2);
+        else if (act == PTGNN_AMD_ACT_RELU) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_RELU, 2);
+        else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 2);
+      }
+#undef PTGNN_EDGE_LAUNCH
+      PTGNN_LAUNCH_CHECK();
+    }
+    row_base += tab.edge_off[tab.num_types];
+  }
+  return PTGNN_AMD_OK;
+}

@@ -73,6 +73,17 @@ def _no_grad_needed(*tensors) -> bool:
     return not any(t is not None and t.requires_grad for t in tensors)
 
 
+# Per-edge grouped GEMM vs per-node pre-transform: FLOPs are 2*E*K*M vs 2*N*T*K*M, the per-edge rows pay a
+# random 512-B gather each; measured crossover on MI355X (profiles/) is near E ~ 0.8 * N * T.
+EDGE_PATH_BIAS = 1.25
+
+
+def _prefer_edge_path(num_edges: int, num_nodes: int, num_types: int, state_dim: int, msg_dim: int) -> bool:
+    if state_dim % 32 != 0 or msg_dim % 4 != 0 or num_types < 2:
+        return False
+    return num_edges * EDGE_PATH_BIAS < num_nodes * num_types
+
+
 def _check_device(node_states: torch.Tensor):
     if not node_states.is_cuda:
         raise _lib.PtgnnAmdError(
@@ -175,8 +186,15 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
         plan = ops.plan_for(adjacency_lists, num_nodes)
         gru = self.__state_update
         if self._fused_ok(node_states, edge_features):
-            y = ops.linear(node_states, self._stacked_edge_weights())          # [N, T*M]
-            agg = ops.gather_reduce(y, plan, self._message_dimension, self.__aggregation_fn)
+            M, T = self._message_dimension, len(adjacency_lists)
+            if _prefer_edge_path(plan.num_edges, num_nodes, T, self.__state_dimension, M):
+                # many sparse edge types: one grouped per-edge GEMM, messages in reference order
+                msgs = ops.edge_linear(node_states, adjacency_lists,
+                                       [l.weight for l in self.__edge_message_transformation_layers], False)
+                agg = ops.gather_reduce(msgs, plan, M, self.__aggregation_fn, type_bits=0, col=plan.perm)
+            else:
+                y = ops.linear(node_states, self._stacked_edge_weights())      # [N, T*M]
+                agg = ops.gather_reduce(y, plan, M, self.__aggregation_fn)
             return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
 
         # general per-edge path (training / dropout / edge features): message order = type-major
@@ -305,7 +323,7 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             return False
         return _no_grad_needed(node_states, *self.parameters())
 
-    def _aggregate_and_update(self, ysrc, ydst, plan) -> torch.Tensor:
+    def _aggregate_and_update(self, ysrc, ydst, plan, col=None, type_bits=None) -> torch.Tensor:
         """Fused gather/reduce with GELU + LayerNorm folded into the kernel epilogue when the
         layer's activation/normalisation are the stock ones, then the dense update."""
         M = self._message_dimension
@@ -318,9 +336,9 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
                 ysrc, plan, M, self.__aggregation_fn, ydst=ydst, epilogue=epi,
                 ln_weight=self._ln.weight if self._ln is not None else None,
                 ln_bias=self._ln.bias if self._ln is not None else None,
-                ln_eps=self._ln.eps if self._ln is not None else 1e-5)
+                ln_eps=self._ln.eps if self._ln is not None else 1e-5, col=col, type_bits=type_bits)
             return self._update(agg, True)
-        agg = ops.gather_reduce(ysrc, plan, M, self.__aggregation_fn, ydst=ydst)
+        agg = ops.gather_reduce(ysrc, plan, M, self.__aggregation_fn, ydst=ydst, col=col, type_bits=type_bits)
         return self._update(agg, False)
 
     def forward_sharded(self, node_states: torch.Tensor, shard) -> torch.Tensor:
@@ -375,6 +393,11 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
 
         if self._fused_ok(node_states, edge_features):
             plan = ops.plan_for(adjacency_lists, num_nodes)
+            if _prefer_edge_path(plan.num_edges, num_nodes, T, self.__input_state_dim, M):
+                msgs = ops.edge_linear(node_states, adjacency_lists,
+                                       [m.linears[0].weight for m in self.__edge_message_transformation_layers],
+                                       self.__use_target_state_as_message_input)
+                return self._aggregate_and_update(msgs, None, plan, col=plan.perm, type_bits=0)
             y = ops.linear(node_states, self._stacked_edge_weights())
             ysrc = y[:, :T * M]
             ydst = y[:, T * M:] if self.__use_target_state_as_message_input else None

@@ -275,6 +275,42 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+def edge_linear(x: torch.Tensor, adjacency_lists, weights: Sequence[torch.Tensor], use_dst: bool,
+                act: Optional[str] = None) -> torch.Tensor:
+    """msg[off_t + e] = act([x[src_t[e]] ; x[dst_t[e]] (if use_dst)] W_t^T) for every edge type in one
+    launch; rows in type-major message order.  weights[t] is the type's nn.Linear weight."""
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    x = _rowmajor(x)
+    T = len(adjacency_lists)
+    H = x.shape[1]
+    M = weights[0].shape[0]
+    counts = [int(a[0].shape[0]) for a in adjacency_lists]
+    E = sum(counts)
+    msg = torch.empty(max(E, 1), M, dtype=torch.float32, device=x.device)
+    ws = [w.detach().contiguous() for w in weights]
+    for w in ws:
+        if tuple(w.shape) != (M, H * (2 if use_dst else 1)) or not w.is_cuda or w.dtype != torch.float32:
+            raise _lib.PtgnnAmdError(f"edge_linear: weight shape {tuple(w.shape)} does not match "
+                                     f"[{M}, {H * (2 if use_dst else 1)}]")
+    srcs = [a[0].contiguous() for a in adjacency_lists]
+    dsts = [a[1].contiguous() for a in adjacency_lists]
+    PtrArr, CntArr = ctypes.c_void_p * T, ctypes.c_int64 * T
+    sp = PtrArr(*[s.data_ptr() if s.numel() else None for s in srcs])
+    dp = PtrArr(*[d.data_ptr() if d.numel() else None for d in dsts])
+    wp = PtrArr(*[w.data_ptr() for w in ws])
+    cn = CntArr(*counts)
+    K = H * (2 if use_dst else 1)
+    with _timed("edge_linear", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
+        rc = lib.ptgnn_amd_edge_linear_f32(x.data_ptr(), _ld(x), H, ctypes.cast(sp, ctypes.c_void_p),
+                                           ctypes.cast(dp, ctypes.c_void_p) if use_dst else None,
+                                           ctypes.cast(cn, ctypes.c_void_p),
+                                           ctypes.cast(wp, ctypes.c_void_p), T, M, ACT_IDS[act],
+                                           msg.data_ptr(), M, _stream(msg))
+    _lib.check(rc, "ptgnn_amd_edge_linear_f32")
+    return msg[:E] if E > 0 else msg[:0]
+
+
 def gru_cell(a: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh) -> torch.Tensor:
     lib = _lib.load()
     _require_cuda_f32("a", a)

@@ -433,3 +433,58 @@ def test_sharded_layer_equals_unsharded(kind, agg):
     got = torch.cat(outs)
     # each destination row is reduced on one rank in the unsharded order -> identical results
     np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# grouped per-edge GEMM (many sparse edge types)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("use_dst", [False, True])
+@pytest.mark.parametrize("H,M", [(32, 64), (128, 128), (64, 200)])
+def test_edge_linear_matches_reference_order(use_dst, H, M):
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(H + M)
+    n = 700
+    counts = [1000, 0, 129, 1, 128, 513]
+    adj = [(torch.randint(0, n, (c,), generator=g), torch.randint(0, n, (c,), generator=g)) for c in counts]
+    x = torch.randn(n, H, generator=g)
+    K = 2 * H if use_dst else H
+    ws = [torch.randn(M, K, generator=g) / K ** 0.5 for _ in counts]
+    want = torch.cat([(torch.cat([x[s], x[d]], -1) if use_dst else x[s]).double() @ w.double().t()
+                      for (s, d), w in zip(adj, ws)]).float()
+    got = ops.edge_linear(x.cuda(), to_cuda_adj(adj), [w.cuda() for w in ws], use_dst).cpu()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("kind", ["ggnn", "mlp", "mlp_notarget"])
+@pytest.mark.parametrize("agg", ["sum", "max"])
+def test_edge_path_equals_pretransform_path_and_oracle(kind, agg, monkeypatch):
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, ops, workloads
+    mb = workloads.batched_graphs(5, 400, 6, 2.2, seed=3)
+    N, H = mb["num_nodes"], 64
+    adj = O.augment_adjacency(mb["adjacency_lists"], N, True, True)     # T = 13, E ~ 5.4 N
+    T = len(adj)
+    torch.manual_seed(9)
+    if kind == "ggnn":
+        layer = L.GatedMessagePassingLayer(H, H, T, agg)
+    else:
+        layer = L.MlpMessagePassingLayer(H, H, H, T, agg, use_target_state_as_message_input=kind == "mlp")
+    x = workloads.node_states(N, H, seed=4)
+    feats = [torch.empty(a[0].shape[0], 0) for a in adj]
+    want = (O.ggnn_layer if kind == "ggnn" else O.mlp_mp_layer)(x, adj, feats, layer.export_weights())
+    layer = layer.cuda().eval()
+    cadj = to_cuda_adj(adj)
+    outs = {}
+    for name, bias in (("edge", 1e-9), ("node", 1e9)):
+        monkeypatch.setattr(L, "EDGE_PATH_BIAS", bias)
+        ops.clear_plan_cache()
+        timer = ops.KernelTimer()
+        ops.set_kernel_timer(timer)
+        with torch.no_grad():
+            outs[name] = layer(x.cuda(), cadj, None, {}, {}, empty_feats(cadj, "cuda")).cpu()
+        ops.set_kernel_timer(None)
+        used = set(timer.summary())
+        assert ("edge_linear" in used) == (name == "edge"), used
+    np.testing.assert_allclose(outs["edge"].numpy(), want.numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(outs["node"].numpy(), want.numpy(), rtol=0, atol=TOL)
