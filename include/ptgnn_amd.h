@@ -82,7 +82,10 @@ int ptgnn_amd_csr_build(const int64_t *const *src_per_type, /* host [num_types] 
                         const int64_t *const *dst_per_type, /* host [num_types] of device ptrs */
                         const int64_t *edges_per_type,      /* host [num_types]                */
                         int32_t num_types, int64_t num_nodes, int64_t num_src_rows,
-                        int swap_src_dst, /* 1: build the transposed plan (rows = sources)     */
+                        int swap_src_dst, /* 0: rows = dst, col = (src << type_bits) | type          *
+                                           * 1: rows = src, col = (dst << type_bits) | type          *
+                                           * 2: rows = src * num_types + type, col = dst; pass       *
+                                           *    num_nodes = source rows * num_types (backward plan)  */
                         int32_t *rowptr, int32_t *col, int32_t *perm /* nullable */,
                         void *workspace, size_t workspace_bytes, void *stream);
 

@@ -27,7 +27,11 @@ struct TypeTable {
   int32_t type_base;  // global type id of entry 0 (for > kMaxTypes chunking)
 };
 
-__global__ __launch_bounds__(256) void k_pack(TypeTable tab, int32_t type_bits, int swap,
+// mode 0: rows = dst,            payload = (src << type_bits) | type   (forward plan)
+// mode 1: rows = src,            payload = (dst << type_bits) | type   (transposed plan)
+// mode 2: rows = src * T + type, payload = dst                         (backward of the message table:
+//         row r of the [N*T, M] gradient view sums the output gradients of its out-edges)
+__global__ __launch_bounds__(256) void k_pack(TypeTable tab, int32_t type_bits, int mode, int total_types,
                                               uint32_t *__restrict__ keys,
                                               int32_t *__restrict__ pos,
                                               int32_t *__restrict__ packed, int64_t pos_base) {
@@ -42,11 +46,17 @@ __global__ __launch_bounds__(256) void k_pack(TypeTable tab, int32_t type_bits, 
     }
     const int64_t i = e - tab.offset[lo];
     int64_t s = tab.src[lo][i], d = tab.dst[lo][i];
-    if (swap) { const int64_t t = s; s = d; d = t; }
+    const int64_t ty = tab.type_base + lo;
     const int64_t g = pos_base + e;
-    keys[g] = (uint32_t)d;
     pos[g] = (int32_t)g;
-    packed[g] = (int32_t)((s << type_bits) | (int64_t)(tab.type_base + lo));
+    if (mode == 2) {
+      keys[g] = (uint32_t)(s * total_types + ty);
+      packed[g] = (int32_t)d;
+    } else {
+      if (mode == 1) { const int64_t t = s; s = d; d = t; }
+      keys[g] = (uint32_t)d;
+      packed[g] = (int32_t)((s << type_bits) | ty);
+    }
   }
 }
 
@@ -157,9 +167,12 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
                   PTGNN_AMD_EINVAL, "csr_build: null adjacency list for type %d", t);
     num_edges += edges_per_type[t];
   }
+  PTGNN_REQUIRE(swap_src_dst >= 0 && swap_src_dst <= 2, PTGNN_AMD_EINVAL, "csr_build: bad mode");
   const int type_bits = ptgnn_amd_type_bits(num_types);
+  // mode 2: `num_nodes` is the number of plan rows = source rows * num_types (caller passes it so)
   const int64_t src_rows = num_src_rows > num_nodes ? num_src_rows : num_nodes;
-  PTGNN_REQUIRE(num_edges < ((int64_t)1 << 31) && (src_rows << type_bits) < ((int64_t)1 << 31),
+  PTGNN_REQUIRE(num_edges < ((int64_t)1 << 31) &&
+                    (src_rows << (swap_src_dst == 2 ? 0 : type_bits)) < ((int64_t)1 << 31),
                 PTGNN_AMD_EUNSUPPORTED,
                 "csr_build: num_edges=%lld / source rows=%lld x 2^%d exceed the int32 plan format",
                 (long long)num_edges, (long long)src_rows, type_bits);
@@ -189,7 +202,7 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
       if (chunk > 0) {
         const int64_t blocks = (chunk + 255) / 256;
         k_pack<<<(unsigned)(blocks < 4096 ? blocks : 4096), 256, 0, stream>>>(
-            tab, type_bits, swap_src_dst, keys_in, pos_in, packed, base);
+            tab, type_bits, swap_src_dst, num_types, keys_in, pos_in, packed, base);
         PTGNN_LAUNCH_CHECK();
       }
       base += chunk;

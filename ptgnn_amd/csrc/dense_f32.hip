@@ -211,7 +211,7 @@ template <bool ALIGNED, int ACT, int NJ>
 __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
     const float *__restrict__ x, int64_t rows, int K, int64_t ld_x, const float *__restrict__ w,
     int n_out, const float *__restrict__ bias, float *__restrict__ y, int64_t ld_y,
-    int64_t num_tiles, int col_tiles, int vec_store) {
+    int64_t num_tiles, int col_tiles, int vec_store, int ablate) {
   constexpr int BN = 64 * NJ;
   constexpr int B_FLOATS = BN * LDS_LD;
   constexpr int SLAB_LD = 32 * NJ + 4;
@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
 
   Stager<128, ALIGNED, RowClamp> sa;
   Stager<BN, ALIGNED, RowClamp> sb;
-  const RowClamp ra{row0, rows}, rb{col0, n_out};
+  // ablation 16: fold the A rows onto a 2 MB (L2-resident) window => no HBM reads
+  const RowClamp ra{(ablate & 16) ? (row0 & 4095) : row0, rows}, rb{col0, n_out};
   const int nchunks = (K + BK - 1) / BK;
   sa.load(x, ld_x, 0, K, ra);
   sb.load(w, K, 0, K, rb);
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
     }
   }
 
+  if ((ablate & 1) && acc[0][0][0] != 123.456f) return;
   __syncthreads();  // operand buffers are reused as the epilogue slabs
   float *const slab = smem + wave * SLAB_FLOATS;
   constexpr int LPRW = 8 * NJ;             // lanes per output row (float4 each)
@@ -296,8 +298,220 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
 #pragma unroll
     for (int it = 0; it < 32 / RPI; ++it) {
       const int rl = it * RPI + rsub;
-      const int64_t grow = rbase + rl;
+      int64_t grow = rbase + rl;
+      if (ablate & 8) grow &= 1023;  // ablation 8: fold the output onto 1 MB => no HBM writes
       float4 v = *reinterpret_cast<const float4 *>(slab + rl * SLAB_LD + c4);
+      v.x = act_apply<ACT>(v.x + bv.x);
+      v.y = act_apply<ACT>(v.y + bv.y);
+      v.z = act_apply<ACT>(v.z + bv.z);
+      v.w = act_apply<ACT>(v.w + bv.w);
+      if (grow < rows) {
+        float *dst = y + grow * ld_y + gcol;
+        if (vec_store && gcol + 3 < n_out) {
+          *reinterpret_cast<float4 *>(dst) = v;
+        } else {
+          if (gcol + 0 < n_out) dst[0] = v.x;
+          if (gcol + 1 < n_out) dst[1] = v.y;
+          if (gcol + 2 < n_out) dst[2] = v.z;
+          if (gcol + 3 < n_out) dst[3] = v.w;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// linear, persistent with a SOFTWARE-PIPELINED EPILOGUE ("pp").  The r01 ablations show the
+// one-shot kernel loses 22-27 % to its epilogue even when the output folds onto an L2-resident
+// window (so it is the epilogue's own LDS/store instruction stream, not HBM), and co-resident
+// workgroups convoy into lockstep so nobody's MFMAs cover it.  Here each wave keeps TWO accumulator
+// sets: while tile i+1 accumulates into one, tile i's fragments are drained from the other in
+// two halves -- slab writes, float4 read-back and global stores threaded between the MFMA groups of
+// tile i+1's first K-chunks -- so every wave issues one uniform MFMA-dense stream and lockstep no
+// longer matters.  The next chunk (also across tile boundaries) is prefetched into registers.
+// ---------------------------------------------------------------------------------------------
+template <bool ALIGNED, int ACT, int NJ>
+__global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void k_linear_pp(
+    const float *__restrict__ x, int64_t rows, int K, int64_t ld_x, const float *__restrict__ w,
+    int n_out, const float *__restrict__ bias, float *__restrict__ y, int64_t ld_y,
+    int64_t num_tiles, int col_tiles, int vec_store) {
+  constexpr int BN = 64 * NJ;
+  constexpr int B_FLOATS = BN * LDS_LD;
+  constexpr int SLAB_LD = 32 * NJ + 4;
+  constexpr int SLAB_FLOATS = 32 * SLAB_LD;
+  __shared__ __attribute__((aligned(16))) float smem[TILE_FLOATS + B_FLOATS + 4 * SLAB_FLOATS];
+  float *const As = smem, *const Bs = smem + TILE_FLOATS;
+  float *const slab = smem + TILE_FLOATS + B_FLOATS + (threadIdx.x >> 6) * SLAB_FLOATS;  // wave-private
+
+  const TileWalk walk((uint32_t)num_tiles);
+  const int nchunks = (K + BK - 1) / BK;
+  const uint32_t ntiles_mine = walk.count();
+  if (ntiles_mine == 0) return;
+  const int64_t total = (int64_t)ntiles_mine * nchunks;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hi = lane >> 5;
+  constexpr int LPRW = 8 * NJ, RPI = 64 / LPRW, NIT = 32 / RPI;  // read-back geometry of a half
+  const int c4 = (lane % LPRW) * 4, rsub = lane / LPRW;
+
+  f32x16 acc[2][2][NJ];  // [tile parity][i][j]
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][i][j][r] = 0.f;
+
+  Stager<128, ALIGNED, RowClamp> sa;
+  Stager<BN, ALIGNED, RowClamp> sb;
+  TileCursor ld, cp;
+  ld.init(walk, col_tiles);
+  cp.init(walk, col_tiles);
+  int64_t ld_left = total;
+  auto issue_load = [&]() {  // past the end the cursor parks on the last chunk (harmless re-load)
+    sa.load(x, ld_x, ld.chunk * BK, K, RowClamp{(int64_t)ld.row_tile * 128, rows});
+    sb.load(w, K, ld.chunk * BK, K, RowClamp{(int64_t)ld.col_tile * BN, n_out});
+    if (--ld_left > 0) ld.advance(walk, col_tiles, nchunks);
+  };
+
+  // the tile whose fragments sit in acc[parity ^ 1], waiting to be drained
+  int64_t prev_row0 = 0;
+  int prev_col0 = 0;
+  bool has_prev = false;
+  float4 dreg[NIT];
+
+  const float *ap = As + (wm * 64 + li) * LDS_LD + hi;
+  const float *bp = Bs + (wn * 32 * NJ + li) * LDS_LD + hi;
+
+  auto run_tile = [&](auto PAR) {
+    constexpr int P = decltype(PAR)::value;
+    auto mfma_range = [&](int k0, int k1) {
+#pragma unroll
+      for (int ks = k0; ks < k1; ++ks) {
+        float a[2], b[NJ];
+        a[0] = ap[ks * 2];
+        a[1] = ap[32 * LDS_LD + ks * 2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + ks * 2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[P][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[P][i][j], 0, 0, 0);
+      }
+    };
+    // the three drain steps of half `h` of the previous tile (C fragment: col = lane & 31,
+    // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+    auto drain_write = [&](auto H) {
+      constexpr int h = decltype(H)::value;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[P ^ 1][h][j][r];
+          acc[P ^ 1][h][j][r] = 0.f;
+        }
+      __builtin_amdgcn_wave_barrier();
+    };
+    auto drain_read = [&]() {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        dreg[it] = *reinterpret_cast<const float4 *>(slab + (it * RPI + rsub) * SLAB_LD + c4);
+      __builtin_amdgcn_wave_barrier();
+    };
+    auto drain_store = [&](int h) {
+      const int gcol = prev_col0 + wn * 32 * NJ + c4;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias) {
+        if (gcol + 0 < n_out) bv.x = bias[gcol + 0];
+        if (gcol + 1 < n_out) bv.y = bias[gcol + 1];
+        if (gcol + 2 < n_out) bv.z = bias[gcol + 2];
+        if (gcol + 3 < n_out) bv.w = bias[gcol + 3];
+      }
+      const int64_t rbase = prev_row0 + wm * 64 + h * 32;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int64_t grow = rbase + it * RPI + rsub;
+        float4 v = dreg[it];
+        v.x = act_apply<ACT>(v.x + bv.x);
+        v.y = act_apply<ACT>(v.y + bv.y);
+        v.z = act_apply<ACT>(v.z + bv.z);
+        v.w = act_apply<ACT>(v.w + bv.w);
+        if (grow < rows) {
+          float *dst = y + grow * ld_y + gcol;
+          if (vec_store && gcol + 3 < n_out) {
+            *reinterpret_cast<float4 *>(dst) = v;
+          } else {
+            if (gcol + 0 < n_out) dst[0] = v.x;
+            if (gcol + 1 < n_out) dst[1] = v.y;
+            if (gcol + 2 < n_out) dst[2] = v.z;
+            if (gcol + 3 < n_out) dst[3] = v.w;
+          }
+        }
+      }
+    };
+
+    const int64_t row0 = (int64_t)cp.row_tile * 128;
+    const int col0 = (int)cp.col_tile * BN;
+    for (int c = 0; c < nchunks; ++c) {
+      lds_barrier();  // everyone is done reading the previous chunk's operands
+      sa.store(As);
+      sb.store(Bs);
+      lds_barrier();
+      issue_load();   // next chunk (possibly the next tile's first) lands under the MFMAs
+      const bool d0 = has_prev && c == 0;
+      const bool d1 = has_prev && c == (nchunks > 1 ? 1 : 0);
+      if (d0) drain_write(std::integral_constant<int, 0>{});
+      mfma_range(0, 4);
+      if (d0) drain_read();
+      mfma_range(4, 8);
+      if (d0) drain_store(0);
+      if (d1) drain_write(std::integral_constant<int, 1>{});
+      mfma_range(8, 12);
+      if (d1) drain_read();
+      mfma_range(12, 16);
+      if (d1) drain_store(1);
+      cp.advance(walk, col_tiles, nchunks);
+    }
+    prev_row0 = row0;
+    prev_col0 = col0;
+    has_prev = true;
+  };
+
+  issue_load();
+  for (uint32_t ti = 0; ti < ntiles_mine; ti += 2) {
+    run_tile(std::integral_constant<int, 0>{});
+    if (ti + 1 >= ntiles_mine) break;
+    run_tile(std::integral_constant<int, 1>{});
+  }
+
+  // drain the last tile (nothing left to hide it behind)
+  const int lastp = (int)((ntiles_mine - 1) & 1);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] =
+            lastp ? acc[1][h][j][r] : acc[0][h][j][r];
+    __builtin_amdgcn_wave_barrier();
+    const int gcol = prev_col0 + wn * 32 * NJ + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) {
+      if (gcol + 0 < n_out) bv.x = bias[gcol + 0];
+      if (gcol + 1 < n_out) bv.y = bias[gcol + 1];
+      if (gcol + 2 < n_out) bv.z = bias[gcol + 2];
+      if (gcol + 3 < n_out) bv.w = bias[gcol + 3];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int64_t grow = prev_row0 + wm * 64 + h * 32 + it * RPI + rsub;
+      float4 v = *reinterpret_cast<const float4 *>(slab + (it * RPI + rsub) * SLAB_LD + c4);
       v.x = act_apply<ACT>(v.x + bv.x);
       v.y = act_apply<ACT>(v.y + bv.y);
       v.z = act_apply<ACT>(v.z + bv.z);
@@ -639,9 +853,15 @@ extern "C" int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int
   const int col_tiles = (n_out + bn - 1) / bn;
   const int64_t num_tiles = row_tiles * col_tiles;
   PTGNN_REQUIRE(num_tiles < ((int64_t)1 << 31), PTGNN_AMD_EUNSUPPORTED, "linear: too many tiles");
+#ifdef PTGNN_AMD_ABLATE
+  const char *ab = getenv("PTGNN_AMD_ABLATE");
+  const int ablate = ab ? atoi(ab) : 0;
+#else
+  const int ablate = 0;
+#endif
   const int mode = linear_mode();  // 0 shared-tile one-shot, 1 persistent, 2 wave-private staging
-  const bool persistent = mode == 1;
-  const unsigned grid = persistent ? persistent_grid(num_tiles, linear_bpc(nj))
+  const bool persistent = mode == 1 || mode == 3;
+  const unsigned grid = persistent ? persistent_grid(num_tiles, mode == 3 ? (linear_bpc(0) > 0 && getenv("PTGNN_AMD_LINEAR_BPC") ? linear_bpc(nj) : (nj == 1 ? 3 : 2)) : linear_bpc(nj))
                                    : (unsigned)xcd_padded_blocks(num_tiles);
   const bool al = (k % 4 == 0) && (ld_x % 4 == 0) && aligned16(x) && aligned16(w);
   const int vec_store = (ld_y % 4 == 0) && aligned16(y);
@@ -655,12 +875,15 @@ extern "C" int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int
     if (persistent)                                                                            \
       k_linear<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y, ld_y,   \
                                                   num_tiles, col_tiles, vec_store, stagger);   \
+    else if (mode == 3)                                                                        \
+      k_linear_pp<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y, ld_y,  \
+                                                     num_tiles, col_tiles, vec_store);         \
     else if (mode == 2)                                                                        \
       k_linear_wp<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y,      \
                                                      ld_y, num_tiles, col_tiles, vec_store);   \
     else                                                                                       \
-      k_linear_tlp<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y,     \
-                                                      ld_y, num_tiles, col_tiles, vec_store);  \
+      k_linear_tlp<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y, ld_y, \
+                                                      num_tiles, col_tiles, vec_store, ablate); \
   } while (0)
 #define PTGNN_LINEAR_ACT(AL, NJ)                                                          \
   do {                                                                                    \

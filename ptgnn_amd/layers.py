@@ -26,7 +26,7 @@ import torch
 from torch import nn
 
 from ptgnn_amd import _lib, ops
-from ptgnn_amd.scatter import segment_reduce
+from ptgnn_amd.scatter import gather_reduce as gather_reduce_autograd, segment_reduce
 
 try:  # inside a ptgnn install the layers ARE ptgnn layers
     from ptgnn.neuralmodels.gnn.messagepassing.abstractmessagepassing import (  # type: ignore
@@ -167,14 +167,18 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                 self._stacked = (key, torch.cat([w.detach() for w in ws], dim=0).contiguous())
         return self._stacked[1]
 
-    def _fused_ok(self, node_states, edge_features) -> bool:
+    def _table_ok(self, node_states, edge_features) -> bool:
+        """Message == row of the per-node table X [W_0; ...]^T: no edge features, no per-edge dropout."""
         if self._edge_feature_dimension != 0 or any(f is not None and f.shape[-1] != 0 for f in edge_features):
             return False
         if self.training and self.__dropout.p > 0:
             return False
-        if node_states.dtype != torch.float32:
+        return node_states.dtype == torch.float32
+
+    def _fused_ok(self, node_states, edge_features) -> bool:
+        if not self._table_ok(node_states, edge_features):
             return False
-        return _no_grad_needed(node_states, *self.parameters())
+        return (not torch.is_grad_enabled()) or _no_grad_needed(node_states, *self.parameters())
 
     def forward(self, node_states: torch.Tensor, adjacency_lists: Adj, node_to_graph_idx,
                 reference_node_ids: Dict[str, torch.Tensor],
@@ -197,7 +201,15 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                 agg = ops.gather_reduce(y, plan, M, self.__aggregation_fn)
             return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
 
-        # general per-edge path (training / dropout / edge features): message order = type-major
+        if self._table_ok(node_states, edge_features):
+            # training without per-edge dropout: torch (rocBLAS) for the dense blocks so autograd owns
+            # them, the HIP kernel (forward + backward) for the aggregation
+            w = torch.cat([l.weight for l in self.__edge_message_transformation_layers], dim=0)
+            y = nn.functional.linear(node_states, w)
+            agg = gather_reduce_autograd(y, None, plan, self._message_dimension, self.__aggregation_fn)
+            return gru(agg, node_states)
+
+        # general per-edge path (per-edge dropout / edge features): message order = type-major
         all_messages = []
         for (src, _), feats, lin in zip(adjacency_lists, edge_features,
                                         self.__edge_message_transformation_layers):
@@ -312,16 +324,19 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
                 self._stacked = (key, torch.cat(parts, dim=0).contiguous())   # [(1|2)*T*M, H]
         return self._stacked[1]
 
-    def _fused_ok(self, node_states, edge_features) -> bool:
+    def _table_ok(self, node_states, edge_features) -> bool:
         if not isinstance(self.__aggregation_fn, str):
             return False
         if self._features_dimension != 0 or any(f is not None and f.shape[-1] != 0 for f in edge_features):
             return False
         if not all(m.is_single_linear for m in self.__edge_message_transformation_layers):
             return False
-        if node_states.dtype != torch.float32:
+        return node_states.dtype == torch.float32
+
+    def _fused_ok(self, node_states, edge_features) -> bool:
+        if not self._table_ok(node_states, edge_features):
             return False
-        return _no_grad_needed(node_states, *self.parameters())
+        return (not torch.is_grad_enabled()) or _no_grad_needed(node_states, *self.parameters())
 
     def _aggregate_and_update(self, ysrc, ydst, plan, col=None, type_bits=None) -> torch.Tensor:
         """Fused gather/reduce with GELU + LayerNorm folded into the kernel epilogue when the
@@ -402,6 +417,20 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             ysrc = y[:, :T * M]
             ydst = y[:, T * M:] if self.__use_target_state_as_message_input else None
             return self._aggregate_and_update(ysrc, ydst, plan)
+
+        if self._table_ok(node_states, edge_features):
+            # training: dense blocks through torch autograd, aggregation fwd + bwd on the HIP kernel
+            plan = ops.plan_for(adjacency_lists, num_nodes)
+            H = self.__input_state_dim
+            ws = [m.linears[0].weight for m in self.__edge_message_transformation_layers]
+            parts = [w[:, :H] for w in ws]
+            if self.__use_target_state_as_message_input:
+                parts += [w[:, H:2 * H] for w in ws]
+            y = nn.functional.linear(node_states, torch.cat(parts, dim=0))
+            ysrc = y[:, :T * M]
+            ydst = y[:, T * M:] if self.__use_target_state_as_message_input else None
+            agg = gather_reduce_autograd(ysrc, ydst, plan, M, self.__aggregation_fn)
+            return self._update(agg, False)
 
         # general per-edge path
         all_targets, all_messages = [], []

@@ -103,20 +103,46 @@ class GraphPlan:
     """
 
     __slots__ = ("rowptr", "col", "perm", "type_bits", "num_nodes", "num_edges", "num_types",
-                 "_transposed", "_adj_refs", "__weakref__")
+                 "num_src_rows", "_backward", "_adj", "_adj_refs", "_inv_perm", "__weakref__")
 
     def __init__(self, rowptr, col, perm, type_bits, num_nodes, num_edges, num_types):
         self.rowptr, self.col, self.perm = rowptr, col, perm
         self.type_bits, self.num_nodes = type_bits, num_nodes
         self.num_edges, self.num_types = num_edges, num_types
-        self._transposed = None
+        self.num_src_rows = num_nodes
+        self._backward = None
+        self._adj = None       # the adjacency tensors the plan was built from (for the backward plan)
         self._adj_refs = None
+        self._inv_perm = None
+
+    def backward_plan(self) -> "GraphPlan":
+        """Plan of the transposed problem, rows = src * T + type, col = dst: row r of the [N*T, M] view
+        of the message-table gradient sums the output gradients of its out-edges.  Built lazily on the
+        first backward of a minibatch and shared by all layers."""
+        if self._backward is None:
+            if self._adj is None:
+                raise _lib.PtgnnAmdError("this plan was built without keeping its adjacency lists")
+            self._backward = build_plan(self._adj, self.num_src_rows * self.num_types, mode=2)
+        return self._backward
+
+    def inverse_perm(self) -> torch.Tensor:
+        """original edge position -> CSR slot (int64)."""
+        if self._inv_perm is None:
+            inv = torch.empty(max(self.num_edges, 1), dtype=torch.int64, device=self.perm.device)
+            inv[self.perm[: self.num_edges].to(torch.int64)] = torch.arange(
+                self.num_edges, device=self.perm.device)
+            self._inv_perm = inv
+        return self._inv_perm
 
 
 def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num_nodes: int,
                transposed: bool = False, want_perm: bool = True,
-               num_src_rows: Optional[int] = None) -> GraphPlan:
-    """One stable sort per minibatch; reused by every layer of the forward."""
+               num_src_rows: Optional[int] = None, mode: Optional[int] = None) -> GraphPlan:
+    """One stable sort per minibatch; reused by every layer of the forward.  mode: 0 forward plan
+    (rows = dst), 1 transposed (rows = src), 2 backward plan (rows = src * T + type, col = dst;
+    `num_nodes` must then be source rows * T)."""
+    if mode is None:
+        mode = 1 if transposed else 0
     lib = _lib.load()
     T = len(adjacency_lists)
     if T == 0:
@@ -153,14 +179,18 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
                                      ctypes.cast(dst_ptrs, ctypes.c_void_p),
                                      ctypes.cast(cnts, ctypes.c_void_p), T, num_nodes,
                                      int(num_src_rows or 0),
-                                     1 if transposed else 0, rowptr.data_ptr(), col.data_ptr(),
+                                     mode, rowptr.data_ptr(), col.data_ptr(),
                                      perm.data_ptr() if perm is not None else None, ws.data_ptr(),
                                      ws_bytes, _stream(rowptr))
     _lib.check(rc, "ptgnn_amd_csr_build")
     # `ws`, `srcs`, `dsts` are stream-ordered: torch's caching allocator only hands their memory to
     # later work on the same stream, so dropping the references here is safe.
     # col/perm keep >= 1 element so their base pointer is never null (E == 0 batches are legal)
-    return GraphPlan(rowptr, col, perm, type_bits, num_nodes, E, T)
+    plan = GraphPlan(rowptr, col, perm, 0 if mode == 2 else type_bits, num_nodes, E, T)
+    if mode == 0:
+        plan.num_src_rows = int(num_src_rows or num_nodes)
+        plan._adj = list(zip(srcs, dsts))
+    return plan
 
 
 _PLAN_CACHE: List[GraphPlan] = []

@@ -88,3 +88,90 @@ def scatter(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional
     plan = ops.build_plan([(index, index)], int(dim_size))
     res = segment_reduce(src.to(torch.float32), plan, reduce).to(dt)
     return res.squeeze(1) if squeeze else res
+
+
+class _GatherReduce(torch.autograd.Function):
+    """Differentiable fused aggregation  out[v] = REDUCE_i ( ysrc[src_i, t_i] (+ ydst[v, t_i]) )  over a
+    plan.  Forward and the heavy half of backward are the HIP gather/segment-reduce kernel:
+
+      * sum / mean: d ysrc viewed as [N*T, M] is itself a segment-sum -- row (s, t) adds up the output
+        gradients of its out-edges -- i.e. the SAME kernel over the backward plan (rows = src*T + type,
+        col = dst), deterministic and atomic-free;
+      * max / min : the forward records the winning CSR slot per (node, feature) (torch_scatter's
+        arg_out); the gradient is routed to that slot's edge and then segment-summed per (src, type).
+    """
+
+    @staticmethod
+    def forward(ctx, ysrc, ydst, plan, msg_dim, reduce):
+        needs = ysrc.requires_grad or (ydst is not None and ydst.requires_grad)
+        want_arg = reduce in ("max", "min") and needs
+        res = ops.gather_reduce(ysrc, plan, msg_dim, reduce, ydst=ydst, return_arg=want_arg)
+        ctx.plan, ctx.reduce, ctx.msg_dim = plan, reduce, msg_dim
+        ctx.src_shape = tuple(ysrc.shape)
+        ctx.has_dst = ydst is not None
+        if want_arg:
+            out, arg = res
+            ctx.save_for_backward(arg)
+            return out
+        ctx.save_for_backward()
+        return res
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan, reduce, M = ctx.plan, ctx.reduce, ctx.msg_dim
+        T, N, E = plan.num_types, plan.num_nodes, plan.num_edges
+        g = grad_out.contiguous()
+        dev = g.device
+        need_src, need_dst = ctx.needs_input_grad[0], ctx.has_dst and ctx.needs_input_grad[1]
+        d_src = d_dst = None
+        if E == 0:
+            if need_src:
+                d_src = g.new_zeros(ctx.src_shape)
+            if need_dst:
+                d_dst = g.new_zeros(N, T * M)
+            return d_src, d_dst, None, None, None
+        deg = (plan.rowptr[1:] - plan.rowptr[:-1])
+        mask = (1 << plan.type_bits) - 1
+        if reduce in ("sum", "add", "mean"):
+            if reduce == "mean":
+                g = g / deg.clamp(min=1).to(g.dtype).unsqueeze(1)
+            if need_src:
+                bp = plan.backward_plan()
+                d_src = ops.gather_reduce(g, bp, M, "sum").view(plan.num_src_rows, T * M)
+            if need_dst:
+                if T == 1:
+                    d_dst = g * deg.to(g.dtype).unsqueeze(1)
+                else:  # cnt[v, t] = number of in-edges of type t
+                    slot_t = (plan.col[:E] & mask).to(torch.int64)
+                    slot_v = torch.repeat_interleave(torch.arange(N, device=dev), deg.to(torch.int64),
+                                                     output_size=E)
+                    cnt = torch.zeros(N * T, dtype=g.dtype, device=dev)
+                    cnt.index_add_(0, slot_v * T + slot_t, torch.ones(E, dtype=g.dtype, device=dev))
+                    d_dst = (cnt.view(N, T, 1) * g.view(N, 1, M)).reshape(N, T * M)
+        else:
+            (arg,) = ctx.saved_tensors                                  # [N, M] winning slot or -1
+            valid = arg >= 0
+            slot = arg.clamp(min=0).to(torch.int64)
+            cols = torch.arange(M, device=dev).unsqueeze(0).expand(N, M)
+            if need_src:
+                bp = plan.backward_plan()
+                e_orig = plan.perm[:E].to(torch.int64)[slot]            # original edge of the winner
+                dmsg = g.new_zeros(E * M)
+                dmsg.index_put_(((e_orig * M + cols)[valid],), g[valid])
+                d_src = ops.gather_reduce(dmsg.view(E, M), bp, M, "sum", type_bits=0,
+                                          col=bp.perm).view(plan.num_src_rows, T * M)
+            if need_dst:
+                t_win = (plan.col[:E] & mask).to(torch.int64)[slot]
+                d_dst = g.new_zeros(N, T * M)
+                d_dst.scatter_(1, t_win * M + cols, torch.where(valid, g, torch.zeros_like(g)))
+        if d_src is not None and tuple(d_src.shape) != ctx.src_shape:
+            d_src = d_src.reshape(ctx.src_shape)
+        return d_src, d_dst, None, None, None
+
+
+def gather_reduce(ysrc: torch.Tensor, ydst: Optional[torch.Tensor], plan: "ops.GraphPlan", msg_dim: int,
+                  reduce: str) -> torch.Tensor:
+    """Differentiable fused aggregation over a message table (see `_GatherReduce`)."""
+    if reduce not in ops.REDUCE_IDS:
+        raise ValueError(f"unknown aggregation function {reduce!r}")
+    return _GatherReduce.apply(ysrc, ydst, plan, msg_dim, reduce)
