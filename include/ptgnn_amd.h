@@ -124,6 +124,18 @@ int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_ysrc,
                                 const float *ln_beta, float ln_eps, float *out, int64_t ld_out,
                                 int32_t *argout /* nullable */, void *stream);
 
+/* Backward of the max/min aggregation w.r.t. the message table, over the BACKWARD plan (rows =
+ * src * T + type, col = dst, built by ptgnn_amd_csr_build mode 2):
+ *   out[r, c] = sum_{i in row r}  [ arg[col_i, c] == slot_of[i] ] * grad[col_i, c]
+ * arg = the forward call's argout (winning forward CSR slot per (dst node, feature)); slot_of[i] = the
+ * forward slot of backward slot i.  This is torch_scatter's "gradient flows to arg_out only"
+ * rule (abstractmessagepassing.py:38-50 through torch_scatter's autograd) without materialising the
+ * [E, M] per-edge gradient. */
+int ptgnn_amd_gather_reduce_masked_f32(const float *grad, int64_t ld_grad, const int32_t *arg,
+                                       const int32_t *rowptr, const int32_t *col,
+                                       const int32_t *slot_of, int64_t num_rows, int32_t msg_dim,
+                                       float *out, int64_t ld_out, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * y = act(x W^T + b) on the matrix cores with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * Replaces nn.Linear at gatedmessagepassing.py:20-23,57-61 (all T edge-type weights stacked

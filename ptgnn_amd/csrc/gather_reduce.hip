@@ -48,10 +48,14 @@ struct Args {
   int32_t *argout;
   int64_t num_tiles;
   int32_t epi;
+  const int32_t *mask_arg;   // MASKED: [num source rows of this launch, M] winning forward slot
+  const int32_t *mask_slot;  // MASKED: [E] forward slot of each slot of THIS plan
 };
 
 // VEC = 4: float4 path (msg_dim % 4 == 0, all bases/lds 16-B aligned); VEC = 1: generic.
-template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG>
+// MASKED (sum only): the gathered row is an output gradient that only flows where the forward max/min
+// picked this very edge:  value = (mask_arg[src, c] == mask_slot[i]) ? ysrc[src, c] : 0.
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED = false>
 __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
   constexpr int ROWS_PER_BLOCK = 256 / LPR;
   const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -93,6 +97,26 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
     }
   };
 
+  auto apply_mask = [&](float (&m)[CH][VEC], int64_t srow, int i) {
+    if constexpr (MASKED) {
+      const int want = a.mask_slot[i];
+      const int32_t *ar = a.mask_arg + srow * (int64_t)M;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int colx = cbase + (g + c * LPR) * VEC;
+        if constexpr (VEC == 4) {
+          if (colx < M) {
+            const int4 w = *reinterpret_cast<const int4 *>(ar + colx);
+            m[c][0] = w.x == want ? m[c][0] : 0.f; m[c][1] = w.y == want ? m[c][1] : 0.f;
+            m[c][2] = w.z == want ? m[c][2] : 0.f; m[c][3] = w.w == want ? m[c][3] : 0.f;
+          }
+        } else {
+          if (colx < M) m[c][0] = ar[colx] == want ? m[c][0] : 0.f;
+        }
+      }
+    }
+  };
+
   auto fold = [&](const float (&m)[CH][VEC], int slot) {
 #pragma unroll
     for (int c = 0; c < CH; ++c)
@@ -123,6 +147,7 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
       const int64_t s = pk[u] >> a.type_bits;
       const int t = pk[u] & tmask;
       load_row(a.ysrc + s * a.ld_y + (int64_t)t * M, m[u]);
+      apply_mask(m[u], s, i + u);
       if (HAS_DST) load_row(dst_base + (int64_t)t * M, d[u]);
     }
 #pragma unroll
@@ -142,6 +167,7 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
     const int t = pk & tmask;
     float m[CH][VEC];
     load_row(a.ysrc + s * a.ld_y + (int64_t)t * M, m);
+    apply_mask(m, s, i);
     if (HAS_DST) {
       float d[CH][VEC];
       load_row(dst_base + (int64_t)t * M, d);
@@ -254,10 +280,46 @@ int launch1(const Args &a, int reduce, int epi, int col_blocks, hipStream_t s) {
   }
 }
 
+template <int VEC, int LPR, int CH>
+int launch_masked(const Args &a, int col_blocks, hipStream_t stream) {
+  constexpr int ROWS_PER_BLOCK = 256 / LPR;
+  Args b = a;
+  b.epi = 0;
+  b.num_tiles = (a.num_nodes + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  dim3 grid((unsigned)xcd_padded_blocks(b.num_tiles), (unsigned)col_blocks);
+  k_gather_reduce<VEC, LPR, CH, PTGNN_AMD_SUM, false, false, true><<<grid, 256, 0, stream>>>(b);
+  PTGNN_LAUNCH_CHECK();
+  return PTGNN_AMD_OK;
+}
+
 }  // namespace
 }  // namespace ptgnn_amd
 
 using namespace ptgnn_amd;
+
+extern "C" int ptgnn_amd_gather_reduce_masked_f32(const float *grad, int64_t ld_grad,
+                                                  const int32_t *arg, const int32_t *rowptr,
+                                                  const int32_t *col, const int32_t *slot_of,
+                                                  int64_t num_rows, int32_t msg_dim, float *out,
+                                                  int64_t ld_out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTGNN_REQUIRE(num_rows >= 0 && msg_dim > 0, PTGNN_AMD_EINVAL, "gather_reduce_masked: bad sizes");
+  if (num_rows == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(grad && arg && rowptr && col && slot_of && out && ld_out >= msg_dim && ld_grad >= msg_dim,
+                PTGNN_AMD_EINVAL, "gather_reduce_masked: null/ld");
+  Args a{grad, nullptr, ld_grad, ld_grad, rowptr, col, 0, num_rows, msg_dim, nullptr, nullptr, 0.f,
+         out, ld_out, nullptr, 0, 0, arg, slot_of};
+  const bool vec4 = (msg_dim % 4 == 0) && (ld_grad % 4 == 0) && (ld_out % 4 == 0) && aligned16(grad) &&
+                    aligned16(out) && aligned16(arg);
+  if (vec4) {
+    if (msg_dim <= 64) return launch_masked<4, 16, 1>(a, 1, stream);
+    if (msg_dim <= 128) return launch_masked<4, 32, 1>(a, 1, stream);
+    if (msg_dim <= 256) return launch_masked<4, 64, 1>(a, 1, stream);
+    return launch_masked<4, 64, 2>(a, (msg_dim + 511) / 512, stream);
+  }
+  if (msg_dim <= 64) return launch_masked<1, 64, 1>(a, 1, stream);
+  return launch_masked<1, 64, 4>(a, (msg_dim + 255) / 256, stream);
+}
 
 extern "C" int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_y, const float *ydst,
                                            int64_t ld_yd, const int32_t *rowptr, const int32_t *col,
@@ -280,7 +342,7 @@ extern "C" int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_y, cons
                 "gather_reduce: argout only with max/min");
 
   Args a{ysrc, ydst, ld_y, ydst ? ld_yd : ld_y, rowptr, col, type_bits, num_nodes, msg_dim, ln_gamma, ln_beta, ln_eps,
-         out, ld_out, argout, 0, 0};
+         out, ld_out, argout, 0, 0, nullptr, nullptr};
   const bool vec4 = (msg_dim % 4 == 0) && (ld_y % 4 == 0) && (!ydst || ld_yd % 4 == 0) && (ld_out % 4 == 0) && aligned16(ysrc) &&
                     aligned16(out) && (!ydst || aligned16(ydst)) && (!argout || aligned16(argout));
   const bool row_epi = (epilogue & PTGNN_AMD_EPI_LAYERNORM) != 0;

@@ -125,6 +125,14 @@ class GraphPlan:
             self._backward = build_plan(self._adj, self.num_src_rows * self.num_types, mode=2)
         return self._backward
 
+    def forward_slot_of_backward_slot(self) -> torch.Tensor:
+        """int32 [E]: for slot i of the backward plan, the forward-plan slot of the same edge."""
+        bp = self.backward_plan()
+        if bp._inv_perm is None:   # reuse the field on the backward plan as the cache
+            inv = self.inverse_perm()
+            bp._inv_perm = inv[bp.perm[: self.num_edges].to(torch.int64)].to(torch.int32).contiguous()
+        return bp._inv_perm
+
     def inverse_perm(self) -> torch.Tensor:
         """original edge position -> CSR slot (int64)."""
         if self._inv_perm is None:
@@ -268,6 +276,22 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
             out.data_ptr(), msg_dim, arg.data_ptr() if arg is not None else None, _stream(out))
     _lib.check(rc, "ptgnn_amd_gather_reduce_f32")
     return (out, arg) if return_arg else out
+
+
+def gather_reduce_masked(grad: torch.Tensor, arg: torch.Tensor, bplan: GraphPlan,
+                         slot_of: torch.Tensor, msg_dim: int) -> torch.Tensor:
+    """out[r] = sum_{i in row r} [arg[col_i] == slot_of[i]] * grad[col_i] over a backward plan."""
+    lib = _lib.load()
+    _require_cuda_f32("grad", grad)
+    grad = _rowmajor(grad)
+    out = torch.empty(bplan.num_nodes, msg_dim, dtype=torch.float32, device=grad.device)
+    with _timed("gather_reduce_masked", bytes=bplan.num_edges * (8.0 * msg_dim + 8) + bplan.num_nodes * (4.0 * msg_dim + 4)):
+        rc = lib.ptgnn_amd_gather_reduce_masked_f32(grad.data_ptr(), _ld(grad), arg.data_ptr(),
+                                                    bplan.rowptr.data_ptr(), bplan.col.data_ptr(),
+                                                    slot_of.data_ptr(), bplan.num_nodes, msg_dim,
+                                                    out.data_ptr(), msg_dim, _stream(out))
+    _lib.check(rc, "ptgnn_amd_gather_reduce_masked_f32")
+    return out
 
 
 def segment_reduce(messages: torch.Tensor, plan: GraphPlan, reduce: str, return_arg: bool = False):

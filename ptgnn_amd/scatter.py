@@ -153,13 +153,10 @@ class _GatherReduce(torch.autograd.Function):
             valid = arg >= 0
             slot = arg.clamp(min=0).to(torch.int64)
             cols = torch.arange(M, device=dev).unsqueeze(0).expand(N, M)
-            if need_src:
+            if need_src:   # masked segment-sum over the backward plan: no [E, M] gradient is materialised
                 bp = plan.backward_plan()
-                e_orig = plan.perm[:E].to(torch.int64)[slot]            # original edge of the winner
-                dmsg = g.new_zeros(E * M)
-                dmsg.index_put_(((e_orig * M + cols)[valid],), g[valid])
-                d_src = ops.gather_reduce(dmsg.view(E, M), bp, M, "sum", type_bits=0,
-                                          col=bp.perm).view(plan.num_src_rows, T * M)
+                d_src = ops.gather_reduce_masked(g, arg, bp, plan.forward_slot_of_backward_slot(),
+                                                 M).view(plan.num_src_rows, T * M)
             if need_dst:
                 t_win = (plan.col[:E] & mask).to(torch.int64)[slot]
                 d_dst = g.new_zeros(N, T * M)
