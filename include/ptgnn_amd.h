@@ -87,6 +87,10 @@ int ptgnn_amd_csr_build(const int64_t *const *src_per_type, /* host [num_types] 
                                            * 2: rows = src * num_types + type, col = dst; pass       *
                                            *    num_nodes = source rows * num_types (backward plan)  */
                         int32_t *rowptr, int32_t *col, int32_t *perm /* nullable */,
+                        int32_t *max_degree /* nullable device scalar: longest row */,
+                        int32_t hub_threshold /* 0 = no hub list */,
+                        int32_t *hub_entries /* nullable: int32 [2 * ceil(E/1024)][2] (chunk,row) */,
+                        int32_t *hub_count /* nullable device scalar: number of pairs */,
                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* Optional debug aid (the reference performs no range check either): counts indices outside
@@ -115,14 +119,31 @@ int ptgnn_amd_validate_indices(const int64_t *idx, int64_t n, int64_t num_nodes,
  *   argout: nullable int32 [num_nodes, M]; for max/min the winning CSR slot, -1 if empty
  *          (backward routing; torch_scatter's arg_out).
  *   ln_gamma/ln_beta: LayerNorm affine parameters (EPI_*LAYERNORM only).
+ *
+ * Hub rows (power-law graphs): rows with more than `hub_threshold` in-edges (0 = never; otherwise
+ * >= 2048 and equal to the threshold given to ptgnn_amd_csr_build) are split over 1024-slot chunks:
+ * one small extra launch walks the plan's (chunk, row) list `hub_entries`/`hub_count`; the last
+ * chunk of a hub to arrive folds the chunk partials in order and applies the epilogue, so one
+ * 10^5-edge destination does not serialise on one lane group.  Needs `hub_ws` of
+ * ptgnn_amd_hub_workspace_bytes(num_edges, msg_dim, argout != 0) bytes (scratch) and `hub_tickets`,
+ * int32[ptgnn_amd_hub_ticket_count(num_edges, msg_dim)] that is ZERO on entry (the kernel leaves it
+ * zero again, so one zeroed buffer per plan serves every call on a stream); with either NULL every
+ * row takes the serial path.  Deterministic; a hub row's fp32 fold order differs from the serial
+ * order (max/min and argout are exact).
  * ---------------------------------------------------------------------------------------- */
+size_t ptgnn_amd_hub_workspace_bytes(int64_t num_edges, int32_t msg_dim, int with_arg);
+int64_t ptgnn_amd_hub_ticket_count(int64_t num_edges, int32_t msg_dim);
 int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_ysrc,
                                 const float *ydst /* nullable */, int64_t ld_ydst,
                                 const int32_t *rowptr, const int32_t *col,
                                 int32_t type_bits, int64_t num_nodes, int32_t msg_dim,
                                 int reduce, int epilogue, const float *ln_gamma,
                                 const float *ln_beta, float ln_eps, float *out, int64_t ld_out,
-                                int32_t *argout /* nullable */, void *stream);
+                                int32_t *argout /* nullable */, int64_t num_edges,
+                                int32_t hub_threshold, const int32_t *hub_entries /* nullable */,
+                                const int32_t *hub_count /* nullable */, void *hub_ws /* nullable */,
+                                size_t hub_ws_bytes, int32_t *hub_tickets /* nullable */,
+                                void *stream);
 
 /* Backward of the max/min aggregation w.r.t. the message table, over the BACKWARD plan (rows =
  * src * T + type, col = dst, built by ptgnn_amd_csr_build mode 2):
@@ -134,7 +155,11 @@ int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_ysrc,
 int ptgnn_amd_gather_reduce_masked_f32(const float *grad, int64_t ld_grad, const int32_t *arg,
                                        const int32_t *rowptr, const int32_t *col,
                                        const int32_t *slot_of, int64_t num_rows, int32_t msg_dim,
-                                       float *out, int64_t ld_out, void *stream);
+                                       float *out, int64_t ld_out, int64_t num_edges,
+                                       int32_t hub_threshold, const int32_t *hub_entries,
+                                       const int32_t *hub_count, void *hub_ws /* nullable */,
+                                       size_t hub_ws_bytes, int32_t *hub_tickets /* nullable */,
+                                       void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * y = act(x W^T + b) on the matrix cores with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).

@@ -83,6 +83,41 @@ __global__ __launch_bounds__(256) void k_finish(const uint32_t *__restrict__ key
     for (int64_t v = k + 1; v <= num_nodes; ++v) rowptr[v] = (int32_t)num_edges;
 }
 
+// (chunk, row) pairs of every row longer than `threshold`, appended in arbitrary order (consumers
+// treat the pairs independently); *count must be 0 on entry.
+__global__ __launch_bounds__(256) void k_hub_list(const int32_t *__restrict__ rowptr, int64_t num_rows,
+                                                  int32_t threshold, int32_t chunk,
+                                                  int32_t *__restrict__ entries,
+                                                  int32_t *__restrict__ count) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < num_rows;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    if (end - beg <= threshold) continue;
+    const int c0 = beg / chunk, c1 = (end - 1) / chunk;
+    const int base = atomicAdd(count, c1 - c0 + 1);
+    for (int c = c0; c <= c1; ++c) {
+      entries[2 * (base + c - c0)] = c;
+      entries[2 * (base + c - c0) + 1] = (int32_t)r;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_max_degree(const int32_t *__restrict__ rowptr, int64_t num_rows,
+                                                    int32_t *__restrict__ out) {
+  int best = 0;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < num_rows;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const int d = rowptr[r + 1] - rowptr[r];
+    best = d > best ? d : best;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int other = __shfl_xor(best, o, 64);
+    best = other > best ? other : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(out, best);
+}
+
 __global__ __launch_bounds__(256) void k_validate(const int64_t *__restrict__ idx, int64_t n,
                                                   int64_t num_nodes, int32_t *bad) {
   int local = 0;
@@ -153,8 +188,9 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
                                    const int64_t *edges_per_type, int32_t num_types,
                                    int64_t num_nodes, int64_t num_src_rows, int swap_src_dst,
                                    int32_t *rowptr,
-                                   int32_t *col, int32_t *perm, void *workspace,
-                                   size_t workspace_bytes, void *stream_) {
+                                   int32_t *col, int32_t *perm, int32_t *max_degree,
+                                   int32_t hub_threshold, int32_t *hub_entries, int32_t *hub_count,
+                                   void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PTGNN_REQUIRE(num_types >= 0 && num_nodes >= 0, PTGNN_AMD_EINVAL, "csr_build: negative size");
   PTGNN_REQUIRE(rowptr != nullptr, PTGNN_AMD_EINVAL, "csr_build: rowptr is null");
@@ -216,6 +252,23 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
   k_finish<<<(unsigned)blocks, 256, 0, stream>>>(keys_out, pos_out, packed, num_edges, num_nodes,
                                                  rowptr, col, perm);
   PTGNN_LAUNCH_CHECK();
+  if (hub_entries && hub_count && hub_threshold > 0) {
+    PTGNN_HIP(hipMemsetAsync(hub_count, 0, sizeof(int32_t), stream));
+    if (num_edges > hub_threshold && num_nodes > 0) {
+      const int64_t hb = (num_nodes + 255) / 256;
+      k_hub_list<<<(unsigned)(hb < 2048 ? hb : 2048), 256, 0, stream>>>(rowptr, num_nodes, hub_threshold,
+                                                                        1024, hub_entries, hub_count);
+      PTGNN_LAUNCH_CHECK();
+    }
+  }
+  if (max_degree) {
+    PTGNN_HIP(hipMemsetAsync(max_degree, 0, sizeof(int32_t), stream));
+    if (num_edges > 0 && num_nodes > 0) {
+      const int64_t mb = (num_nodes + 255) / 256;
+      k_max_degree<<<(unsigned)(mb < 1024 ? mb : 1024), 256, 0, stream>>>(rowptr, num_nodes, max_degree);
+      PTGNN_LAUNCH_CHECK();
+    }
+  }
   return PTGNN_AMD_OK;
 }
 

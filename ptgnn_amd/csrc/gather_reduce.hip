@@ -10,14 +10,28 @@
 //   * the edge loop is unrolled x4 with all 4 row loads issued before the first use, to keep
 //     >= 4 KiB per wave in flight against ~1-2 us gather latency;
 //   * consecutive row tiles run on the same XCD (xcd_swizzle) so one graph of a disjoint-union
-//     batch keeps its node states in a single 4 MiB L2.
+//     batch keeps its node states in a single 4 MiB L2;
+//   * HUB rows (in-degree > hub_threshold, power-law graphs): one lane group folding 10^5..10^6
+//     edges serially would set the kernel's duration, so such rows are skipped by the main kernel
+//     and split over 1024-slot chunks: the plan lists every (chunk, hub row) pair once per
+//     minibatch (ptgnn_amd_csr_build), and ONE small extra launch walks that list: a workgroup
+//     reduces its chunk of the hub with all its lane groups (slot-interleaved, combined in a fixed
+//     order), publishes the partial, and the LAST chunk of a hub to arrive (one ticket counter per
+//     hub, agent-scope release/acquire) folds the partials in chunk order and applies the row
+//     epilogue -- deterministic values, no float atomics.  The fold ORDER of a hub row differs from
+//     the reference's serial order (fp32 rounding only; max/min and their arg stay exact).  A plan
+//     without hubs costs one ~2 us launch whose workgroups read a zero count and exit.
 // Algorithmic bytes per edge: 4*M (message row) + 4 (col) ; per node: 4*M (out) [+ 4*M dst term].
 #include <float.h>
+
+#include <type_traits>
 
 #include "common.h"
 
 namespace ptgnn_amd {
 namespace {
+
+constexpr int kHubChunk = 1024;  // CSR slots per hub chunk; hub_threshold must be >= 2 * kHubChunk
 
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -50,36 +64,39 @@ struct Args {
   int32_t epi;
   const int32_t *mask_arg;   // MASKED: [num source rows of this launch, M] winning forward slot
   const int32_t *mask_slot;  // MASKED: [E] forward slot of each slot of THIS plan
+  int32_t hub_threshold;     // rows with more in-edges are left to the hub kernels (0 = no hub path)
+  float *hub_part;           // [2 * num_chunks, M] chunk partials
+  int32_t *hub_arg;          // [2 * num_chunks, M] (argout only)
+  int32_t *hub_tickets;      // [num_chunks * col_blocks] arrival counters, zero between launches
+  const int32_t *hub_entries;  // plan: (chunk, row) pairs
+  const int32_t *hub_count;    // plan: number of pairs
+  int64_t num_edges;
 };
 
-// VEC = 4: float4 path (msg_dim % 4 == 0, all bases/lds 16-B aligned); VEC = 1: generic.
-// MASKED (sum only): the gathered row is an output gradient that only flows where the forward max/min
-// picked this very edge:  value = (mask_arg[src, c] == mask_slot[i]) ? ysrc[src, c] : 0.
-template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED = false>
-__global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
-  constexpr int ROWS_PER_BLOCK = 256 / LPR;
-  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  if (tile >= a.num_tiles) return;
-  const int g = threadIdx.x % LPR;
-  const int64_t row = tile * ROWS_PER_BLOCK + threadIdx.x / LPR;
-  // column block (only > 0 when msg_dim exceeds LPR*VEC*CH; epilogues are then disabled by host)
-  const int cbase = blockIdx.y * (LPR * VEC * CH);
-  if (row >= a.num_nodes) return;  // whole lane-group exits together (no cross-group shuffles)
-
-  const int beg = a.rowptr[row], end = a.rowptr[row + 1];
-  const int32_t tmask = (1 << a.type_bits) - 1;
-  const int M = a.msg_dim;
-  const int EPI = a.epi;  // wave-uniform
-
+// Per-lane-group state and the steps every kernel composes: fold a slot range, fold another partial,
+// finish + store the row.  VEC = 4: float4 path (msg_dim % 4 == 0, 16-B aligned rows); VEC = 1:
+// generic.  MASKED (sum only): the gathered row is an output gradient that only flows where the
+// forward max/min picked this very edge:  value = (mask_arg[src, c] == mask_slot[i]) ? row[c] : 0.
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED>
+struct RowOp {
+  const Args &a;
+  const int g, cbase, M;
+  const int32_t tmask;
   float acc[CH][VEC];
   int arg[CH][VEC];
-  constexpr float kInit = REDUCE == PTGNN_AMD_MAX ? -FLT_MAX : (REDUCE == PTGNN_AMD_MIN ? FLT_MAX : 0.f);
-#pragma unroll
-  for (int c = 0; c < CH; ++c)
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) { acc[c][v] = kInit; arg[c][v] = -1; }
 
-  auto load_row = [&](const float *base, float (&dst)[CH][VEC]) {
+  static constexpr float kInit =
+      REDUCE == PTGNN_AMD_MAX ? -FLT_MAX : (REDUCE == PTGNN_AMD_MIN ? FLT_MAX : 0.f);
+
+  __device__ __forceinline__ RowOp(const Args &a_, int g_, int cbase_)
+      : a(a_), g(g_), cbase(cbase_), M(a_.msg_dim), tmask((1 << a_.type_bits) - 1) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { acc[c][v] = kInit; arg[c][v] = -1; }
+  }
+
+  __device__ __forceinline__ void load_row(const float *base, float (&dst)[CH][VEC]) const {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int colx = cbase + (g + c * LPR) * VEC;
@@ -95,9 +112,9 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
         dst[c][0] = colx < M ? base[colx] : 0.f;
       }
     }
-  };
+  }
 
-  auto apply_mask = [&](float (&m)[CH][VEC], int64_t srow, int i) {
+  __device__ __forceinline__ void apply_mask(float (&m)[CH][VEC], int64_t srow, int i) const {
     if constexpr (MASKED) {
       const int want = a.mask_slot[i];
       const int32_t *ar = a.mask_arg + srow * (int64_t)M;
@@ -115,9 +132,10 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
         }
       }
     }
-  };
+  }
 
-  auto fold = [&](const float (&m)[CH][VEC], int slot) {
+  // fold one candidate (value, slot); on max/min ties the earlier slot stays (torch_scatter's arg)
+  __device__ __forceinline__ void fold(const float (&m)[CH][VEC], int slot) {
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -130,165 +148,338 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
           acc[c][v] += m[c][v];
         }
       }
-  };
+  }
 
-  const float *dst_base = HAS_DST ? a.ydst + row * a.ld_yd : nullptr;
+  // fold a partial whose slots are not ordered w.r.t. ours (interleaved groups): ties -> lower slot
+  __device__ __forceinline__ void fold_partial(const float (&m)[CH][VEC], const int (&ma)[CH][VEC]) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if (REDUCE == PTGNN_AMD_MAX || REDUCE == PTGNN_AMD_MIN) {
+          const bool better = REDUCE == PTGNN_AMD_MAX ? m[c][v] > acc[c][v] : m[c][v] < acc[c][v];
+          bool take = better;
+          if (HAS_ARG)
+            take = better || (m[c][v] == acc[c][v] && ma[c][v] >= 0 && (arg[c][v] < 0 || ma[c][v] < arg[c][v]));
+          if (take) { acc[c][v] = m[c][v]; if (HAS_ARG) arg[c][v] = ma[c][v]; }
+        } else {
+          acc[c][v] += m[c][v];
+        }
+      }
+  }
 
-  constexpr int U = 4;
-  int i = beg;
-  for (; i + U <= end; i += U) {
-    int32_t pk[U];
+  // slots beg, beg+stride, ... < end of destination row `row`
+  __device__ __forceinline__ void reduce(int64_t row, int beg, int end, int stride) {
+    const float *dst_base = HAS_DST ? a.ydst + row * a.ld_yd : nullptr;
+    constexpr int U = 4;
+    int i = beg;
+    for (; i + (U - 1) * stride < end; i += U * stride) {
+      int32_t pk[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) pk[u] = a.col[i + u];
-    float m[U][CH][VEC];
-    float d[U][CH][VEC];
+      for (int u = 0; u < U; ++u) pk[u] = a.col[i + u * stride];
+      float m[U][CH][VEC];
+      float d[U][CH][VEC];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t s = pk[u] >> a.type_bits;
-      const int t = pk[u] & tmask;
-      load_row(a.ysrc + s * a.ld_y + (int64_t)t * M, m[u]);
-      apply_mask(m[u], s, i + u);
-      if (HAS_DST) load_row(dst_base + (int64_t)t * M, d[u]);
+      for (int u = 0; u < U; ++u) {
+        const int64_t s = pk[u] >> a.type_bits;
+        const int t = pk[u] & tmask;
+        load_row(a.ysrc + s * a.ld_y + (int64_t)t * M, m[u]);
+        apply_mask(m[u], s, i + u * stride);
+        if (HAS_DST) load_row(dst_base + (int64_t)t * M, d[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (HAS_DST) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) m[u][c][v] += d[u][c][v];
+        }
+        fold(m[u], i + u * stride);
+      }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (; i < end; i += stride) {
+      const int32_t pk = a.col[i];
+      const int64_t s = pk >> a.type_bits;
+      const int t = pk & tmask;
+      float m[CH][VEC];
+      load_row(a.ysrc + s * a.ld_y + (int64_t)t * M, m);
+      apply_mask(m, s, i);
       if (HAS_DST) {
+        float d[CH][VEC];
+        load_row(dst_base + (int64_t)t * M, d);
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) m[u][c][v] += d[u][c][v];
+          for (int v = 0; v < VEC; ++v) m[c][v] += d[c][v];
       }
-      fold(m[u], i + u);
+      fold(m, i);
     }
   }
-  for (; i < end; ++i) {
-    const int32_t pk = a.col[i];
-    const int64_t s = pk >> a.type_bits;
-    const int t = pk & tmask;
-    float m[CH][VEC];
-    load_row(a.ysrc + s * a.ld_y + (int64_t)t * M, m);
-    apply_mask(m, s, i);
-    if (HAS_DST) {
-      float d[CH][VEC];
-      load_row(dst_base + (int64_t)t * M, d);
+
+  __device__ __forceinline__ void store(float *orow, int32_t *arow) const {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int colx = cbase + (g + c * LPR) * VEC;
+      if (colx >= M) continue;
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(orow + colx) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+        if (HAS_ARG) *reinterpret_cast<int4 *>(arow + colx) = make_int4(arg[c][0], arg[c][1], arg[c][2], arg[c][3]);
+      } else {
+        orow[colx] = acc[c][0];
+        if (HAS_ARG) arow[colx] = arg[c][0];
+      }
+    }
+  }
+
+  // mean / empty-segment rule / row epilogue / store
+  __device__ __forceinline__ void finish_and_store(int64_t row, int deg) {
+    const int EPI = a.epi;  // wave-uniform
+    if (REDUCE == PTGNN_AMD_MEAN) {
+      const float cnt = (float)(deg < 1 ? 1 : deg);
 #pragma unroll
       for (int c = 0; c < CH; ++c)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) m[c][v] += d[c][v];
+        for (int v = 0; v < VEC; ++v) acc[c][v] = acc[c][v] / cnt;
     }
-    fold(m, i);
+    if ((REDUCE == PTGNN_AMD_MAX || REDUCE == PTGNN_AMD_MIN) && deg == 0) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;  // torch_scatter: empty segment -> 0
+    }
+    if (EPI & PTGNN_AMD_EPI_GELU) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[c][v] = gelu_erf(acc[c][v]);
+    }
+    if (EPI & PTGNN_AMD_EPI_LAYERNORM) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s += ((g + c * LPR) * VEC + v < M) ? acc[c][v] : 0.f;
+      const float mean = group_sum<LPR>(s) / (float)M;
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float dlt = acc[c][v] - mean;
+          q += ((g + c * LPR) * VEC + v < M) ? dlt * dlt : 0.f;
+        }
+      const float rstd = 1.0f / sqrtf(group_sum<LPR>(q) / (float)M + a.ln_eps);
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const int colx = (g + c * LPR) * VEC + v;
+          if (colx < M) acc[c][v] = (acc[c][v] - mean) * rstd * a.ln_gamma[colx] + a.ln_beta[colx];
+        }
+    }
+    store(a.out + row * a.ld_out, HAS_ARG ? a.argout + row * (int64_t)M : nullptr);
   }
 
-  const int deg = end - beg;
-  if (REDUCE == PTGNN_AMD_MEAN) {
-    const float cnt = (float)(deg < 1 ? 1 : deg);
+  __device__ __forceinline__ void load_partial(const float *prow, const int32_t *parow,
+                                               float (&m)[CH][VEC], int (&ma)[CH][VEC]) const {
+    load_row(prow, m);
 #pragma unroll
-    for (int c = 0; c < CH; ++c)
+    for (int c = 0; c < CH; ++c) {
+      const int colx = cbase + (g + c * LPR) * VEC;
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[c][v] = acc[c][v] / cnt;
+      for (int v = 0; v < VEC; ++v) ma[c][v] = (HAS_ARG && colx + v < M) ? parow[colx + v] : -1;
+    }
   }
-  if ((REDUCE == PTGNN_AMD_MAX || REDUCE == PTGNN_AMD_MIN) && deg == 0) {
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;  // torch_scatter: empty segment -> 0
-  }
+};
 
-  if (EPI & PTGNN_AMD_EPI_GELU) {
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[c][v] = gelu_erf(acc[c][v]);
-  }
-  if (EPI & PTGNN_AMD_EPI_LAYERNORM) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) s += ((g + c * LPR) * VEC + v < M) ? acc[c][v] : 0.f;
-    const float mean = group_sum<LPR>(s) / (float)M;
-    float q = 0.f;
+// ------------------------------------------------------------------------------------------------
+// main kernel: one row per lane group
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED>
+__global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
+  constexpr int ROWS_PER_BLOCK = 256 / LPR;
+  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile >= a.num_tiles) return;
+  const int64_t row = tile * ROWS_PER_BLOCK + threadIdx.x / LPR;
+  if (row >= a.num_nodes) return;  // whole lane-group exits together (no cross-group shuffles)
+  const int beg = a.rowptr[row], end = a.rowptr[row + 1];
+  if (a.hub_threshold > 0 && end - beg > a.hub_threshold) return;  // hub: the chunk kernel owns it
+  // column block (only > 0 when msg_dim exceeds LPR*VEC*CH; epilogues are then disabled by host)
+  RowOp<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED> op(a, threadIdx.x % LPR,
+                                                         blockIdx.y * (LPR * VEC * CH));
+  op.reduce(row, beg, end, 1);
+  op.finish_and_store(row, end - beg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// hub kernel: workgroups walk the plan's (chunk, hub row) list
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED>
+__global__ __launch_bounds__(256) void k_hub_chunks(Args a) {
+  using Op = RowOp<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED>;
+  constexpr int G = 256 / LPR;          // lane groups per workgroup
+  constexpr int W = LPR * VEC * CH;     // columns per column block
+  __shared__ float pv[G * W];
+  __shared__ int pa[HAS_ARG ? G * W : 1];
+
+  const int count = *a.hub_count;
+  const int grp = threadIdx.x / LPR, g = threadIdx.x % LPR;
+  const int cbase = blockIdx.y * W;
+  const int64_t num_chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;
+#pragma unroll 1
+  for (int e = blockIdx.x; e < count; e += gridDim.x) {
+    const int64_t chunk = a.hub_entries[2 * e];
+    const int64_t row = a.hub_entries[2 * e + 1];
+    const int64_t cbeg = chunk * kHubChunk;
+    const int64_t cend = (cbeg + kHubChunk < a.num_edges) ? cbeg + kHubChunk : a.num_edges;
+    const int rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
+    const int sbeg = (int)(rbeg > cbeg ? rbeg : cbeg), send = (int)(rend < cend ? rend : cend);
+    // partial slot of this (chunk, row): 0 if the hub owns the chunk's first slot, else 1
+    const int which = rbeg <= cbeg ? 0 : 1;
+    Op op(a, g, cbase);
+    op.reduce(row, sbeg + grp, send, G);
+    __syncthreads();  // the previous entry's readers are done with the staging arrays
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const float dlt = acc[c][v] - mean;
-        q += ((g + c * LPR) * VEC + v < M) ? dlt * dlt : 0.f;
+        pv[grp * W + (g + c * LPR) * VEC + v] = op.acc[c][v];
+        if (HAS_ARG) pa[grp * W + (g + c * LPR) * VEC + v] = op.arg[c][v];
       }
-    const float rstd = 1.0f / sqrtf(group_sum<LPR>(q) / (float)M + a.ln_eps);
+    __syncthreads();
+    if (grp != 0) continue;           // group 0 (part of wave 0) finishes the entry
+    for (int q = 1; q < G; ++q) {     // fixed combine order => deterministic
+      float m[CH][VEC];
+      int ma[CH][VEC];
 #pragma unroll
-    for (int c = 0; c < CH; ++c)
+      for (int c = 0; c < CH; ++c)
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        const int colx = (g + c * LPR) * VEC + v;
-        if (colx < M) acc[c][v] = (acc[c][v] - mean) * rstd * a.ln_gamma[colx] + a.ln_beta[colx];
-      }
-  }
-
-  float *orow = a.out + row * a.ld_out;
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int colx = cbase + (g + c * LPR) * VEC;
-    if (colx >= M) continue;
-    if constexpr (VEC == 4) {
-      *reinterpret_cast<float4 *>(orow + colx) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
-      if (HAS_ARG)
-        *reinterpret_cast<int4 *>(a.argout + row * (int64_t)M + colx) =
-            make_int4(arg[c][0], arg[c][1], arg[c][2], arg[c][3]);
-    } else {
-      orow[colx] = acc[c][0];
-      if (HAS_ARG) a.argout[row * (int64_t)M + colx] = arg[c][0];
+        for (int v = 0; v < VEC; ++v) {
+          m[c][v] = pv[q * W + (g + c * LPR) * VEC + v];
+          ma[c][v] = HAS_ARG ? pa[q * W + (g + c * LPR) * VEC + v] : -1;
+        }
+      op.fold_partial(m, ma);
     }
+    const int64_t c_first = rbeg / kHubChunk, c_last = (rend - 1) / kHubChunk;
+    op.store(a.hub_part + (2 * chunk + which) * (int64_t)a.msg_dim,
+             HAS_ARG ? a.hub_arg + (2 * chunk + which) * (int64_t)a.msg_dim : nullptr);
+    // publish: every storing lane releases at agent scope, then ONE lane takes a ticket
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int32_t *ticket = a.hub_tickets + (int64_t)blockIdx.y * num_chunks + c_first;
+    int arrived = 0;
+    if (g == 0) arrived = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrived = __shfl(arrived, 0, LPR);
+    if (arrived != (int)(c_last - c_first)) continue;   // not the last chunk of this hub
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1 lines before reading partials
+    if (g == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-clean
+    Op fin(a, g, cbase);
+    for (int64_t c = c_first; c <= c_last; ++c) {
+      const int w2 = (c > c_first || rbeg == (int)(c_first * kHubChunk)) ? 0 : 1;
+      float m[CH][VEC];
+      int ma[CH][VEC];
+      fin.load_partial(a.hub_part + (2 * c + w2) * (int64_t)a.msg_dim,
+                       HAS_ARG ? a.hub_arg + (2 * c + w2) * (int64_t)a.msg_dim : nullptr, m, ma);
+      fin.fold_partial(m, ma);
+    }
+    fin.finish_and_store(row, rend - rbeg);
   }
 }
 
-template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST>
-int launch2(const Args &a, int epi, int col_blocks, hipStream_t stream) {
+// ------------------------------------------------------------------------------------------------
+// launch plumbing
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED>
+int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
   constexpr int ROWS_PER_BLOCK = 256 / LPR;
-  Args b = a;
-  b.epi = epi;
-  b.num_tiles = (a.num_nodes + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  dim3 grid((unsigned)xcd_padded_blocks(b.num_tiles), (unsigned)col_blocks);
-  if constexpr (REDUCE == PTGNN_AMD_MAX || REDUCE == PTGNN_AMD_MIN) {
-    if (a.argout) {
-      k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, true><<<grid, 256, 0, stream>>>(b);
-      PTGNN_LAUNCH_CHECK();
-      return PTGNN_AMD_OK;
-    }
-  }
-  k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, false><<<grid, 256, 0, stream>>>(b);
+  Args a = a0;
+  a.num_tiles = (a.num_nodes + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  dim3 grid((unsigned)xcd_padded_blocks(a.num_tiles), (unsigned)col_blocks);
+  k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED><<<grid, 256, 0, stream>>>(a);
   PTGNN_LAUNCH_CHECK();
+  if (a.hub_threshold > 0) {
+    // the list length lives on the device: a fixed grid strides over it (zero entries => instant exit)
+    int64_t chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;
+    dim3 hgrid((unsigned)(chunks < 1024 ? chunks : 1024), (unsigned)col_blocks);
+    k_hub_chunks<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED><<<hgrid, 256, 0, stream>>>(a);
+    PTGNN_LAUNCH_CHECK();
+  }
   return PTGNN_AMD_OK;
 }
 
-template <int VEC, int LPR, int CH>
-int launch1(const Args &a, int reduce, int epi, int col_blocks, hipStream_t s) {
-  const bool d = a.ydst != nullptr;
-  switch (reduce) {
-    case PTGNN_AMD_SUM:
-      return d ? launch2<VEC, LPR, CH, PTGNN_AMD_SUM, true>(a, epi, col_blocks, s)
-               : launch2<VEC, LPR, CH, PTGNN_AMD_SUM, false>(a, epi, col_blocks, s);
-    case PTGNN_AMD_MEAN:
-      return d ? launch2<VEC, LPR, CH, PTGNN_AMD_MEAN, true>(a, epi, col_blocks, s)
-               : launch2<VEC, LPR, CH, PTGNN_AMD_MEAN, false>(a, epi, col_blocks, s);
-    case PTGNN_AMD_MAX:
-      return d ? launch2<VEC, LPR, CH, PTGNN_AMD_MAX, true>(a, epi, col_blocks, s)
-               : launch2<VEC, LPR, CH, PTGNN_AMD_MAX, false>(a, epi, col_blocks, s);
-    default:
-      return d ? launch2<VEC, LPR, CH, PTGNN_AMD_MIN, true>(a, epi, col_blocks, s)
-               : launch2<VEC, LPR, CH, PTGNN_AMD_MIN, false>(a, epi, col_blocks, s);
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST>
+int launch2(const Args &a, int col_blocks, hipStream_t stream) {
+  if constexpr (REDUCE == PTGNN_AMD_MAX || REDUCE == PTGNN_AMD_MIN) {
+    if (a.argout) return launch_all<VEC, LPR, CH, REDUCE, HAS_DST, true, false>(a, col_blocks, stream);
   }
+  return launch_all<VEC, LPR, CH, REDUCE, HAS_DST, false, false>(a, col_blocks, stream);
 }
 
 template <int VEC, int LPR, int CH>
-int launch_masked(const Args &a, int col_blocks, hipStream_t stream) {
-  constexpr int ROWS_PER_BLOCK = 256 / LPR;
-  Args b = a;
-  b.epi = 0;
-  b.num_tiles = (a.num_nodes + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  dim3 grid((unsigned)xcd_padded_blocks(b.num_tiles), (unsigned)col_blocks);
-  k_gather_reduce<VEC, LPR, CH, PTGNN_AMD_SUM, false, false, true><<<grid, 256, 0, stream>>>(b);
-  PTGNN_LAUNCH_CHECK();
+int launch1(const Args &a, int reduce, int col_blocks, hipStream_t s) {
+  const bool d = a.ydst != nullptr;
+  switch (reduce) {
+    case PTGNN_AMD_SUM:
+      return d ? launch2<VEC, LPR, CH, PTGNN_AMD_SUM, true>(a, col_blocks, s)
+               : launch2<VEC, LPR, CH, PTGNN_AMD_SUM, false>(a, col_blocks, s);
+    case PTGNN_AMD_MEAN:
+      return d ? launch2<VEC, LPR, CH, PTGNN_AMD_MEAN, true>(a, col_blocks, s)
+               : launch2<VEC, LPR, CH, PTGNN_AMD_MEAN, false>(a, col_blocks, s);
+    case PTGNN_AMD_MAX:
+      return d ? launch2<VEC, LPR, CH, PTGNN_AMD_MAX, true>(a, col_blocks, s)
+               : launch2<VEC, LPR, CH, PTGNN_AMD_MAX, false>(a, col_blocks, s);
+    default:
+      return d ? launch2<VEC, LPR, CH, PTGNN_AMD_MIN, true>(a, col_blocks, s)
+               : launch2<VEC, LPR, CH, PTGNN_AMD_MIN, false>(a, col_blocks, s);
+  }
+}
+
+template <int N>
+using IC = std::integral_constant<int, N>;
+
+// picks the lane-group geometry for msg_dim; f(IC<VEC>, IC<LPR>, IC<CH>, col_blocks)
+template <typename F>
+int dispatch_geometry(bool vec4, int msg_dim, bool row_epi, F f) {
+  if (vec4) {
+    if (msg_dim <= 64) return f(IC<4>{}, IC<16>{}, IC<1>{}, 1);
+    if (msg_dim <= 128) return f(IC<4>{}, IC<32>{}, IC<1>{}, 1);
+    if (msg_dim <= 256) return f(IC<4>{}, IC<64>{}, IC<1>{}, 1);
+    if (msg_dim <= 512) return f(IC<4>{}, IC<64>{}, IC<2>{}, 1);
+    PTGNN_REQUIRE(!row_epi, PTGNN_AMD_EUNSUPPORTED,
+                  "gather_reduce: LayerNorm epilogue supports msg_dim <= 512 (got %d)", msg_dim);
+    return f(IC<4>{}, IC<64>{}, IC<2>{}, (msg_dim + 511) / 512);
+  }
+  if (msg_dim <= 64) return f(IC<1>{}, IC<64>{}, IC<1>{}, 1);
+  if (msg_dim <= 256) return f(IC<1>{}, IC<64>{}, IC<4>{}, 1);
+  PTGNN_REQUIRE(!row_epi, PTGNN_AMD_EUNSUPPORTED,
+                "gather_reduce: unaligned LayerNorm epilogue supports msg_dim <= 256 (got %d)", msg_dim);
+  return f(IC<1>{}, IC<64>{}, IC<4>{}, (msg_dim + 255) / 256);
+}
+
+int setup_hub(Args &a, int64_t num_edges, int32_t hub_threshold, const int32_t *hub_entries,
+              const int32_t *hub_count, void *hub_ws, size_t hub_ws_bytes, int32_t *hub_tickets,
+              bool with_arg) {
+  a.num_edges = num_edges;
+  a.hub_threshold = 0;
+  a.hub_part = nullptr;
+  a.hub_arg = nullptr;
+  a.hub_tickets = hub_tickets;
+  a.hub_entries = hub_entries;
+  a.hub_count = hub_count;
+  if (hub_ws == nullptr || hub_tickets == nullptr || hub_entries == nullptr || hub_count == nullptr ||
+      hub_threshold <= 0 || num_edges <= hub_threshold)
+    return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(hub_threshold >= 2 * kHubChunk, PTGNN_AMD_EINVAL,
+                "gather_reduce: hub_threshold must be 0 or >= %d", 2 * kHubChunk);
+  const size_t need = ptgnn_amd_hub_workspace_bytes(num_edges, a.msg_dim, with_arg);
+  PTGNN_REQUIRE(hub_ws_bytes >= need, PTGNN_AMD_EWORKSPACE, "gather_reduce: hub workspace %zu < %zu",
+                hub_ws_bytes, need);
+  const size_t chunks = (size_t)((num_edges + kHubChunk - 1) / kHubChunk);
+  char *p = (char *)(((uintptr_t)hub_ws + 255) & ~(uintptr_t)255);
+  a.hub_part = (float *)p;
+  a.hub_arg = with_arg ? (int32_t *)(p + 2 * chunks * (size_t)a.msg_dim * 4) : nullptr;
+  a.hub_threshold = hub_threshold;
   return PTGNN_AMD_OK;
 }
 
@@ -297,28 +488,17 @@ int launch_masked(const Args &a, int col_blocks, hipStream_t stream) {
 
 using namespace ptgnn_amd;
 
-extern "C" int ptgnn_amd_gather_reduce_masked_f32(const float *grad, int64_t ld_grad,
-                                                  const int32_t *arg, const int32_t *rowptr,
-                                                  const int32_t *col, const int32_t *slot_of,
-                                                  int64_t num_rows, int32_t msg_dim, float *out,
-                                                  int64_t ld_out, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  PTGNN_REQUIRE(num_rows >= 0 && msg_dim > 0, PTGNN_AMD_EINVAL, "gather_reduce_masked: bad sizes");
-  if (num_rows == 0) return PTGNN_AMD_OK;
-  PTGNN_REQUIRE(grad && arg && rowptr && col && slot_of && out && ld_out >= msg_dim && ld_grad >= msg_dim,
-                PTGNN_AMD_EINVAL, "gather_reduce_masked: null/ld");
-  Args a{grad, nullptr, ld_grad, ld_grad, rowptr, col, 0, num_rows, msg_dim, nullptr, nullptr, 0.f,
-         out, ld_out, nullptr, 0, 0, arg, slot_of};
-  const bool vec4 = (msg_dim % 4 == 0) && (ld_grad % 4 == 0) && (ld_out % 4 == 0) && aligned16(grad) &&
-                    aligned16(out) && aligned16(arg);
-  if (vec4) {
-    if (msg_dim <= 64) return launch_masked<4, 16, 1>(a, 1, stream);
-    if (msg_dim <= 128) return launch_masked<4, 32, 1>(a, 1, stream);
-    if (msg_dim <= 256) return launch_masked<4, 64, 1>(a, 1, stream);
-    return launch_masked<4, 64, 2>(a, (msg_dim + 511) / 512, stream);
-  }
-  if (msg_dim <= 64) return launch_masked<1, 64, 1>(a, 1, stream);
-  return launch_masked<1, 64, 4>(a, (msg_dim + 255) / 256, stream);
+extern "C" int64_t ptgnn_amd_hub_ticket_count(int64_t num_edges, int32_t msg_dim) {
+  if (num_edges <= 0 || msg_dim <= 0) return 0;
+  // one counter per (chunk, column block); column blocks only exist beyond 512 columns
+  const int64_t col_blocks = msg_dim <= 512 ? 1 : (msg_dim + 255) / 256;
+  return (num_edges + kHubChunk - 1) / kHubChunk * col_blocks;
+}
+
+extern "C" size_t ptgnn_amd_hub_workspace_bytes(int64_t num_edges, int32_t msg_dim, int with_arg) {
+  if (num_edges <= 0 || msg_dim <= 0) return 0;
+  const size_t chunks = (size_t)((num_edges + kHubChunk - 1) / kHubChunk);
+  return 2 * chunks * (size_t)msg_dim * 4 * (with_arg ? 2 : 1) + 256;
 }
 
 extern "C" int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_y, const float *ydst,
@@ -326,9 +506,12 @@ extern "C" int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_y, cons
                                            int32_t type_bits, int64_t num_nodes, int32_t msg_dim,
                                            int reduce, int epilogue, const float *ln_gamma,
                                            const float *ln_beta, float ln_eps, float *out,
-                                           int64_t ld_out, int32_t *argout, void *stream_) {
+                                           int64_t ld_out, int32_t *argout, int64_t num_edges,
+                                           int32_t hub_threshold, const int32_t *hub_entries,
+                                           const int32_t *hub_count, void *hub_ws,
+                                           size_t hub_ws_bytes, int32_t *hub_tickets, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  PTGNN_REQUIRE(num_nodes >= 0 && msg_dim > 0, PTGNN_AMD_EINVAL, "gather_reduce: bad sizes");
+  PTGNN_REQUIRE(num_nodes >= 0 && msg_dim > 0 && num_edges >= 0, PTGNN_AMD_EINVAL, "gather_reduce: bad sizes");
   PTGNN_REQUIRE(reduce >= PTGNN_AMD_SUM && reduce <= PTGNN_AMD_MIN, PTGNN_AMD_EINVAL,
                 "gather_reduce: unknown reduce %d", reduce);
   PTGNN_REQUIRE(epilogue >= 0 && epilogue <= 3, PTGNN_AMD_EINVAL, "gather_reduce: bad epilogue");
@@ -341,25 +524,51 @@ extern "C" int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_y, cons
   PTGNN_REQUIRE(argout == nullptr || reduce >= PTGNN_AMD_MAX, PTGNN_AMD_EINVAL,
                 "gather_reduce: argout only with max/min");
 
-  Args a{ysrc, ydst, ld_y, ydst ? ld_yd : ld_y, rowptr, col, type_bits, num_nodes, msg_dim, ln_gamma, ln_beta, ln_eps,
-         out, ld_out, argout, 0, 0, nullptr, nullptr};
-  const bool vec4 = (msg_dim % 4 == 0) && (ld_y % 4 == 0) && (!ydst || ld_yd % 4 == 0) && (ld_out % 4 == 0) && aligned16(ysrc) &&
-                    aligned16(out) && (!ydst || aligned16(ydst)) && (!argout || aligned16(argout));
+  Args a{};
+  a.ysrc = ysrc; a.ydst = ydst; a.ld_y = ld_y; a.ld_yd = ydst ? ld_yd : ld_y;
+  a.rowptr = rowptr; a.col = col; a.type_bits = type_bits; a.num_nodes = num_nodes; a.msg_dim = msg_dim;
+  a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.out = out; a.ld_out = ld_out;
+  a.argout = argout; a.epi = epilogue;
+  const int rc = setup_hub(a, num_edges, hub_threshold, hub_entries, hub_count, hub_ws, hub_ws_bytes,
+                           hub_tickets, argout != nullptr);
+  if (rc != PTGNN_AMD_OK) return rc;
+  const bool vec4 = (msg_dim % 4 == 0) && (ld_y % 4 == 0) && (!ydst || ld_yd % 4 == 0) && (ld_out % 4 == 0) &&
+                    aligned16(ysrc) && aligned16(out) && (!ydst || aligned16(ydst)) &&
+                    (!argout || aligned16(argout));
   const bool row_epi = (epilogue & PTGNN_AMD_EPI_LAYERNORM) != 0;
-  if (vec4) {
-    if (msg_dim <= 64) return launch1<4, 16, 1>(a, reduce, epilogue, 1, stream);
-    if (msg_dim <= 128) return launch1<4, 32, 1>(a, reduce, epilogue, 1, stream);
-    if (msg_dim <= 256) return launch1<4, 64, 1>(a, reduce, epilogue, 1, stream);
-    if (msg_dim <= 512) return launch1<4, 64, 2>(a, reduce, epilogue, 1, stream);
-    PTGNN_REQUIRE(!row_epi, PTGNN_AMD_EUNSUPPORTED,
-                  "gather_reduce: LayerNorm epilogue supports msg_dim <= 512 (got %d)", msg_dim);
-    return launch1<4, 64, 2>(a, reduce, epilogue, (msg_dim + 511) / 512, stream);
-  }
-  if (msg_dim <= 64) return launch1<1, 64, 1>(a, reduce, epilogue, 1, stream);
-  if (msg_dim <= 256) return launch1<1, 64, 4>(a, reduce, epilogue, 1, stream);
-  PTGNN_REQUIRE(!row_epi, PTGNN_AMD_EUNSUPPORTED,
-                "gather_reduce: unaligned LayerNorm epilogue supports msg_dim <= 256 (got %d)", msg_dim);
-  return launch1<1, 64, 4>(a, reduce, epilogue, (msg_dim + 255) / 256, stream);
+  return dispatch_geometry(vec4, msg_dim, row_epi, [&](auto V, auto L, auto C, int col_blocks) {
+    return launch1<decltype(V)::value, decltype(L)::value, decltype(C)::value>(a, reduce, col_blocks, stream);
+  });
+}
+
+extern "C" int ptgnn_amd_gather_reduce_masked_f32(const float *grad, int64_t ld_grad,
+                                                  const int32_t *arg, const int32_t *rowptr,
+                                                  const int32_t *col, const int32_t *slot_of,
+                                                  int64_t num_rows, int32_t msg_dim, float *out,
+                                                  int64_t ld_out, int64_t num_edges,
+                                                  int32_t hub_threshold, const int32_t *hub_entries,
+                                                  const int32_t *hub_count, void *hub_ws,
+                                                  size_t hub_ws_bytes, int32_t *hub_tickets,
+                                                  void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTGNN_REQUIRE(num_rows >= 0 && msg_dim > 0 && num_edges >= 0, PTGNN_AMD_EINVAL,
+                "gather_reduce_masked: bad sizes");
+  if (num_rows == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(grad && arg && rowptr && col && slot_of && out && ld_out >= msg_dim && ld_grad >= msg_dim,
+                PTGNN_AMD_EINVAL, "gather_reduce_masked: null/ld");
+  Args a{};
+  a.ysrc = grad; a.ld_y = ld_grad; a.ld_yd = ld_grad; a.rowptr = rowptr; a.col = col;
+  a.num_nodes = num_rows; a.msg_dim = msg_dim; a.out = out; a.ld_out = ld_out;
+  a.mask_arg = arg; a.mask_slot = slot_of;
+  const int rc = setup_hub(a, num_edges, hub_threshold, hub_entries, hub_count, hub_ws, hub_ws_bytes,
+                           hub_tickets, false);
+  if (rc != PTGNN_AMD_OK) return rc;
+  const bool vec4 = (msg_dim % 4 == 0) && (ld_grad % 4 == 0) && (ld_out % 4 == 0) && aligned16(grad) &&
+                    aligned16(out) && aligned16(arg);
+  return dispatch_geometry(vec4, msg_dim, false, [&](auto V, auto L, auto C, int col_blocks) {
+    return launch_all<decltype(V)::value, decltype(L)::value, decltype(C)::value, PTGNN_AMD_SUM, false, false,
+                      true>(a, col_blocks, stream);
+  });
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -103,7 +103,8 @@ class GraphPlan:
     """
 
     __slots__ = ("rowptr", "col", "perm", "type_bits", "num_nodes", "num_edges", "num_types",
-                 "num_src_rows", "_backward", "_adj", "_adj_refs", "_inv_perm", "__weakref__")
+                 "num_src_rows", "_backward", "_adj", "_adj_refs", "_inv_perm", "_ready", "_waited",
+                 "_hub_tickets", "hub_entries", "hub_count", "__weakref__")
 
     def __init__(self, rowptr, col, perm, type_bits, num_nodes, num_edges, num_types):
         self.rowptr, self.col, self.perm = rowptr, col, perm
@@ -114,6 +115,33 @@ class GraphPlan:
         self._adj = None       # the adjacency tensors the plan was built from (for the backward plan)
         self._adj_refs = None
         self._inv_perm = None
+        self._ready = None     # event recorded on the plan stream after the build (None = same stream)
+        self._waited = set()
+        self._hub_tickets = {}
+        self.hub_entries = self.hub_count = None   # (chunk, row) pairs of rows > HUB_THRESHOLD
+
+    def may_have_hubs(self) -> bool:
+        """Only plans with more edges than the threshold can contain a hub row (whether they do is
+        known on the device: `hub_count`)."""
+        return self.hub_entries is not None
+
+    def hub_tickets(self, msg_dim: int) -> torch.Tensor:
+        """Arrival counters of the hub chunks: zeroed once per plan, left zero by every launch."""
+        n = _lib.load().ptgnn_amd_hub_ticket_count(self.num_edges, msg_dim)
+        t = self._hub_tickets.get(n)
+        if t is None:
+            t = torch.zeros(max(n, 1), dtype=torch.int32, device=self.rowptr.device)
+            self._hub_tickets[n] = t
+        return t
+
+    def wait(self) -> None:
+        """Make the current stream wait for a plan that was built on the side stream (once per stream).
+        Consumers call this right before their first launch that reads rowptr/col/perm."""
+        if self._ready is not None:
+            cur = torch.cuda.current_stream(self.rowptr.device)
+            if cur.cuda_stream not in self._waited:
+                cur.wait_event(self._ready)
+                self._waited.add(cur.cuda_stream)
 
     def backward_plan(self) -> "GraphPlan":
         """Plan of the transposed problem, rows = src * T + type, col = dst: row r of the [N*T, M] view
@@ -122,6 +150,7 @@ class GraphPlan:
         if self._backward is None:
             if self._adj is None:
                 raise _lib.PtgnnAmdError("this plan was built without keeping its adjacency lists")
+            self.wait()
             self._backward = build_plan(self._adj, self.num_src_rows * self.num_types, mode=2)
         return self._backward
 
@@ -136,6 +165,7 @@ class GraphPlan:
     def inverse_perm(self) -> torch.Tensor:
         """original edge position -> CSR slot (int64)."""
         if self._inv_perm is None:
+            self.wait()
             inv = torch.empty(max(self.num_edges, 1), dtype=torch.int64, device=self.perm.device)
             inv[self.perm[: self.num_edges].to(torch.int64)] = torch.arange(
                 self.num_edges, device=self.perm.device)
@@ -177,6 +207,10 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
     perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if want_perm else None
     ws_bytes = lib.ptgnn_amd_csr_workspace_bytes(E, num_nodes)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    hub_entries = hub_count = None
+    if HUB_THRESHOLD > 0 and E > HUB_THRESHOLD:
+        hub_entries = torch.empty(2 * ((E + 1023) // 1024), 2, dtype=torch.int32, device=dev)
+        hub_count = torch.empty(1, dtype=torch.int32, device=dev)
     PtrArr, CntArr = ctypes.c_void_p * T, ctypes.c_int64 * T
     src_ptrs = PtrArr(*[s.data_ptr() if s.numel() else None for s in srcs])
     dst_ptrs = PtrArr(*[d.data_ptr() if d.numel() else None for d in dsts])
@@ -188,13 +222,17 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
                                      ctypes.cast(cnts, ctypes.c_void_p), T, num_nodes,
                                      int(num_src_rows or 0),
                                      mode, rowptr.data_ptr(), col.data_ptr(),
-                                     perm.data_ptr() if perm is not None else None, ws.data_ptr(),
-                                     ws_bytes, _stream(rowptr))
+                                     perm.data_ptr() if perm is not None else None, None,
+                                     HUB_THRESHOLD if hub_entries is not None else 0,
+                                     hub_entries.data_ptr() if hub_entries is not None else None,
+                                     hub_count.data_ptr() if hub_count is not None else None,
+                                     ws.data_ptr(), ws_bytes, _stream(rowptr))
     _lib.check(rc, "ptgnn_amd_csr_build")
     # `ws`, `srcs`, `dsts` are stream-ordered: torch's caching allocator only hands their memory to
     # later work on the same stream, so dropping the references here is safe.
     # col/perm keep >= 1 element so their base pointer is never null (E == 0 batches are legal)
     plan = GraphPlan(rowptr, col, perm, 0 if mode == 2 else type_bits, num_nodes, E, T)
+    plan.hub_entries, plan.hub_count = hub_entries, hub_count
     if mode == 0:
         plan.num_src_rows = int(num_src_rows or num_nodes)
         plan._adj = list(zip(srcs, dsts))
@@ -203,6 +241,42 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
 
 _PLAN_CACHE: List[GraphPlan] = []
 _PLAN_CACHE_SIZE = 4
+
+# Rows longer than this are reduced chunk-parallel by the hub kernels (see gather_reduce.hip).
+HUB_THRESHOLD = 4096
+
+# The plan (sort) is latency-bound integer work and the first dense block of a layer (pre-transform /
+# per-edge GEMM) does not read it, so the build runs on a side HIP stream under that GEMM; the
+# aggregation kernel waits on the plan's event.
+OVERLAP_PLAN_BUILD = False   # measured r01: no gain -- the GEMM already fills every CU, both just slow down
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[key] = st
+    return st
+
+
+def _build_plan_overlapped(adjacency_lists, num_nodes: int) -> GraphPlan:
+    dev = adjacency_lists[0][0].device
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)                      # the adjacency tensors' producers ran on `main`
+    with torch.cuda.stream(side):
+        plan = build_plan(adjacency_lists, num_nodes)
+        plan._ready = torch.cuda.Event()
+        plan._ready.record(side)
+    for s, d in adjacency_lists:                # read by side-stream kernels: defer allocator reuse
+        s.record_stream(side)
+        d.record_stream(side)
+    for t in (plan.rowptr, plan.col, plan.perm, plan.hub_entries, plan.hub_count):  # alloc on `side`, used on `main`
+        if t is not None:
+            t.record_stream(main)
+    return plan
 
 
 def plan_for(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num_nodes: int) -> GraphPlan:
@@ -220,7 +294,8 @@ def plan_for(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num_n
                 break
         if ok:
             return plan
-    plan = build_plan(adjacency_lists, num_nodes)
+    plan = _build_plan_overlapped(adjacency_lists, num_nodes) if OVERLAP_PLAN_BUILD else \
+        build_plan(adjacency_lists, num_nodes)
     plan._adj_refs = [(weakref.ref(s), s._version, weakref.ref(d), d._version)
                       for s, d in adjacency_lists]
     _PLAN_CACHE.insert(0, plan)
@@ -235,6 +310,14 @@ def clear_plan_cache():
 # ------------------------------------------------------------------------------------------------
 # kernels
 # ------------------------------------------------------------------------------------------------
+def _hub_workspace(plan: GraphPlan, msg_dim: int, with_arg: bool, device):
+    """Chunk-partial buffer for the hub kernels, or (None, 0) when the plan is known hub-free."""
+    if not plan.may_have_hubs():
+        return None, 0
+    nbytes = _lib.load().ptgnn_amd_hub_workspace_bytes(plan.num_edges, msg_dim, 1 if with_arg else 0)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
 def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str,
                   ydst: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
                   ln_weight: Optional[torch.Tensor] = None, ln_bias: Optional[torch.Tensor] = None,
@@ -259,6 +342,7 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
         arg = torch.empty(N, msg_dim, dtype=torch.int32, device=ysrc.device)
     if epilogue & EPI_LAYERNORM:
         ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+    plan.wait()
     tb = plan.type_bits if type_bits is None else type_bits
     colt = plan.col if col is None else col
     # algorithmic bytes (SURVEY.md 8d "(L)"): per edge one message row + its col entry; per node the
@@ -266,6 +350,7 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
     nbytes = (plan.num_edges * (4.0 * msg_dim + 4) + N * (4.0 * msg_dim + 4)
               + (N * 4.0 * msg_dim if ydst is not None else 0.0)
               + (N * 4.0 * msg_dim if arg is not None else 0.0))
+    hub_ws, hub_bytes = _hub_workspace(plan, msg_dim, arg is not None, ysrc.device)
     with _timed("gather_reduce", bytes=nbytes):
         rc = lib.ptgnn_amd_gather_reduce_f32(
             ysrc.data_ptr(), ld_y, ydst.data_ptr() if ydst is not None else None, ld_yd,
@@ -273,7 +358,12 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
             REDUCE_IDS[reduce], epilogue,
             ln_weight.data_ptr() if ln_weight is not None else None,
             ln_bias.data_ptr() if ln_bias is not None else None, float(ln_eps),
-            out.data_ptr(), msg_dim, arg.data_ptr() if arg is not None else None, _stream(out))
+            out.data_ptr(), msg_dim, arg.data_ptr() if arg is not None else None,
+            plan.num_edges, HUB_THRESHOLD if hub_ws is not None else 0,
+            plan.hub_entries.data_ptr() if hub_ws is not None else None,
+            plan.hub_count.data_ptr() if hub_ws is not None else None,
+            hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes,
+            plan.hub_tickets(msg_dim).data_ptr() if hub_ws is not None else None, _stream(out))
     _lib.check(rc, "ptgnn_amd_gather_reduce_f32")
     return (out, arg) if return_arg else out
 
@@ -284,12 +374,21 @@ def gather_reduce_masked(grad: torch.Tensor, arg: torch.Tensor, bplan: GraphPlan
     lib = _lib.load()
     _require_cuda_f32("grad", grad)
     grad = _rowmajor(grad)
+    bplan.wait()
     out = torch.empty(bplan.num_nodes, msg_dim, dtype=torch.float32, device=grad.device)
+    hub_ws, hub_bytes = _hub_workspace(bplan, msg_dim, False, grad.device)
     with _timed("gather_reduce_masked", bytes=bplan.num_edges * (8.0 * msg_dim + 8) + bplan.num_nodes * (4.0 * msg_dim + 4)):
         rc = lib.ptgnn_amd_gather_reduce_masked_f32(grad.data_ptr(), _ld(grad), arg.data_ptr(),
                                                     bplan.rowptr.data_ptr(), bplan.col.data_ptr(),
                                                     slot_of.data_ptr(), bplan.num_nodes, msg_dim,
-                                                    out.data_ptr(), msg_dim, _stream(out))
+                                                    out.data_ptr(), msg_dim, bplan.num_edges,
+                                                    HUB_THRESHOLD if hub_ws is not None else 0,
+                                                    bplan.hub_entries.data_ptr() if hub_ws is not None else None,
+                                                    bplan.hub_count.data_ptr() if hub_ws is not None else None,
+                                                    hub_ws.data_ptr() if hub_ws is not None else None,
+                                                    hub_bytes,
+                                                    bplan.hub_tickets(msg_dim).data_ptr() if hub_ws is not None else None,
+                                                    _stream(out))
     _lib.check(rc, "ptgnn_amd_gather_reduce_masked_f32")
     return out
 

@@ -34,6 +34,7 @@ class _SegmentReduce(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         plan, reduce, E = ctx.plan, ctx.reduce, ctx.num_edges
+        plan.wait()
         grad_out = grad_out.contiguous()
         D = grad_out.shape[1]
         if E == 0:
@@ -119,6 +120,7 @@ class _GatherReduce(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         plan, reduce, M = ctx.plan, ctx.reduce, ctx.msg_dim
+        plan.wait()
         T, N, E = plan.num_types, plan.num_nodes, plan.num_edges
         g = grad_out.contiguous()
         dev = g.device

@@ -40,3 +40,30 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "linear"
     if what == "linear":
         linear_shapes()
+
+
+def powerlaw():
+    """BASELINE config 5 at its per-GPU size (8-way dst-range shard of N=10M / E=100M, H=256):
+    1.25M rows, 12.5M in-edges with power-law destinations."""
+    from ptgnn_amd import workloads
+    N, E, M = 1_250_000, 12_500_000, 256
+    for alpha in (0.8, 1.1):
+        adj = workloads.power_law_graph(N, E, alpha=alpha, seed=1)
+        deg = torch.bincount(adj[0][1], minlength=N)
+        cadj = [(adj[0][0].cuda(), adj[0][1].cuda())]
+        y = torch.randn(N, M, device="cuda")
+        for thr in (4096, 0):
+            ops.HUB_THRESHOLD = thr
+            plan = ops.build_plan(cadj, N)
+            for red in ("sum", "max"):
+                ms = timeit(lambda: ops.gather_reduce(y, plan, M, red), n=5, warm=2)
+                nbytes = E * (4.0 * M + 4) + N * (4.0 * M + 4)
+                print(f"powerlaw alpha={alpha} max_deg={int(deg.max())} hubs>{4096}={int((deg > 4096).sum())} "
+                      f"hub_threshold={thr} {red}: {ms:.3f} ms  {E / ms / 1e6:.2f} G edges/s  {nbytes / ms / 1e9:.2f} TB/s")
+            t = timeit(lambda: ops.build_plan(cadj, N), n=5, warm=2)
+            print(f"   plan build: {t:.3f} ms")
+        del y, plan
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "powerlaw":
+    powerlaw()

@@ -49,7 +49,7 @@ def test_argument_validation_without_a_gpu(lib):
     rc = lib.ptgnn_amd_linear_f32(None, 4, 0, 4, None, 4, None, 0, None, 4, None)
     assert rc == -1 and b"linear" in lib.ptgnn_amd_last_error()
     rc = lib.ptgnn_amd_gather_reduce_f32(None, 4, None, 4, None, None, 0, 4, 4, 9, 0, None, None, 1e-5,
-                                         None, 4, None, None)
+                                         None, 4, None, 0, 0, None, None, None, 0, None, None)
     assert rc == -1 and b"reduce" in lib.ptgnn_amd_last_error()
     with pytest.raises(PtgnnAmdError):
         _lib.check(rc, "gather_reduce")
