@@ -276,9 +276,44 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
   float *const slab = smem + wave * SLAB_FLOATS;
   constexpr int LPRW = 8 * NJ;             // lanes per output row (float4 each)
   constexpr int RPI = 64 / LPRW;           // rows per wave-instruction
+  constexpr int NIT = 32 / RPI;
   const int c4 = (lane % LPRW) * 4;
   const int rsub = lane / LPRW;
   const int gcol = col0 + wn * 32 * NJ + c4;
+  // Interior tiles (all of them but the last row/column of tiles) take a straight-line path: the
+  // guarded variant below compiles to a read -> wait -> ~8 branches -> store chain per float4 and
+  // cost 22-27 % of the kernel (profiles/r01_notes.md).
+  const bool interior = (vec_store & 1) && row0 + 128 <= rows && col0 + BN <= n_out &&
+                        (bias == nullptr || (vec_store & 2));
+  if (interior) {
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4 *>(bias + gcol);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
+      __builtin_amdgcn_wave_barrier();
+      float4 v[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        v[it] = *reinterpret_cast<const float4 *>(slab + (it * RPI + rsub) * SLAB_LD + c4);
+      __builtin_amdgcn_wave_barrier();
+      float *dst = y + (row0 + wm * 64 + i * 32 + rsub) * ld_y + gcol;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        float4 o;
+        o.x = act_apply<ACT>(v[it].x + bv.x);
+        o.y = act_apply<ACT>(v[it].y + bv.y);
+        o.z = act_apply<ACT>(v[it].z + bv.z);
+        o.w = act_apply<ACT>(v[it].w + bv.w);
+        *reinterpret_cast<float4 *>(dst + (int64_t)it * RPI * ld_y) = o;
+      }
+    }
+    return;
+  }
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) {
     if (gcol + 0 < n_out) bv.x = bias[gcol + 0];
@@ -286,17 +321,17 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
     if (gcol + 2 < n_out) bv.z = bias[gcol + 2];
     if (gcol + 3 < n_out) bv.w = bias[gcol + 3];
   }
-#pragma unroll
+#pragma unroll 1
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
+        slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = i == 0 ? acc[0][j][r] : acc[1][j][r];
     __builtin_amdgcn_wave_barrier();
     const int64_t rbase = row0 + wm * 64 + i * 32;
-#pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
       const int rl = it * RPI + rsub;
       int64_t grow = rbase + rl;
       if (ablate & 8) grow &= 1023;  // ablation 8: fold the output onto 1 MB => no HBM writes
@@ -307,7 +342,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
       v.w = act_apply<ACT>(v.w + bv.w);
       if (grow < rows) {
         float *dst = y + grow * ld_y + gcol;
-        if (vec_store && gcol + 3 < n_out) {
+        if ((vec_store & 1) && gcol + 3 < n_out) {
           *reinterpret_cast<float4 *>(dst) = v;
         } else {
           if (gcol + 0 < n_out) dst[0] = v.x;
@@ -770,14 +805,25 @@ __global__ __launch_bounds__(256, 2) void k_gru(const float *__restrict__ a, int
   if (j >= H) return;
   const float bir = b_ih[j], biz = b_ih[H + j], bin = b_ih[2 * H + j];
   const float bhr = b_hh[j], bhz = b_hh[H + j], bhn = b_hh[2 * H + j];
+  // torch.nn.GRUCell: gi = W_ih x + b_ih, gh = W_hh h + b_hh
+  float res[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-    // torch.nn.GRUCell: gi = W_ih x + b_ih, gh = W_hh h + b_hh
     const float rg_ = sigmoidf_((acc_r[r] + bir) + bhr);
     const float zg = sigmoidf_((acc_z[r] + biz) + bhz);
     const float ng = tanhf((acc_in[r] + bin) + rg_ * (acc_hn[r] + bhn));
-    if (row < n) out[row * ld_out + j] = (1.0f - zg) * ng + zg * hprev[r];
+    res[r] = (1.0f - zg) * ng + zg * hprev[r];
+  }
+  float *dst = out + (row0 + wave * 32 + 4 * hi) * ld_out + j;
+  if (row0 + 128 <= n) {  // interior tile: straight-line stores (2 x 128 B per wave-instruction)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * ld_out] = res[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (row < n) out[row * ld_out + j] = res[r];
+    }
   }
 }
 
@@ -864,7 +910,7 @@ extern "C" int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int
   const unsigned grid = persistent ? persistent_grid(num_tiles, mode == 3 ? (linear_bpc(0) > 0 && getenv("PTGNN_AMD_LINEAR_BPC") ? linear_bpc(nj) : (nj == 1 ? 3 : 2)) : linear_bpc(nj))
                                    : (unsigned)xcd_padded_blocks(num_tiles);
   const bool al = (k % 4 == 0) && (ld_x % 4 == 0) && aligned16(x) && aligned16(w);
-  const int vec_store = (ld_y % 4 == 0) && aligned16(y);
+  const int vec_store = ((ld_y % 4 == 0) && aligned16(y) ? 1 : 0) | ((bias && aligned16(bias) && n_out % 4 == 0) ? 2 : 0);
   hipStream_t st = (hipStream_t)stream_;
   // start offset per co-resident slot: one tile's own MFMA time, in s_sleep(127) units (8128 clk)
   const char *sg = getenv("PTGNN_AMD_LINEAR_STAGGER");

@@ -132,16 +132,44 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
   const int c4 = (lane % LPRW) * 4, rsub = lane / LPRW;
   const int gcol = col0 + wn * 32 * NJ + c4;
   const int64_t rows_left = n_edges - e0;   // valid rows of this tile
+  constexpr int NIT = 32 / RPI;
+  if (rows_left >= 128 && col0 + BN <= n_out) {
+    // interior tile: straight-line slab round trip + float4 stores (a guarded epilogue compiles to a
+    // read -> wait -> branches -> store chain per float4; profiles/r01_notes.md)
 #pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
+      __builtin_amdgcn_wave_barrier();
+      float4 v[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        v[it] = *reinterpret_cast<const float4 *>(slab + (it * RPI + rsub) * SLAB_LD + c4);
+      __builtin_amdgcn_wave_barrier();
+      float *dst = msg + (out_row0 + wm * 64 + i * 32 + rsub) * ld_msg + gcol;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        float4 o;
+        o.x = act_apply<ACT>(v[it].x); o.y = act_apply<ACT>(v[it].y);
+        o.z = act_apply<ACT>(v[it].z); o.w = act_apply<ACT>(v[it].w);
+        *reinterpret_cast<float4 *>(dst + (int64_t)it * RPI * ld_msg) = o;
+      }
+    }
+    return;
+  }
+#pragma unroll 1
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
+        slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = i == 0 ? acc[0][j][r] : acc[1][j][r];
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
       const int rl = it * RPI + rsub;
       const int trow = wm * 64 + i * 32 + rl;
       float4 v = *reinterpret_cast<const float4 *>(slab + rl * SLAB_LD + c4);
