@@ -5,9 +5,17 @@
 //   1. k_pack   : walk the T lists (pointer table in the kernel argument segment), narrow to
 //                 int32, emit key = row (dst), payload = packed (src << type_bits | type) and the
 //                 edge position in the type-major concatenation.
-//   2. stable LSD radix sort of (key, position) over ceil(log2(N)) bits (rocPRIM device sort).
+//   2. stable LSD radix sort of (key, position) over ceil(log2(rows)) bits, <= 9 bits per pass
+//      (18-bit node ids = 2 passes).  Hand-written for the sizes that matter here: rocPRIM's onesweep
+//      sort runs 1.1 M pairs as ~140 long-running workgroups (29 us per pass on MI355X, latency-bound
+//      with half the CUs idle); these kernels use one workgroup per 1024 pairs (one pair per lane):
+//        k_radix_hist    per-workgroup digit histogram            -> hist[digit][workgroup]
+//        exclusive scan  of the digit-major histogram (rocPRIM device scan: plumbing, 1 small launch)
+//        k_radix_scatter stable rank = earlier waves' count (LDS) + same-digit lanes below (ballots)
+//      PTGNN_AMD_SORT=rocprim selects the library sort instead (A/B + fallback).
 //   3. k_finish : payload gather into CSR order + rowptr from key boundaries.
-// HBM-bound integer work: 8 B/edge read once, O(passes * 8 B/edge) inside the sort.
+// HBM-bound integer work: 8 B/edge read once, O(passes * 16 B/edge) inside the sort.
+#include <stdlib.h>
 #include <string.h>
 
 #include <rocprim/rocprim.hpp>
@@ -83,6 +91,63 @@ __global__ __launch_bounds__(256) void k_finish(const uint32_t *__restrict__ key
     for (int64_t v = k + 1; v <= num_nodes; ++v) rowptr[v] = (int32_t)num_edges;
 }
 
+// ---- stable LSD radix sort of (key, value) pairs, one pair per lane, 1024 pairs per workgroup ------
+constexpr int kSortBlock = 1024;
+constexpr int kMaxBins = 512;
+
+__global__ __launch_bounds__(kSortBlock) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n,
+                                                           int shift, int bits,
+                                                           int32_t *__restrict__ hist, int64_t nblocks) {
+  __shared__ int lh[kMaxBins];
+  const int bins = 1 << bits;
+  for (int j = threadIdx.x; j < bins; j += kSortBlock) lh[j] = 0;
+  __syncthreads();
+  const int64_t i = blockIdx.x * (int64_t)kSortBlock + threadIdx.x;
+  if (i < n) atomicAdd(&lh[(keys[i] >> shift) & (bins - 1)], 1);
+  __syncthreads();
+  for (int j = threadIdx.x; j < bins; j += kSortBlock) hist[(int64_t)j * nblocks + blockIdx.x] = lh[j];
+}
+
+__global__ __launch_bounds__(kSortBlock) void k_radix_scatter(
+    const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, int64_t n, int shift, int bits,
+    const int32_t *__restrict__ offs /* scanned hist */, int64_t nblocks) {
+  __shared__ int wave_cnt[(kSortBlock / 64) * kMaxBins];
+  const int bins = 1 << bits;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = threadIdx.x; j < (kSortBlock / 64) * bins; j += kSortBlock) wave_cnt[j] = 0;
+  const int64_t i = blockIdx.x * (int64_t)kSortBlock + threadIdx.x;
+  const bool valid = i < n;
+  const uint32_t key = valid ? keys_in[i] : 0u;
+  const int32_t val = valid ? vals_in[i] : 0;
+  const int digit = (int)((key >> shift) & (uint32_t)(bins - 1));
+  // lanes of this wave that hold the same digit (ballots are wave-wide, 64 bits)
+  unsigned long long same = __ballot(valid);
+  for (int b = 0; b < bits; ++b) {
+    const bool bit = (digit >> b) & 1;
+    const unsigned long long bal = __ballot(bit);
+    same &= bit ? bal : ~bal;
+  }
+  const int rank = __popcll(same & ((1ull << lane) - 1ull));
+  __syncthreads();                                     // wave_cnt is zeroed
+  if (valid && rank == 0) wave_cnt[wave * bins + digit] = __popcll(same);
+  __syncthreads();
+  for (int d = threadIdx.x; d < bins; d += kSortBlock) {   // exclusive prefix over the 16 waves
+    int run = 0;
+    for (int w = 0; w < kSortBlock / 64; ++w) {
+      const int t = wave_cnt[w * bins + d];
+      wave_cnt[w * bins + d] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  if (valid) {
+    const int64_t pos = (int64_t)offs[(int64_t)digit * nblocks + blockIdx.x] + wave_cnt[wave * bins + digit] + rank;
+    keys_out[pos] = key;
+    vals_out[pos] = val;
+  }
+}
+
 // (chunk, row) pairs of every row longer than `threshold`, appended in arbitrary order (consumers
 // treat the pairs independently); *count must be 0 on entry.
 __global__ __launch_bounds__(256) void k_hub_list(const int32_t *__restrict__ rowptr, int64_t num_rows,
@@ -132,8 +197,22 @@ __global__ __launch_bounds__(256) void k_validate(const int64_t *__restrict__ id
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t keys_in, keys_out, pos_in, pos_out, packed, sort_tmp, sort_tmp_bytes, total;
+  size_t keys_in, keys_out, pos_in, pos_out, packed, sort_tmp, sort_tmp_bytes, hist, hist_scan, total;
 };
+
+// The one-pair-per-lane kernels win up to a few million edges (minibatch sizes: 0.11 vs 0.15 ms at
+// 1.1 M, 0.085 vs 0.16 ms at 0.6 M edges); beyond that rocPRIM's many-items-per-thread onesweep
+// coalesces its scatters better (0.67 vs 0.80 ms at 12.5 M).  PTGNN_AMD_SORT=rocprim|custom forces one.
+bool use_rocprim_sort(int64_t num_edges) {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("PTGNN_AMD_SORT");
+    v = !e ? 0 : (strcmp(e, "rocprim") == 0 ? 1 : (strcmp(e, "custom") == 0 ? 2 : 0));
+  }
+  if (v == 1) return true;
+  if (v == 2) return false;
+  return num_edges > ((int64_t)4 << 20);
+}
 
 int end_bit_for(int64_t num_nodes) {
   int b = 1;
@@ -144,9 +223,16 @@ int end_bit_for(int64_t num_nodes) {
 hipError_t sort_tmp_bytes(int64_t num_edges, int64_t num_nodes, size_t *bytes) {
   *bytes = 0;
   if (num_edges == 0) return hipSuccess;
-  return rocprim::radix_sort_pairs(nullptr, *bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                   (int32_t *)nullptr, (int32_t *)nullptr, (size_t)num_edges, 0,
-                                   end_bit_for(num_nodes), (hipStream_t)0);
+  size_t a = 0, b = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, a, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                           (int32_t *)nullptr, (int32_t *)nullptr, (size_t)num_edges, 0,
+                                           end_bit_for(num_nodes), (hipStream_t)0);
+  if (e != hipSuccess) return e;
+  const size_t nh = (size_t)kMaxBins * (size_t)((num_edges + kSortBlock - 1) / kSortBlock);
+  e = rocprim::exclusive_scan(nullptr, b, (int32_t *)nullptr, (int32_t *)nullptr, 0, nh,
+                              rocprim::plus<int32_t>(), (hipStream_t)0);
+  *bytes = a > b ? a : b;
+  return e;
 }
 
 bool layout(int64_t num_edges, int64_t num_nodes, WsLayout *L) {
@@ -161,6 +247,9 @@ bool layout(int64_t num_edges, int64_t num_nodes, WsLayout *L) {
   L->packed = o;   o += e4;
   L->sort_tmp = o; o += align_up(tmp, 256);
   L->sort_tmp_bytes = tmp;
+  const size_t nh = align_up((size_t)kMaxBins * (size_t)((num_edges + kSortBlock - 1) / kSortBlock) * 4, 256);
+  L->hist = o;      o += nh;
+  L->hist_scan = o; o += nh;
   L->total = o + 256;
   return true;
 }
@@ -244,8 +333,34 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
       base += chunk;
     }
     size_t tmp = L.sort_tmp_bytes;
-    PTGNN_HIP(rocprim::radix_sort_pairs(ws + L.sort_tmp, tmp, keys_in, keys_out, pos_in, pos_out,
-                                        (size_t)num_edges, 0, end_bit_for(num_nodes), stream));
+    if (use_rocprim_sort(num_edges)) {
+      PTGNN_HIP(rocprim::radix_sort_pairs(ws + L.sort_tmp, tmp, keys_in, keys_out, pos_in, pos_out,
+                                          (size_t)num_edges, 0, end_bit_for(num_nodes), stream));
+    } else {
+      const int total_bits = end_bit_for(num_nodes);
+      const int passes = (total_bits + 8) / 9;
+      const int bits = (total_bits + passes - 1) / passes;          // <= 9
+      const int64_t nblocks = (num_edges + kSortBlock - 1) / kSortBlock;
+      int32_t *hist = (int32_t *)(ws + L.hist), *hscan = (int32_t *)(ws + L.hist_scan);
+      uint32_t *ka = keys_in, *kb = keys_out;
+      int32_t *va = pos_in, *vb = pos_out;
+      for (int p = 0; p < passes; ++p) {
+        const int shift = p * bits;
+        k_radix_hist<<<(unsigned)nblocks, kSortBlock, 0, stream>>>(ka, num_edges, shift, bits, hist, nblocks);
+        PTGNN_LAUNCH_CHECK();
+        size_t stmp = L.sort_tmp_bytes;
+        PTGNN_HIP(rocprim::exclusive_scan(ws + L.sort_tmp, stmp, hist, hscan, 0,
+                                          (size_t)((int64_t)(1 << bits) * nblocks),
+                                          rocprim::plus<int32_t>(), stream));
+        k_radix_scatter<<<(unsigned)nblocks, kSortBlock, 0, stream>>>(ka, va, kb, vb, num_edges, shift, bits,
+                                                                      hscan, nblocks);
+        PTGNN_LAUNCH_CHECK();
+        uint32_t *tk = ka; ka = kb; kb = tk;
+        int32_t *tv = va; va = vb; vb = tv;
+      }
+      keys_out = ka;   // the sorted pairs live in whichever buffer the last pass wrote
+      pos_out = va;
+    }
   }
   const int64_t work = num_edges > 0 ? num_edges : 1;
   const int64_t blocks = num_edges > 0 ? (work + 255) / 256 : 64;
