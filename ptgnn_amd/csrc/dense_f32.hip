@@ -154,9 +154,41 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear(
     lds_barrier();  // the slab aliases the operand buffer other waves may still be reading
     constexpr int LPRW = 8 * NJ;             // lanes per output row (float4 each)
     constexpr int RPI = 64 / LPRW;           // rows per wave-instruction
+    constexpr int NIT = 32 / RPI;
     const int c4 = (lane % LPRW) * 4;
     const int rsub = lane / LPRW;
     const int gcol = col0 + wn * 32 * NJ + c4;
+    if ((vec_store & 1) && row0 + 128 <= rows && col0 + BN <= n_out && (bias == nullptr || (vec_store & 2))) {
+      float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias) bv4 = *reinterpret_cast<const float4 *>(bias + gcol);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
+            acc[i][j][r] = 0.f;
+          }
+        __builtin_amdgcn_wave_barrier();
+        float4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          v[it] = *reinterpret_cast<const float4 *>(slab + (it * RPI + rsub) * SLAB_LD + c4);
+        __builtin_amdgcn_wave_barrier();
+        float *dst = y + (row0 + wm * 64 + i * 32 + rsub) * ld_y + gcol;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          float4 o;
+          o.x = act_apply<ACT>(v[it].x + bv4.x);
+          o.y = act_apply<ACT>(v[it].y + bv4.y);
+          o.z = act_apply<ACT>(v[it].z + bv4.z);
+          o.w = act_apply<ACT>(v[it].w + bv4.w);
+          *reinterpret_cast<float4 *>(dst + (int64_t)it * RPI * ld_y) = o;
+        }
+      }
+      continue;
+    }
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) {
       if (gcol + 0 < n_out) bv.x = bias[gcol + 0];
@@ -187,7 +219,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear(
         v.w = act_apply<ACT>(v.w + bv.w);
         if (grow < rows) {
           float *dst = y + grow * ld_y + gcol;
-          if (vec_store && gcol + 3 < n_out) {
+          if ((vec_store & 1) && gcol + 3 < n_out) {
             *reinterpret_cast<float4 *>(dst) = v;
           } else {
             if (gcol + 0 < n_out) dst[0] = v.x;
@@ -478,7 +510,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void k_linear_pp(
         v.w = act_apply<ACT>(v.w + bv.w);
         if (grow < rows) {
           float *dst = y + grow * ld_y + gcol;
-          if (vec_store && gcol + 3 < n_out) {
+          if ((vec_store & 1) && gcol + 3 < n_out) {
             *reinterpret_cast<float4 *>(dst) = v;
           } else {
             if (gcol + 0 < n_out) dst[0] = v.x;
@@ -553,7 +585,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void k_linear_pp(
       v.w = act_apply<ACT>(v.w + bv.w);
       if (grow < rows) {
         float *dst = y + grow * ld_y + gcol;
-        if (vec_store && gcol + 3 < n_out) {
+        if ((vec_store & 1) && gcol + 3 < n_out) {
           *reinterpret_cast<float4 *>(dst) = v;
         } else {
           if (gcol + 0 < n_out) dst[0] = v.x;
@@ -701,7 +733,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void k_linear_wp(
       v.w = act_apply<ACT>(v.w + bv.w);
       if (grow < rows) {
         float *dst = y + grow * ld_y + gcol;
-        if (vec_store && gcol + 3 < n_out) {
+        if ((vec_store & 1) && gcol + 3 < n_out) {
           *reinterpret_cast<float4 *>(dst) = v;
         } else {
           if (gcol + 0 < n_out) dst[0] = v.x;
