@@ -93,6 +93,11 @@ int ptgnn_amd_csr_build(const int64_t *const *src_per_type, /* host [num_types] 
                         int32_t *hub_count /* nullable device scalar: number of pairs */,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* The hub (chunk, row) list of an existing rowptr (plans that are not built by ptgnn_amd_csr_build,
+ * e.g. pooling over the already sorted node_to_graph_idx).  *hub_count must be 0 on entry. */
+int ptgnn_amd_hub_list(const int32_t *rowptr, int64_t num_rows, int32_t hub_threshold,
+                       int32_t *hub_entries, int32_t *hub_count, void *stream);
+
 /* Optional debug aid (the reference performs no range check either): counts indices outside
  * [0, num_nodes) into *bad_count (device int32, caller zeroes it). */
 int ptgnn_amd_validate_indices(const int64_t *idx, int64_t n, int64_t num_nodes,

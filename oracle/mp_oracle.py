@@ -128,6 +128,25 @@ def mlp_mp_layer(node_states, adjacency_lists: Adj, edge_features, w: Dict,
     return (x, aggregated) if return_aggregate else x
 
 
+def global_gru_exchange(node_states, node_to_graph_idx, w: Dict):
+    """GruGlobalStateUpdate with WeightedSum / Simple pooling (eval mode):
+    globalgraphexchange.py:29-64 + varsizedsummary.py:28-41,68-81.
+
+    w: {"pool": "weighted_sum"|"sum"|"mean"|"max"|"min", "pool_w": [1, D] (weighted_sum),
+        "w_ih", "w_hh", "b_ih", "b_hh"}
+    """
+    num_samples = int(node_to_graph_idx.max()) + 1                                # :40
+    if w["pool"] == "weighted_sum":
+        weights = torch.sigmoid(linear(node_states, w["pool_w"]).squeeze(-1))     # varsizedsummary.py:73-75
+        pooled = scatter(node_states * weights.unsqueeze(-1), node_to_graph_idx, dim=0,
+                         dim_size=num_samples, reduce="sum")                      # :76-81
+    else:
+        pooled = scatter(node_states, node_to_graph_idx, dim=0, dim_size=num_samples,
+                         reduce=w["pool"])                                        # :35-41
+    per_node = pooled[node_to_graph_idx]                                          # globalgraphexchange.py:45
+    return gru_cell(per_node, node_states, w["w_ih"], w["w_hh"], w["b_ih"], w["b_hh"])  # :62-64
+
+
 # --------------------------------------------------------------------------------------------
 # the container: edge augmentation + layer loop
 # --------------------------------------------------------------------------------------------
@@ -144,7 +163,8 @@ def augment_adjacency(adjacency_lists: Adj, num_nodes: int, introduce_backwards_
     return adj
 
 
-def run_layer_stack(node_states, adjacency_lists: Adj, layers: Sequence[Dict], edge_features=None):
+def run_layer_stack(node_states, adjacency_lists: Adj, layers: Sequence[Dict], edge_features=None,
+                    node_to_graph_idx=None):
     """GraphNeuralNetwork.gnn, graphneuralnetwork.py:121-131 (+ residual layers,
     residuallayers.py:8-96).  `layers` is a list of specs {"kind": ..., ...}; a tied layer is
     the same dict repeated."""
@@ -159,6 +179,8 @@ def run_layer_stack(node_states, adjacency_lists: Adj, layers: Sequence[Dict], e
             x = ggnn_layer(x, adjacency_lists, edge_features, spec)
         elif kind == "mlp":
             x = mlp_mp_layer(x, adjacency_lists, edge_features, spec)
+        elif kind == "global_gru":
+            x = global_gru_exchange(x, node_to_graph_idx, spec)
         elif kind == "residual_origin":                                           # residuallayers.py:31
             stash[spec["name"]] = x
         elif kind == "residual_concat":                                           # :86
@@ -173,13 +195,13 @@ def run_layer_stack(node_states, adjacency_lists: Adj, layers: Sequence[Dict], e
 
 
 def gnn_forward(initial_node_representations, adjacency_lists: Adj, layers: Sequence[Dict],
-                introduce_backwards_edges: bool, add_self_edges: bool):
+                introduce_backwards_edges: bool, add_self_edges: bool, node_to_graph_idx=None):
     """GraphNeuralNetwork.forward minus the embedder, graphneuralnetwork.py:160-209.
     Returns (output_node_representations, num_edges_counted) where the edge count follows
     :198 (edges after augmentation)."""
     n = initial_node_representations.shape[0]
     adj = augment_adjacency(adjacency_lists, n, introduce_backwards_edges, add_self_edges)
-    out = run_layer_stack(initial_node_representations, adj, layers)
+    out = run_layer_stack(initial_node_representations, adj, layers, node_to_graph_idx=node_to_graph_idx)
     return out, sum(int(a[0].shape[0]) for a in adj)
 
 
@@ -275,6 +297,17 @@ def weights_from_reference_layer(layer) -> Dict:
                 spec["dense_w"], spec["dense_b"] = m.weight.detach().clone(), m.bias.detach().clone()
             elif n == "Tanh":
                 spec["tanh"] = True
+        return spec
+    if cls == "GruGlobalStateUpdate":
+        p = "_GruGlobalStateUpdate__gru_cell."
+        pool = getattr(layer, "_AbstractGlobalGraphExchange__global_graph_representation_module")
+        spec = {"kind": "global_gru", "w_ih": sd[p + "weight_ih"], "w_hh": sd[p + "weight_hh"],
+                "b_ih": sd[p + "bias_ih"], "b_hh": sd[p + "bias_hh"]}
+        if type(pool).__name__ == "WeightedSumVarSizedElementReduce":
+            spec["pool"] = "weighted_sum"
+            spec["pool_w"] = pool.state_dict()["_WeightedSumVarSizedElementReduce__weights_layer.weight"].clone()
+        else:
+            spec["pool"] = getattr(pool, "_SimpleVarSizedElementReduce__summarization_type")
         return spec
     raise TypeError(cls)
 

@@ -387,6 +387,18 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
   return PTGNN_AMD_OK;
 }
 
+extern "C" int ptgnn_amd_hub_list(const int32_t *rowptr, int64_t num_rows, int32_t hub_threshold,
+                                   int32_t *hub_entries, int32_t *hub_count, void *stream_) {
+  PTGNN_REQUIRE(rowptr && hub_entries && hub_count && num_rows >= 0 && hub_threshold >= 2048,
+                PTGNN_AMD_EINVAL, "hub_list: bad arguments");
+  if (num_rows == 0) return PTGNN_AMD_OK;
+  const int64_t hb = (num_rows + 255) / 256;
+  k_hub_list<<<(unsigned)(hb < 2048 ? hb : 2048), 256, 0, (hipStream_t)stream_>>>(
+      rowptr, num_rows, hub_threshold, 1024, hub_entries, hub_count);
+  PTGNN_LAUNCH_CHECK();
+  return PTGNN_AMD_OK;
+}
+
 extern "C" int ptgnn_amd_validate_indices(const int64_t *idx, int64_t n, int64_t num_nodes,
                                           int32_t *bad_count, void *stream_) {
   PTGNN_REQUIRE(n >= 0 && bad_count && (n == 0 || idx), PTGNN_AMD_EINVAL, "validate: bad args");

@@ -239,6 +239,26 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
     return plan
 
 
+def plan_from_sorted_index(index: torch.Tensor, num_segments: int) -> GraphPlan:
+    """Plan of a segment reduce whose index is already sorted (node_to_graph_idx of a disjoint-union
+    batch): no sort -- rowptr is a searchsorted over the index, col/perm are the identity."""
+    if not index.is_cuda or index.dtype != torch.int64 or index.dim() != 1:
+        raise _lib.PtgnnAmdError("plan_from_sorted_index: expected a 1-D CUDA int64 index")
+    n = int(index.shape[0])
+    bounds = torch.arange(num_segments + 1, device=index.device, dtype=torch.int64)
+    rowptr = torch.searchsorted(index, bounds).to(torch.int32)
+    ident = torch.arange(max(n, 1), device=index.device, dtype=torch.int32)
+    plan = GraphPlan(rowptr, ident, ident, 0, num_segments, n, 1)
+    if HUB_THRESHOLD > 0 and n > HUB_THRESHOLD:   # graphs are long segments: reuse the hub machinery
+        lib = _lib.load()
+        plan.hub_entries = torch.empty(2 * ((n + 1023) // 1024), 2, dtype=torch.int32, device=index.device)
+        plan.hub_count = torch.zeros(1, dtype=torch.int32, device=index.device)
+        rc = lib.ptgnn_amd_hub_list(rowptr.data_ptr(), num_segments, HUB_THRESHOLD,
+                                    plan.hub_entries.data_ptr(), plan.hub_count.data_ptr(), _stream(rowptr))
+        _lib.check(rc, "ptgnn_amd_hub_list")
+    return plan
+
+
 _PLAN_CACHE: List[GraphPlan] = []
 _PLAN_CACHE_SIZE = 4
 

@@ -1,0 +1,111 @@
+"""Node -> graph pooling ("var-sized element reduce") and the global-exchange layer that uses it:
+mirrors of ptgnn/neuralmodels/reduceops/varsizedsummary.py:11-81 and
+ptgnn/neuralmodels/gnn/messagepassing/globalgraphexchange.py (same class names, constructor keywords
+and name-mangled parameter names), used by the VarMisuse GGNN stack (varmisuse/train.py:76-107).
+
+The pooling is the same segment reduce as message aggregation with `node_to_graph_idx` as the index.
+A disjoint-union batch lists the nodes of graph 0, then graph 1, ... (graphneuralnetwork.py:418-423),
+so the index is SORTED and the plan needs no sort at all: rowptr = searchsorted, col = identity.
+"""
+from typing import NamedTuple, Union
+
+import torch
+from torch import nn
+
+from ptgnn_amd import _lib, ops
+from ptgnn_amd.layers import AbstractMessagePassingLayer, _check_device, _no_grad_needed
+from ptgnn_amd.scatter import segment_reduce
+
+
+class ElementsToSummaryRepresentationInput(NamedTuple):
+    """varsizedsummary.py:11-18."""
+    element_embeddings: torch.Tensor
+    element_to_sample_map: torch.Tensor
+    num_samples: Union[torch.Tensor, int]
+
+
+class AbstractVarSizedElementReduce(nn.Module):
+    def forward(self, inputs: ElementsToSummaryRepresentationInput) -> torch.Tensor:
+        raise NotImplementedError
+
+
+def _pool(values: torch.Tensor, index: torch.Tensor, num_samples, reduce: str) -> torch.Tensor:
+    if not values.is_cuda:
+        raise _lib.PtgnnAmdError("ptgnn_amd reduce ops run on the MI355X only")
+    plan = ops.plan_from_sorted_index(index, int(num_samples))
+    dt = values.dtype
+    return segment_reduce(values.to(torch.float32).contiguous(), plan, reduce).to(dt)
+
+
+class SimpleVarSizedElementReduce(AbstractVarSizedElementReduce):
+    def __init__(self, summarization_type: str):
+        super().__init__()
+        assert summarization_type in {"sum", "mean", "max", "min"}
+        self.__summarization_type = summarization_type
+
+    def forward(self, inputs: ElementsToSummaryRepresentationInput) -> torch.Tensor:
+        return _pool(inputs.element_embeddings, inputs.element_to_sample_map, inputs.num_samples,
+                     self.__summarization_type)
+
+
+class WeightedSumVarSizedElementReduce(AbstractVarSizedElementReduce):
+    def __init__(self, representation_size: int):
+        super().__init__()
+        self.__weights_layer = nn.Linear(representation_size, 1, bias=False)
+
+    def forward(self, inputs: ElementsToSummaryRepresentationInput) -> torch.Tensor:
+        x = inputs.element_embeddings
+        weights = torch.sigmoid(self.__weights_layer(x).squeeze(-1))          # [num_elements]
+        return _pool(x * weights.unsqueeze(-1), inputs.element_to_sample_map, inputs.num_samples, "sum")
+
+
+class AbstractGlobalGraphExchange(AbstractMessagePassingLayer):
+    """globalgraphexchange.py:13-45: pool node states per graph, broadcast back, update the nodes."""
+
+    def __init__(self, global_graph_representation_module: AbstractVarSizedElementReduce,
+                 dropout_rate: float = 0.0):
+        super().__init__()
+        self.__global_graph_representation_module = global_graph_representation_module
+        self.__dropout = nn.Dropout(p=dropout_rate)
+
+    def _update_node_states(self, node_states, global_info_per_node):
+        raise NotImplementedError
+
+    def forward(self, node_states, adjacency_lists, node_to_graph_idx, reference_node_ids,
+                reference_node_graph_idx, edge_features) -> torch.Tensor:
+        _check_device(node_states)
+        # the batch is a disjoint union in graph order => the last node belongs to the last graph
+        # (the reference's `node_to_graph_idx.max() + 1` is the same host read-back)
+        num_graphs = int(node_to_graph_idx[-1]) + 1 if node_to_graph_idx.numel() else 0
+        e = ElementsToSummaryRepresentationInput(node_states, node_to_graph_idx, num_graphs)
+        graph_reps = self.__dropout(self.__global_graph_representation_module(e))
+        if graph_reps.dtype == torch.float32 and _no_grad_needed(graph_reps):
+            per_node = ops.gather_rows(graph_reps.contiguous(), node_to_graph_idx)
+        else:
+            per_node = graph_reps[node_to_graph_idx]
+        return self._update_node_states(node_states, per_node)
+
+
+class GruGlobalStateUpdate(AbstractGlobalGraphExchange):
+    def __init__(self, global_graph_representation_module: AbstractVarSizedElementReduce,
+                 input_state_size: int, summarized_state_size: int, dropout_rate: float = 0.0):
+        super().__init__(global_graph_representation_module, dropout_rate)
+        self.__input_dim = input_state_size
+        self.__summarized_state_size = summarized_state_size
+        self.__gru_cell = nn.GRUCell(input_size=summarized_state_size, hidden_size=input_state_size)
+
+    def _update_node_states(self, node_states, global_info_per_node):
+        gru = self.__gru_cell
+        if (node_states.dtype == torch.float32
+                and _no_grad_needed(node_states, global_info_per_node, *gru.parameters())):
+            return ops.gru_cell(global_info_per_node, node_states, gru.weight_ih, gru.weight_hh,
+                                gru.bias_ih, gru.bias_hh)
+        return gru(global_info_per_node, node_states)
+
+    @property
+    def input_state_dimension(self) -> int:
+        return self.__input_dim
+
+    @property
+    def output_state_dimension(self) -> int:
+        return self.__input_dim

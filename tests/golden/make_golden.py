@@ -30,6 +30,9 @@ from ptgnn.neuralmodels.gnn import GraphData, GraphNeuralNetwork, GraphNeuralNet
 from ptgnn.neuralmodels.gnn.messagepassing import (  # noqa: E402
     GatedMessagePassingLayer, MlpMessagePassingLayer, MeanResidualLayer)
 from ptgnn.neuralmodels.gnn.messagepassing.residuallayers import ConcatResidualLayer  # noqa: E402
+from ptgnn.neuralmodels.gnn.messagepassing import GruGlobalStateUpdate  # noqa: E402
+from ptgnn.neuralmodels.reduceops.varsizedsummary import (  # noqa: E402
+    SimpleVarSizedElementReduce, WeightedSumVarSizedElementReduce)
 
 from oracle.fixtures import pack_adj, pack_specs  # noqa: E402
 from oracle.mp_oracle import weights_from_reference_layer  # noqa: E402
@@ -171,6 +174,35 @@ def containers():
          node_to_graph_idx=node_to_graph, **pack_adj(adj), **pack_specs(specs))
 
 
+def varmisuse_ggnn():
+    """VarMisuse GGNN architecture (varmisuse/train.py:76-107) at hidden 16, T0=2 -> T=5, with one
+    weighted-sum and one max global exchange."""
+    gen = torch.Generator().manual_seed(99)
+    n, H, T = 60, 16, 5
+    node_to_graph = torch.repeat_interleave(torch.arange(3), torch.tensor([25, 5, 30]))
+    torch.manual_seed(12)
+    ggnn = GatedMessagePassingLayer(H, H, T, "sum", dropout_rate=0.01)
+    r1, r2 = MeanResidualLayer(H), MeanResidualLayer(H)
+    g1 = GruGlobalStateUpdate(WeightedSumVarSizedElementReduce(H), H, H, dropout_rate=0.1)
+    g2 = GruGlobalStateUpdate(SimpleVarSizedElementReduce("max"), H, H, dropout_rate=0.1)
+    mods = [r1.pass_through_dummy_layer(), r2.pass_through_dummy_layer(), ggnn, ggnn, ggnn, g1, ggnn, r1,
+            ggnn, ggnn, ggnn, g2, ggnn, r2]
+    net = GraphNeuralNetwork(mods, _Identity(), introduce_backwards_edges=True, add_self_edges=True).eval()
+    adj = rand_adj(gen, n, [80, 33])
+    x = torch.randn(n, H, generator=gen)
+    with torch.no_grad():
+        out = net(node_data={"x": x}, adjacency_lists=[a for a in adj], edge_feature_data=[],
+                  node_to_graph_idx=node_to_graph, reference_node_ids={}, reference_node_graph_idx={},
+                  num_graphs=3)
+    s_ggnn = weights_from_reference_layer(ggnn)
+    sg1, sg2 = weights_from_reference_layer(g1), weights_from_reference_layer(g2)
+    specs = [{"kind": "residual_origin", "name": "r1"}, {"kind": "residual_origin", "name": "r2"},
+             s_ggnn, s_ggnn, s_ggnn, sg1, s_ggnn, {"kind": "residual_mean", "name": "r1"},
+             s_ggnn, s_ggnn, s_ggnn, sg2, s_ggnn, {"kind": "residual_mean", "name": "r2"}]
+    save("gnn_stack_ggnn_varmisuse_global", x=x, y=out.output_node_representations,
+         node_to_graph_idx=node_to_graph, **pack_adj(adj), **pack_specs(specs))
+
+
 class _NodeModel(AbstractNeuralModel):
     """Minimal node 'embedder' model: a node is an int id, the minibatch is the id list."""
 
@@ -256,4 +288,5 @@ if __name__ == "__main__":
     torch.set_num_threads(1)
     single_layers()
     containers()
+    varmisuse_ggnn()
     batcher()

@@ -59,6 +59,22 @@ def stack_from_specs(specs):
             if id(spec) not in built:
                 built[id(spec)] = layer_from_spec(spec)
             mods.append(built[id(spec)])
+        elif k == "global_gru":
+            from ptgnn_amd import reduceops as R
+            H = spec["w_hh"].shape[1]
+            D = spec["w_ih"].shape[1]
+            pool = (R.WeightedSumVarSizedElementReduce(H) if spec["pool"] == "weighted_sum"
+                    else R.SimpleVarSizedElementReduce(spec["pool"]))
+            lay = R.GruGlobalStateUpdate(pool, H, D)
+            sd = lay.state_dict()
+            p = "_GruGlobalStateUpdate__gru_cell."
+            sd[p + "weight_ih"], sd[p + "weight_hh"] = spec["w_ih"], spec["w_hh"]
+            sd[p + "bias_ih"], sd[p + "bias_hh"] = spec["b_ih"], spec["b_hh"]
+            if spec["pool"] == "weighted_sum":
+                key = [k2 for k2 in sd if k2.endswith("weights_layer.weight")][0]
+                sd[key] = spec["pool_w"]
+            lay.load_state_dict(sd)
+            mods.append(lay)
         elif k == "residual_origin":
             mods.append(("origin", spec["name"], len(mods)))
         elif k in ("residual_concat", "residual_mean"):

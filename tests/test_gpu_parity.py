@@ -619,3 +619,46 @@ def test_hub_path_is_deterministic_and_skipped_when_not_needed():
     assert not small.may_have_hubs()            # cannot contain a hub: no chunk workgroups, no workspace
     # the ticket counters are left zero by every launch
     assert int(plan.hub_tickets(M).abs().sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# VarMisuse GGNN stack with global graph exchange
+# ------------------------------------------------------------------------------------------------
+def test_varmisuse_ggnn_stack_with_global_exchange_matches_reference_golden():
+    from oracle.fixtures import unpack_adj, unpack_specs
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    g = load_golden("gnn_stack_ggnn_varmisuse_global")
+    adj, specs = unpack_adj(g), unpack_specs(g)
+    net = GraphNeuralNetwork(stack_from_specs(specs), torch.nn.Identity(), introduce_backwards_edges=True,
+                             add_self_edges=True).cuda().eval()
+    x = torch.from_numpy(g["x"]).cuda()
+    n2g = torch.from_numpy(g["node_to_graph_idx"]).cuda()
+    with torch.no_grad():
+        out = net(node_data={"input": x}, adjacency_lists=to_cuda_adj(adj), edge_feature_data=[],
+                  node_to_graph_idx=n2g, reference_node_ids={}, reference_node_graph_idx={}, num_graphs=3)
+    np.testing.assert_allclose(out.output_node_representations.cpu().numpy(), g["y"], rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("pool", ["sum", "mean", "max", "weighted"])
+def test_pooling_over_sorted_index_matches_oracle(pool):
+    from oracle import scatter_ref
+    from ptgnn_amd import reduceops as R
+    g = torch.Generator().manual_seed(2)
+    sizes = torch.tensor([5000, 1, 0, 9000, 300])          # includes an empty graph and a long one
+    idx = torch.repeat_interleave(torch.arange(5), sizes)
+    x = torch.randn(int(sizes.sum()), 64, generator=g)
+    e = R.ElementsToSummaryRepresentationInput(x.cuda(), idx.cuda(), 5)
+    if pool == "weighted":
+        mod = R.WeightedSumVarSizedElementReduce(64).cuda()
+        w = mod.state_dict()["_WeightedSumVarSizedElementReduce__weights_layer.weight"].cpu()
+        want = scatter_ref.scatter((x * torch.sigmoid(x @ w.t())).double(), idx, dim=0, dim_size=5, reduce="sum")
+    else:
+        mod = R.SimpleVarSizedElementReduce(pool).cuda()
+        want = scatter_ref.scatter(x.double(), idx, dim=0, dim_size=5, reduce=pool)
+    with torch.no_grad():
+        got = mod(e).cpu()
+    if pool == "max":
+        np.testing.assert_array_equal(got.numpy(), want.float().numpy())
+    else:
+        np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=2e-5, atol=2e-4)
+    assert float(got[2].abs().sum()) == 0.0                # empty graph -> 0

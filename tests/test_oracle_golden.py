@@ -39,6 +39,15 @@ def test_container_matches_reference(name, bwd, selfe):
     np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=1e-5)
 
 
+def test_varmisuse_ggnn_stack_with_global_exchange_matches_reference():
+    g = load_golden("gnn_stack_ggnn_varmisuse_global")
+    adj, specs = unpack_adj(g), unpack_specs(g)
+    x = torch.from_numpy(g["x"])
+    n2g = torch.from_numpy(g["node_to_graph_idx"])
+    y, _ = O.gnn_forward(x, adj, specs, True, True, node_to_graph_idx=n2g)
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=1e-5)
+
+
 def test_augmentation_order():
     a = [(torch.tensor([0, 1]), torch.tensor([1, 2])), (torch.tensor([2]), torch.tensor([0]))]
     aug = O.augment_adjacency(a, 3, True, True)
