@@ -137,6 +137,54 @@ def make_cfg3(dev):
                     "(incl. reverse+self), Typilus GGNN arch: 8 GGNN layers H=128 (+concat residual), max"}
 
 
+def train_cfg3(dev, dropout, steps=6, warmup=2):
+    """Training step (forward + backward + Adam) of the same Graph2Class-style stack with a linear
+    classification head on the `supernodes` references -- the quantity README.md:15-17 quotes
+    (1.13 M edges/s on a V100).  dropout = 0.1 is the shipped Typilus setting (per-edge dropout =>
+    general per-edge path); dropout = 0 uses the table path with the HIP aggregation both ways."""
+    from ptgnn_amd import layers as L, ops, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    H, T = 128, 17
+    mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234)
+    torch.manual_seed(1234)
+    ggnn = L.GatedMessagePassingLayer(H, H, T, "max", dropout_rate=dropout)
+    r1 = L.ConcatResidualLayer(H)
+    last = L.GatedMessagePassingLayer(2 * H, H, T, "max", dropout_rate=dropout)
+    net = GraphNeuralNetwork([r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last], torch.nn.Identity(),
+                             True, True).to(dev).train()
+    N = mb["num_nodes"]
+    E = 2 * sum(int(a[0].shape[0]) for a in mb["adjacency_lists"]) + N
+    x = workloads.node_states(N, H, seed=5).to(dev)
+    adj = [(s.to(dev), d.to(dev)) for s, d in mb["adjacency_lists"]]
+    n2g = mb["node_to_graph_idx"].to(dev)
+    refs = {k: v.to(dev) for k, v in mb["reference_node_ids"].items()}
+    refg = {k: v.to(dev) for k, v in mb["reference_node_graph_idx"].items()}
+    head = torch.nn.Linear(2 * H, 100).to(dev)
+    opt = torch.optim.Adam(list(net.parameters()) + list(head.parameters()), lr=1e-4)
+    target = torch.randint(0, 100, (refs["supernodes"].shape[0],), device=dev)
+
+    def step():
+        ops.clear_plan_cache()
+        opt.zero_grad(set_to_none=True)
+        out = net(node_data={"input": x}, adjacency_lists=adj, edge_feature_data=[], node_to_graph_idx=n2g,
+                  reference_node_ids=refs, reference_node_graph_idx=refg, num_graphs=mb["num_graphs"])
+        logits = head(out.output_node_representations[out.node_idx_references["supernodes"]])
+        torch.nn.functional.cross_entropy(logits, target).backward()
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"dropout": dropout, "ms_per_train_step": round(dt * 1e3, 3),
+            "edges_per_sec_readme_convention": round(E / dt, 1), "graphs_per_sec": round(mb["num_graphs"] / dt, 1),
+            "vs_readme_v100_training_1129k": round(E / dt / 1.129e6, 2)}
+
+
 def step_cfg3(st):
     from ptgnn_amd import ops
     ops.clear_plan_cache()
@@ -272,6 +320,9 @@ def main():
                 "vs_readme_v100_inference_2527k": round(st3["E"] / (sec3 / k3) / 2.527e6, 2),
                 "kernels": kernel_table(sum3)}
             del st3
+            torch.cuda.empty_cache()
+            result["graph2class_train"] = [train_cfg3(dev, 0.0), train_cfg3(dev, 0.1)]
+            torch.cuda.empty_cache()
         if args.workload == "cfg2" and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_cfg2(st)
     if world > 1 or args.force_sharded:
