@@ -43,6 +43,9 @@ def parse():
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--force-sharded", action="store_true",
                    help="run the dst-range-sharded code path (process group, halo all-to-all) even at N=1")
+    p.add_argument("--cut-edges", action="store_true",
+                   help="N>1: ONE random graph over all ranks ((N-1)/N of the edges cut, halo all-to-all per "
+                        "layer) instead of the default disjoint union of per-rank graphs")
     return p.parse_args()
 
 
@@ -83,7 +86,7 @@ def max_over_ranks(seconds, world, dev):
 # ------------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------------
-def make_cfg2(dev, rank, world, force_sharded=False):
+def make_cfg2(dev, rank, world, force_sharded=False, cut_edges=False):
     """configs[1]; for world > 1 every rank owns its own 200k-node destination range."""
     from ptgnn_amd import layers as L, workloads
     N, E, H = 200_000, 1_100_000, 128
@@ -95,9 +98,14 @@ def make_cfg2(dev, rank, world, force_sharded=False):
         state = {"adj": [(s.to(dev), d.to(dev)) for s, d in adj], "x": x.to(dev), "cpu_adj": adj, "cpu_x": x}
     else:
         from ptgnn_amd import sharded
-        state = sharded.make_weak_scaling_shard(N, E, H, rank, world, dev, seed=1234)
-    state.update(layer=layer, N=N, E=E, H=H, layers_per_step=1,
-                 desc="cfg2: synthetic random graph N=200k E=1.1M, 1 MLP-MP layer H=M=128, T=1, sum")
+        state = sharded.make_weak_scaling_shard(N, E, H, rank, world, dev, seed=1234, cut_edges=cut_edges)
+        state["cut_edges"] = cut_edges
+    desc = "cfg2: synthetic random graph N=200k E=1.1M, 1 MLP-MP layer H=M=128, T=1, sum"
+    if "adj" not in state:
+        desc += (f" per GPU; one graph of {world} x 200k nodes, sources uniform over all ranks "
+                 f"({world - 1}/{world} of the edges cut)" if cut_edges else
+                 f" per GPU; disjoint union of {world} such graphs, dst-range partition on graph boundaries")
+    state.update(layer=layer, N=N, E=E, H=H, layers_per_step=1, desc=desc)
     return state
 
 
@@ -275,7 +283,7 @@ def main():
     _lib.load()
 
     if args.workload == "cfg2":
-        st = make_cfg2(dev, rank, world, args.force_sharded)
+        st = make_cfg2(dev, rank, world, args.force_sharded, args.cut_edges)
         step = lambda: step_cfg2(st, world)  # noqa: E731
     else:
         if world > 1:
@@ -301,12 +309,23 @@ def main():
         "config": {"workload": st["desc"], "nodes_per_gpu": st["N"], "edges_per_gpu": st["E"],
                    "hidden": st["H"], "mp_layers_per_step": layers, "mode": "forward (inference), fp32",
                    "plan_build_in_step": True,
-                   "parallelism": "single GPU" if "adj" in st else f"dst-range shard x{world} + halo all-to-all"},
+                   "parallelism": "single GPU" if "adj" in st else (
+                       f"dst-range shard x{world} + halo all-to-all per layer" if st.get("cut_edges") else
+                       f"dst-range shard x{world} on graph boundaries (no cut edges => no data-path collective)")},
         "nodes_per_sec_per_layer": round(st["N"] * world / (seconds / args.steps / layers), 1),
         "edges_per_sec_readme_convention": round(edges_all_ranks / (seconds / args.steps), 1),
         "roofline": roof, "kernels": ktab,
     }
 
+    if world > 1 and args.workload == "cfg2" and not args.cut_edges and not args.no_secondary:
+        # the same weak-scaling shard with cut edges: exercises the RCCL halo all-to-all every layer
+        st_cut = make_cfg2(dev, rank, world, True, True)
+        k2 = max(5, args.steps // 2)
+        sec_cut, _ = timed_region(lambda: step_cfg2(st_cut, world), k2, 2, world, dev)
+        result["cut_edges_variant"] = {
+            "workload": st_cut["desc"], "ms_per_step": round(sec_cut / k2 * 1e3, 4),
+            "edges_per_sec_per_layer": round(st_cut["E"] * world / (sec_cut / k2), 1)}
+        del st_cut
     if rank == 0 and world == 1 and not args.force_sharded:
         if args.workload == "cfg2" and not args.no_secondary:
             st3 = make_cfg3(dev)

@@ -53,6 +53,7 @@ class ShardedGraph:
         self.lo = self.hi = 0
         self.n_local = self.n_halo = 0
         self.bounds: Optional[torch.Tensor] = None       # int64 [world + 1] on device
+        self.bounds_host: List[int] = []
         self.need_ids: Optional[torch.Tensor] = None      # global ids of halo rows, sorted
         self.send_ids: Optional[torch.Tensor] = None      # local row ids to send, grouped by peer
         self.send_splits: List[int] = []
@@ -60,60 +61,92 @@ class ShardedGraph:
         self.local_adj: Adj = []
         self.plan: Optional["ops.GraphPlan"] = None
         self.group = None
+        self.no_cut = False    # True when NO rank has a remote source: the exchange is skipped entirely
 
     # -- construction ---------------------------------------------------------------------------
     @staticmethod
     def build(adjacency_lists: Adj, node_range: Tuple[int, int], group=None,
-              build_plan: bool = True) -> "ShardedGraph":
+              build_plan: bool = True, all_ranges: Optional[Sequence[Tuple[int, int]]] = None
+              ) -> "ShardedGraph":
         """adjacency_lists: int64 (src, dst) per edge type in GLOBAL node ids, holding exactly the
-        edges whose dst lies in this rank's `node_range`."""
+        edges whose dst lies in this rank's `node_range`.  `all_ranges` (every rank's range, in rank
+        order) skips the all-gather when the partition is static."""
         g = ShardedGraph()
         g.group = group
         g.rank, g.world = dist.get_rank(group), dist.get_world_size(group)
         g.lo, g.hi = int(node_range[0]), int(node_range[1])
         g.n_local = g.hi - g.lo
         dev = adjacency_lists[0][0].device
-        # every rank learns all range boundaries
-        mine = torch.tensor([g.lo, g.hi], dtype=torch.int64, device=dev)
-        allr = [torch.empty_like(mine) for _ in range(g.world)]
-        dist.all_gather(allr, mine, group=group)
-        los = torch.stack([r[0] for r in allr])
-        his = torch.stack([r[1] for r in allr])
-        if not bool((los[1:] == his[:-1]).all()) :
-            raise ValueError("node ranges must be contiguous and ordered by rank")
-        g.bounds = torch.cat([los, his[-1:]])
+        if all_ranges is None:   # every rank learns all range boundaries
+            mine = torch.tensor([g.lo, g.hi], dtype=torch.int64, device=dev)
+            allr = [torch.empty_like(mine) for _ in range(g.world)]
+            dist.all_gather(allr, mine, group=group)
+            all_ranges = torch.stack(allr).tolist()
+        g.set_bounds(all_ranges, dev)
 
+        # One tiny collective decides whether this minibatch has ANY cut edge.  A disjoint-union batch
+        # partitioned on graph boundaries (graphneuralnetwork.py:418-423 keeps a graph's node ids
+        # contiguous) has none: every rank then runs the single-GPU path with no data-path collective
+        # and skips the halo bookkeeping altogether.
+        flag = torch.zeros(1, dtype=torch.int64, device=dev)
+        for s_, _ in adjacency_lists:
+            if s_.numel():
+                lo_s, hi_s = torch.aminmax(s_)
+                flag += ((lo_s < g.lo) | (hi_s >= g.hi)).to(torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()) == 0:
+            g.no_cut = True
+            g.n_halo = 0
+            g.need_ids = torch.zeros(0, dtype=torch.int64, device=dev)
+            g.send_ids = g.need_ids
+            g.send_splits = [0] * g.world
+            g.recv_splits = [0] * g.world
+            g.local_adj = [((s_ - g.lo), (d_ - g.lo)) for s_, d_ in adjacency_lists]
+            if build_plan:
+                g.build_plan()
+            return g
         g.index_locally(adjacency_lists)
-        got_counts = torch.empty(g.world, dtype=torch.int64, device=dev)
         need_counts = torch.tensor(g.recv_splits, dtype=torch.int64, device=dev)
+        got_counts = torch.empty_like(need_counts)
         dist.all_to_all_single(got_counts, need_counts, group=group)
         g.send_splits = [int(v) for v in got_counts.tolist()]        # rows I send per peer
         wanted = torch.empty(sum(g.send_splits), dtype=torch.int64, device=dev)
         dist.all_to_all_single(wanted, g.need_ids, g.send_splits, g.recv_splits, group=group)
-        if wanted.numel() and (int(wanted.min()) < g.lo or int(wanted.max()) >= g.hi):
-            raise RuntimeError("a peer requested rows this rank does not own")
-        g.send_ids = wanted - g.lo
+        g.send_ids = wanted - g.lo                                    # owners trust their peers' requests
         if build_plan:
             g.build_plan()
         return g
+
+    def set_bounds(self, all_ranges, device) -> None:
+        los = [int(r[0]) for r in all_ranges]
+        his = [int(r[1]) for r in all_ranges]
+        if any(a != b for a, b in zip(los[1:], his[:-1])) or (los[self.rank], his[self.rank]) != (self.lo, self.hi):
+            raise ValueError("node ranges must be contiguous, ordered by rank and contain this rank's range")
+        self.bounds_host = los + [his[-1]]
+        self.bounds = torch.tensor(self.bounds_host, dtype=torch.int64, device=device)
 
     def index_locally(self, adjacency_lists: Adj) -> None:
         """The collective-free part of `build`: which halo rows this rank needs (de-duplicated, sorted,
         hence grouped by owner because the ranges are ordered) and the remapping of edge endpoints
         into the local table [own rows | halo rows]."""
         dev = adjacency_lists[0][0].device
-        srcs = [a[0] for a in adjacency_lists]
-        all_src = torch.cat(srcs) if srcs else torch.zeros(0, dtype=torch.int64, device=dev)
-        remote = (all_src < self.lo) | (all_src >= self.hi)
-        self.need_ids = torch.unique(all_src[remote], sorted=True)
-        self.n_halo = int(self.need_ids.shape[0])
-        edges = torch.searchsorted(self.need_ids, self.bounds)       # [world + 1] positions
-        self.recv_splits = [int(v) for v in (edges[1:] - edges[:-1]).tolist()]  # rows I receive per peer
+        total = self.bounds_host[-1]            # global node count
+        # mark-and-compact over the global id space: sorted unique remote ids without a sort
+        mark = torch.zeros(total + 1, dtype=torch.int32, device=dev)
+        for s, _ in adjacency_lists:
+            mark.index_fill_(0, s, 1)
+        mark[self.lo:self.hi] = 0               # own rows are not halo rows
+        mark[total] = 0
+        slot = torch.cumsum(mark, 0, dtype=torch.int64) - mark      # halo slot of every marked id
+        per_owner = [0] + slot[self.bounds[1:]].tolist()           # marked ids below each upper bound (1 sync)
+        self.recv_splits = [b - a for a, b in zip(per_owner[:-1], per_owner[1:])]
+        self.n_halo = per_owner[-1]
+        self.need_ids = (torch.nonzero(mark, as_tuple=False).flatten() if self.n_halo
+                         else torch.zeros(0, dtype=torch.int64, device=dev))
         self.local_adj = []
         for s, d in adjacency_lists:
             rem = (s < self.lo) | (s >= self.hi)
-            pos = torch.searchsorted(self.need_ids, s) if self.n_halo else torch.zeros_like(s)
-            ls = torch.where(rem, pos + self.n_local, s - self.lo)
+            ls = torch.where(rem, slot[s] + self.n_local, s - self.lo)
             self.local_adj.append((ls.contiguous(), (d - self.lo).contiguous()))
 
     def build_plan(self) -> None:
@@ -148,23 +181,34 @@ class ShardedGraph:
 # bench / test helpers
 # ------------------------------------------------------------------------------------------------
 def make_weak_scaling_shard(nodes_per_rank: int, edges_per_rank: int, hidden: int, rank: int,
-                            world: int, device, seed: int = 1234) -> Dict:
-    """Weak-scaling version of BASELINE config 2: ONE random graph of world * N nodes; rank p owns
-    nodes [p N, (p+1) N) and their E in-edges, whose sources are uniform over ALL world * N nodes
-    (so (world-1)/world of the edges are cut)."""
+                            world: int, device, seed: int = 1234, cut_edges: bool = False) -> Dict:
+    """Weak-scaling version of BASELINE config 2.  Rank p owns nodes [p N, (p+1) N) and their E
+    in-edges of one batched graph of world * N nodes.
+      cut_edges=False: a disjoint union of `world` random graphs partitioned on graph boundaries (the
+                       shape of ptgnn's minibatches) -- no edge crosses a rank;
+      cut_edges=True : ONE random graph, sources uniform over all world * N nodes, so (world-1)/world
+                       of the edges are cut and every layer exchanges halo rows."""
     g = torch.Generator().manual_seed(seed + 7919 * rank)
     lo = rank * nodes_per_rank
-    src = torch.randint(0, world * nodes_per_rank, (edges_per_rank,), generator=g, dtype=torch.int64)
+    if cut_edges:
+        src = torch.randint(0, world * nodes_per_rank, (edges_per_rank,), generator=g, dtype=torch.int64)
+    else:
+        src = torch.randint(0, nodes_per_rank, (edges_per_rank,), generator=g, dtype=torch.int64) + lo
     dst = torch.randint(0, nodes_per_rank, (edges_per_rank,), generator=g, dtype=torch.int64) + lo
     x = torch.randn(nodes_per_rank, hidden, generator=g, dtype=torch.float32)
     adj = [(src.to(device), dst.to(device))]
-    return {"adj_global": adj, "range": (lo, lo + nodes_per_rank), "x": x.to(device)}
+    return {"adj_global": adj, "range": (lo, lo + nodes_per_rank), "x": x.to(device),
+            "all_ranges": [(p * nodes_per_rank, (p + 1) * nodes_per_rank) for p in range(world)]}
 
 
 def layer_forward(layer, state: Dict) -> torch.Tensor:
     """One sharded message-passing layer: (re)build the shard plan for the minibatch, exchange halo
     rows, aggregate, update.  Nothing is cached across calls (bench.py times the whole thing)."""
-    shard = ShardedGraph.build(state["adj_global"], state["range"])
+    shard = ShardedGraph.build(state["adj_global"], state["range"], build_plan=False,
+                               all_ranges=state.get("all_ranges"))
+    if shard.no_cut:   # no edge crosses a rank boundary: exactly the single-GPU layer on the local block
+        return layer(state["x"], shard.local_adj, None, {}, {}, [None] * len(shard.local_adj))
+    shard.build_plan()
     return layer.forward_sharded(state["x"], shard)
 
 

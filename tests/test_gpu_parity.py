@@ -376,11 +376,11 @@ def _virtual_shards(adj, n, world):
     for _, d in adj:
         indeg += torch.bincount(d, minlength=n)
     ranges = sharded.balanced_node_ranges(indeg, world)
-    bounds = torch.tensor([r[0] for r in ranges] + [ranges[-1][1]], dtype=torch.int64).cuda()
     shards = []
     for p, (lo, hi) in enumerate(ranges):
         g = sharded.ShardedGraph()
-        g.rank, g.world, g.lo, g.hi, g.n_local, g.bounds = p, world, lo, hi, hi - lo, bounds
+        g.rank, g.world, g.lo, g.hi, g.n_local = p, world, lo, hi, hi - lo
+        g.set_bounds(ranges, "cuda")
         g.index_locally([(s[(d >= lo) & (d < hi)].cuda(), d[(d >= lo) & (d < hi)].cuda()) for s, d in adj])
         g.build_plan()
         shards.append(g)

@@ -90,6 +90,42 @@ def test_sharded_matches_unsharded(world, reduce):
     assert all(r[3] > 0 for r in results)   # a random graph always has cut edges
 
 
+def _worker_nocut(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ptgnn_amd import sharded
+        st = sharded.make_weak_scaling_shard(500, 3000, 8, rank, world, "cpu", seed=5, cut_edges=False)
+        sh = sharded.ShardedGraph.build(st["adj_global"], st["range"], build_plan=False,
+                                        all_ranges=st["all_ranges"])
+        assert sh.no_cut and sh.n_halo == 0 and sum(sh.send_splits) == 0
+        lo = st["range"][0]
+        assert torch.equal(sh.local_adj[0][0], st["adj_global"][0][0] - lo)
+        st2 = sharded.make_weak_scaling_shard(500, 3000, 8, rank, world, "cpu", seed=5, cut_edges=True)
+        sh2 = sharded.ShardedGraph.build(st2["adj_global"], st2["range"], build_plan=False)
+        assert not sh2.no_cut and sh2.n_halo > 0 and sum(sh2.send_splits) > 0
+        out_q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        out_q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_disjoint_union_partition_needs_no_exchange():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_nocut, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert r[1] == "ok", r[1]
+
+
 def test_balanced_ranges_follow_edge_mass():
     from ptgnn_amd import sharded
     deg = torch.zeros(1000, dtype=torch.int64)
