@@ -247,9 +247,31 @@ def kernel_table(summary):
             gbs = d["bytes"] / d["calls"] / (ms * 1e-3) / 1e9
             row.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                        frac=round(gbs / HBM_PEAK_GBS, 4))
+        row["algorithmic_bytes_per_launch"] = round(d["bytes"] / d["calls"])
         row["total_ms"] = round(d["ms"], 4)
         table[name] = row
     return table
+
+
+PMC_KERNEL = {"linear": "k_linear_tlp", "gather_reduce": "k_gather_reduce", "gru_cell": "k_gru",
+              "edge_linear": "k_edge_linear"}
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
+    (profiles/r01_<workload>_traffic.json, written by scripts/gpu_profile.sh + summarize_prof.py:
+    FETCH_SIZE x2 wide-read correction + WRITE_SIZE, separate --pmc runs).  PMC counters cannot be read
+    from inside a plain bench run, so the figure is the profiled one and names its source; null when the
+    profile is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_{workload}_traffic.json")
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+        row = prof["kernels"][PMC_KERNEL[kernel]]
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+    return {"traffic": row["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
+            "traffic_source": f"profiles/r01_{workload}_traffic.json ({prof['source']})"}
 
 
 def cpu_baseline_cfg2(st):
@@ -298,8 +320,10 @@ def main():
     value = edges_all_ranks / (seconds / args.steps / layers)
     ktab = kernel_table(summary)
     dominant = max(ktab, key=lambda k: ktab[k]["total_ms"])
-    roof = {k: ktab[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
-    roof.update(kernel=dominant, avg_ms=ktab[dominant]["avg_ms"], traffic=None)
+    roof = {k: ktab[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac",
+                                           "algorithmic_bytes_per_launch")}
+    roof.update(kernel=dominant, avg_ms=ktab[dominant]["avg_ms"])
+    roof.update(pmc_traffic(args.workload, dominant))
 
     result = {
         "metric": "edges/sec per MP layer", "value": round(value, 1), "unit": "edges/s",
