@@ -198,6 +198,60 @@ int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int32_t state_dim,
                               int64_t ld_msg, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training variants of the per-edge message GEMM (GGNN, gatedmessagepassing.py:57-61:
+ * `edge_transformation_layer(self.__dropout(cat([edge_source_states, features])))`).
+ *
+ * ptgnn_amd_edge_linear_dropout_f32: as ptgnn_amd_edge_linear_f32 (no target-state half, no
+ * activation) with nn.Dropout(p) folded in.  The keep mask is a counter-based hash of
+ * (dropout_seed, global message row, forward input column) -- see ptgnn_amd/csrc/dense_common.h --
+ * so no [E, H] mask tensor exists and the backward kernels regenerate it:
+ *   dropout_mode 1: mask the gathered INPUT rows        msg = (mask * x[src] / (1-p)) W_t^T   (forward)
+ *   dropout_mode 2: mask the OUTPUT rows                out = (x[src] W_t^T) * mask / (1-p)
+ *                   (backward w.r.t. the gathered input: x = d_msg, src = identity index,
+ *                    w_per_type = W_t^T [state_dim_fwd, msg_dim_fwd]; here msg_dim = forward state_dim)
+ *   dropout_mode 0 or dropout_p == 0: plain ptgnn_amd_edge_linear_f32.
+ * The mask is Bernoulli(1 - p') per element with p' = round(p * 65536) / 65536.
+ * ---------------------------------------------------------------------------------------- */
+int ptgnn_amd_edge_linear_dropout_f32(const float *x, int64_t ld_x, int32_t state_dim,
+                                      const int64_t *const *src_per_type,
+                                      const int64_t *edges_per_type, const float *const *w_per_type,
+                                      int32_t num_types, int32_t msg_dim, float *msg, int64_t ld_msg,
+                                      int dropout_mode, float dropout_p, uint64_t dropout_seed,
+                                      void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight gradient of the per-edge message Linear for every edge type in one call (autograd of the
+ * nn.Linear at gatedmessagepassing.py:20-23,57-61 / the MLP output layer at mlpmessagepassing.py:96-98):
+ *   grad_w[t, m, k] = sum_{e < E_t} grad_msg[off_t + e, m] * in_t[e, k],
+ *   in_t[e, :] = [ x[src_t[e], :] ; x[dst_t[e], :] (if dst_per_type) ]  (* dropout mask if dropout_p > 0)
+ *   grad_w: [num_types, msg_dim, in_dim] contiguous, in_dim = state_dim * (dst ? 2 : 1); types without
+ *           edges get zeros.  Deterministic: chunk partials on fp32 MFMA, then an ordered reduction.
+ *   workspace: ptgnn_amd_edge_wgrad_workspace_bytes(total edges, num_types, msg_dim, in_dim) bytes.
+ * Requires state_dim % 4 == 0, msg_dim % 4 == 0, 16-byte aligned rows (else EUNSUPPORTED).
+ * ---------------------------------------------------------------------------------------- */
+size_t ptgnn_amd_edge_wgrad_workspace_bytes(int64_t num_edges, int32_t num_types, int32_t msg_dim,
+                                            int32_t in_dim);
+int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int32_t state_dim,
+                                   const int64_t *const *src_per_type,
+                                   const int64_t *const *dst_per_type /* nullable */,
+                                   const int64_t *edges_per_type, const float *grad_msg,
+                                   int64_t ld_grad_msg, int32_t num_types, int32_t msg_dim,
+                                   float dropout_p, uint64_t dropout_seed, float *grad_w,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of the segment reduce w.r.t. the message matrix (the autograd torch_scatter supplies
+ * behind abstractmessagepassing.py:44-50):
+ *   out[perm[s], :] = grad[slot_row[s], :]                                   sum / mean (pre-scaled)
+ *   out[perm[s], c] = arg[slot_row[s], c] == s ? grad[slot_row[s], c] : 0    max / min
+ *   slot_row int32 [num_slots]: destination row of CSR slot s (rowptr expanded); arg: the argout of
+ *   ptgnn_amd_gather_reduce_f32 ([num_rows, dim], nullable); out [num_slots, dim] message order.
+ * ---------------------------------------------------------------------------------------- */
+int ptgnn_amd_segment_spread_f32(const float *grad, int64_t ld_grad, const int32_t *arg /* nullable */,
+                                 const int32_t *slot_row, const int32_t *perm, int64_t num_slots,
+                                 int32_t dim, float *out, int64_t ld_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * h' = GRUCell(a, h)  (gate order r, z, n), gatedmessagepassing.py:25,69.
  *   a [n, m], h [n, hd], w_ih [3hd, m], w_hh [3hd, hd], b_ih/b_hh [3hd], out [n, hd].
  *   Gate GEMMs run on fp32 MFMA with the gate non-linearities fused in the epilogue; no

@@ -11,7 +11,7 @@ constexpr int BK = 32;
 constexpr int LDS_LD = BK + 1;
 
 // Stage a [ROWS x 32] K-chunk of a row-major matrix through registers into LDS, one float4 "part"
-// at a time so the traffic can be threaded between MFMAs.  RowMap maps tile row -> matrix row and
+// at a time so the traffic can be threaded between MFMAs.  RowMap maps (tile row, part) -> matrix row and
 // CLAMPS it into range: out-of-range tile rows read some valid row instead of being predicated,
 // because a branch around a load makes hipcc's waitcnt pass fall back to vmcnt(0) drains.  Such
 // rows only feed output rows/columns that are never stored.  The K tail must be exact, so chunk
@@ -26,7 +26,7 @@ struct Stager {
                                             RowMap rm, int r) {
     const int f = threadIdx.x + r * 256;
     const int row = f >> 3, c4 = (f & 7) * 4;
-    const int64_t mrow = rm(row);
+    const int64_t mrow = rm(row, r);
     const int kk = k0 + c4;
     kvalid = K - kk;
     if (ALIGNED) {
@@ -67,7 +67,7 @@ struct Stager {
 
 struct RowClamp {  // plain matrices: tile row -> min(base_row + row, limit - 1)
   int64_t base, limit;
-  __device__ __forceinline__ int64_t operator()(int row) const {
+  __device__ __forceinline__ int64_t operator()(int row, int /*part*/) const {
     const int64_t r = base + row;
     return r < limit ? r : limit - 1;
   }
@@ -75,7 +75,7 @@ struct RowClamp {  // plain matrices: tile row -> min(base_row + row, limit - 1)
 
 struct GateRows {  // GRU weights: tile row (gate*32 + jj) -> gate*H + min(j0 + jj, H - 1)
   int j0, H;
-  __device__ __forceinline__ int64_t operator()(int row) const {
+  __device__ __forceinline__ int64_t operator()(int row, int /*part*/) const {
     const int gate = row >> 5, j = j0 + (row & 31);
     return (int64_t)gate * H + (j < H ? j : H - 1);
   }
@@ -94,6 +94,49 @@ __device__ __forceinline__ float act_apply(float v) {
   if constexpr (ACT == PTGNN_AMD_ACT_TANH) return tanhf(v);
   if constexpr (ACT == PTGNN_AMD_ACT_RELU) return v > 0.f ? v : 0.f;
   return v;
+}
+
+// Per-edge dropout of the GGNN message input (gatedmessagepassing.py:57-61: Linear(Dropout([x_src ; f_e]))).
+// The keep mask is a counter-based hash of (seed, message row, input column), so forward, the input
+// gradient and the weight gradient regenerate the SAME mask without an [E, H] mask tensor in HBM.
+// One 32-bit hash serves a column pair: bits 0-15 decide the even column, bits 16-31 the odd one;
+// an element is kept when its 16 bits >= thr = round(p * 65536), and kept values are scaled by
+// 1 / (1 - p) like nn.Dropout.  tests/helpers.py restates this in numpy for the parity tests.
+struct DropoutParams {
+  uint64_t seed;
+  uint32_t thr;        // 0 => dropout off
+  float scale;
+  int32_t half_width;  // (forward input width) / 2
+};
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+  return x;
+}
+
+__device__ __forceinline__ uint32_t dropout_bits(const DropoutParams &d, int64_t row, int col_pair) {
+  const uint64_t idx = (uint64_t)row * (uint64_t)d.half_width + (uint64_t)col_pair;
+  uint32_t h = mix32((uint32_t)idx ^ (uint32_t)d.seed);
+  return mix32(h + (uint32_t)(idx >> 32) * 0x9e3779b9u + (uint32_t)(d.seed >> 32));
+}
+
+// v = 4 consecutive columns starting at the (multiple-of-4) column `col` of message row `row`
+__device__ __forceinline__ float4 dropout_apply4(const DropoutParams &d, int64_t row, int col, float4 v) {
+  const uint32_t b0 = dropout_bits(d, row, col >> 1), b1 = dropout_bits(d, row, (col >> 1) + 1);
+  v.x = (b0 & 0xffffu) >= d.thr ? v.x * d.scale : 0.f;
+  v.y = (b0 >> 16) >= d.thr ? v.y * d.scale : 0.f;
+  v.z = (b1 & 0xffffu) >= d.thr ? v.z * d.scale : 0.f;
+  v.w = (b1 >> 16) >= d.thr ? v.w * d.scale : 0.f;
+  return v;
+}
+
+inline DropoutParams make_dropout(float p, uint64_t seed, int width) {
+  DropoutParams d;
+  d.seed = seed;
+  d.thr = p > 0.f ? (uint32_t)((double)p * 65536.0 + 0.5) : 0u;
+  d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  d.half_width = width / 2;
+  return d;
 }
 
 // Epilogue staging: a wave parks a 32 x 64 slab of its C fragments in LDS (row stride 68 floats:

@@ -36,13 +36,19 @@ struct EdgeTypeTable {
 
 struct GatherRows {  // tile row r -> node id of edge (e0 + r); rows past the type's end repeat its last edge
   int64_t idx[4];
-  __device__ __forceinline__ int64_t operator()(int row) const { return idx[row >> 5]; }
+  // indexed by the staging part (a compile-time constant after unrolling): `idx[row >> 5]` is a
+  // dynamic index to the compiler and put the array in scratch memory
+  __device__ __forceinline__ int64_t operator()(int /*row*/, int part) const { return idx[part]; }
 };
 
-template <int ACT, int NJ>
+// DROP: 0 none; 1 = dropout on the gathered input rows (training forward: W_t . Dropout(x_src));
+// 2 = dropout on the OUTPUT rows (training backward: d x_gathered = (d msg . W_t) * mask, with x = d msg
+// read through an identity index and w = W_t^T).  Both index the mask by (global message row, column
+// of the forward input), see DropoutParams.
+template <int ACT, int NJ, int DROP>
 __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
     EdgeTypeTable tab, const float *__restrict__ x, int64_t ld_x, int H, int use_dst, int n_out,
-    float *__restrict__ msg, int64_t ld_msg, int64_t msg_row_base, int col_tiles) {
+    float *__restrict__ msg, int64_t ld_msg, int64_t msg_row_base, int col_tiles, DropoutParams drop) {
   constexpr int BN = 64 * NJ;
   constexpr int B_FLOATS = BN * LDS_LD;
   constexpr int SLAB_LD = 32 * NJ + 4;
@@ -105,6 +111,12 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
   issue(0);
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();
+    if constexpr (DROP == 1) {   // mask this chunk's gathered rows in registers on their way into LDS
+      const int kcol = c * BK + (threadIdx.x & 7) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sa.v[r] = dropout_apply4(drop, out_row0 + (threadIdx.x >> 3) + r * 32, kcol, sa.v[r]);
+    }
     sa.store(As);
     sb.store(Bs);
     __syncthreads();
@@ -155,6 +167,8 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
         float4 o;
         o.x = act_apply<ACT>(v[it].x); o.y = act_apply<ACT>(v[it].y);
         o.z = act_apply<ACT>(v[it].z); o.w = act_apply<ACT>(v[it].w);
+        if constexpr (DROP == 2)
+          o = dropout_apply4(drop, out_row0 + wm * 64 + i * 32 + rsub + it * RPI, gcol, o);
         *reinterpret_cast<float4 *>(dst + (int64_t)it * RPI * ld_msg) = o;
       }
     }
@@ -175,6 +189,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
       float4 v = *reinterpret_cast<const float4 *>(slab + rl * SLAB_LD + c4);
       v.x = act_apply<ACT>(v.x); v.y = act_apply<ACT>(v.y);
       v.z = act_apply<ACT>(v.z); v.w = act_apply<ACT>(v.w);
+      if constexpr (DROP == 2) v = dropout_apply4(drop, out_row0 + trow, gcol < n_out ? gcol : 0, v);
       if (trow < rows_left && gcol < n_out)   // host guarantees n_out % 4 == 0 and 16-B aligned rows
         *reinterpret_cast<float4 *>(msg + (out_row0 + trow) * ld_msg + gcol) = v;
     }
@@ -187,18 +202,21 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
 
 using namespace ptgnn_amd;
 
-extern "C" int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int32_t state_dim,
-                                         const int64_t *const *src_per_type,
-                                         const int64_t *const *dst_per_type,
-                                         const int64_t *edges_per_type,
-                                         const float *const *w_per_type, int32_t num_types,
-                                         int32_t msg_dim, int act, float *msg, int64_t ld_msg,
-                                         void *stream_) {
+static int edge_linear_launch(const float *x, int64_t ld_x, int32_t state_dim,
+                              const int64_t *const *src_per_type, const int64_t *const *dst_per_type,
+                              const int64_t *edges_per_type, const float *const *w_per_type,
+                              int32_t num_types, int32_t msg_dim, int act, float *msg, int64_t ld_msg,
+                              int dropout_mode, float dropout_p, uint64_t dropout_seed, void *stream_) {
   PTGNN_REQUIRE(num_types >= 0 && state_dim > 0 && msg_dim > 0, PTGNN_AMD_EINVAL, "edge_linear: bad sizes");
   PTGNN_REQUIRE(act >= 0 && act <= PTGNN_AMD_ACT_RELU, PTGNN_AMD_EINVAL, "edge_linear: bad act");
   PTGNN_REQUIRE(state_dim % 32 == 0 && msg_dim % 4 == 0, PTGNN_AMD_EUNSUPPORTED,
                 "edge_linear: needs state_dim %% 32 == 0 and msg_dim %% 4 == 0 (got %d, %d)", state_dim,
                 msg_dim);
+  PTGNN_REQUIRE(dropout_mode >= 0 && dropout_mode <= 2 && dropout_p >= 0.f && dropout_p < 1.f,
+                PTGNN_AMD_EINVAL, "edge_linear: bad dropout mode / probability");
+  if (dropout_p == 0.f) dropout_mode = 0;
+  PTGNN_REQUIRE(dropout_mode == 0 || (act == PTGNN_AMD_ACT_NONE && dst_per_type == nullptr),
+                PTGNN_AMD_EUNSUPPORTED, "edge_linear: dropout needs act none and no target-state half");
   if (num_types == 0) return PTGNN_AMD_OK;
   PTGNN_REQUIRE(x && src_per_type && edges_per_type && w_per_type && msg, PTGNN_AMD_EINVAL,
                 "edge_linear: null pointer");
@@ -207,6 +225,8 @@ extern "C" int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int32_t s
   const int use_dst = dst_per_type != nullptr;
   const int nj = msg_dim <= 64 ? 1 : 2;
   const int col_tiles = (msg_dim + 64 * nj - 1) / (64 * nj);
+  // the mask is indexed by the column of the FORWARD input: the A operand in mode 1, the output in mode 2
+  const DropoutParams drop = make_dropout(dropout_p, dropout_seed, dropout_mode == 2 ? msg_dim : state_dim);
   hipStream_t st = (hipStream_t)stream_;
   int64_t row_base = 0;
   for (int t0 = 0; t0 < num_types; t0 += kMaxTypes) {
@@ -233,17 +253,21 @@ extern "C" int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int32_t s
     const int64_t total_tiles = (int64_t)tab.tile_off[tab.num_types] * col_tiles;
     if (total_tiles > 0) {
       const unsigned grid = (unsigned)xcd_padded_blocks(total_tiles);
-#define PTGNN_EDGE_LAUNCH(ACT, NJ)                                                               \
-  k_edge_linear<ACT, NJ><<<grid, 256, 0, st>>>(tab, x, ld_x, state_dim, use_dst, msg_dim, msg,   \
-                                               ld_msg, row_base, col_tiles)
-      if (nj == 1) {
-        if (act == PTGNN_AMD_ACT_TANH) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_TANH, 1);
-        else if (act == PTGNN_AMD_ACT_RELU) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_RELU, 1);
-        else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 1);
+#define PTGNN_EDGE_LAUNCH(ACT, NJ, DROP)                                                            \
+  k_edge_linear<ACT, NJ, DROP><<<grid, 256, 0, st>>>(tab, x, ld_x, state_dim, use_dst, msg_dim, msg, \
+                                                     ld_msg, row_base, col_tiles, drop)
+      if (dropout_mode == 1) {
+        if (nj == 1) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 1, 1); else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 2, 1);
+      } else if (dropout_mode == 2) {
+        if (nj == 1) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 1, 2); else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 2, 2);
+      } else if (nj == 1) {
+        if (act == PTGNN_AMD_ACT_TANH) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_TANH, 1, 0);
+        else if (act == PTGNN_AMD_ACT_RELU) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_RELU, 1, 0);
+        else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 1, 0);
       } else {
-        if (act == PTGNN_AMD_ACT_TANH) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_TANH, 2);
-        else if (act == PTGNN_AMD_ACT_RELU) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_RELU, 2);
-        else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 2);
+        if (act == PTGNN_AMD_ACT_TANH) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_TANH, 2, 0);
+        else if (act == PTGNN_AMD_ACT_RELU) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_RELU, 2, 0);
+        else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 2, 0);
       }
 #undef PTGNN_EDGE_LAUNCH
       PTGNN_LAUNCH_CHECK();
@@ -251,4 +275,27 @@ extern "C" int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int32_t s
     row_base += tab.edge_off[tab.num_types];
   }
   return PTGNN_AMD_OK;
+}
+
+extern "C" int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int32_t state_dim,
+                                         const int64_t *const *src_per_type,
+                                         const int64_t *const *dst_per_type,
+                                         const int64_t *edges_per_type,
+                                         const float *const *w_per_type, int32_t num_types,
+                                         int32_t msg_dim, int act, float *msg, int64_t ld_msg,
+                                         void *stream_) {
+  return edge_linear_launch(x, ld_x, state_dim, src_per_type, dst_per_type, edges_per_type, w_per_type,
+                            num_types, msg_dim, act, msg, ld_msg, 0, 0.f, 0, stream_);
+}
+
+extern "C" int ptgnn_amd_edge_linear_dropout_f32(const float *x, int64_t ld_x, int32_t state_dim,
+                                                 const int64_t *const *src_per_type,
+                                                 const int64_t *edges_per_type,
+                                                 const float *const *w_per_type, int32_t num_types,
+                                                 int32_t msg_dim, float *msg, int64_t ld_msg,
+                                                 int dropout_mode, float dropout_p,
+                                                 uint64_t dropout_seed, void *stream_) {
+  return edge_linear_launch(x, ld_x, state_dim, src_per_type, nullptr, edges_per_type, w_per_type,
+                            num_types, msg_dim, PTGNN_AMD_ACT_NONE, msg, ld_msg, dropout_mode, dropout_p,
+                            dropout_seed, stream_);
 }

@@ -1,0 +1,292 @@
+// Weight gradient of the per-edge message Linear, every edge type in one launch:
+//
+//     dW_t[m, k] = sum_{e < E_t}  d_msg[off_t + e, m] * in_t[e, k],
+//     in_t[e, :] = [ X[src_t[e], :] ; X[dst_t[e], :] (optional) ]   (optionally with the dropout mask
+//                                                                     of the forward, regenerated)
+//
+// i.e. the autograd of `edge_transformation_layer(...)` in gatedmessagepassing.py:57-61 /
+// mlpmessagepassing.py:96-98 for all T types, without materialising the gathered [E, K] input.
+//
+// It is a GEMM whose reduction dimension is the EDGE list (long) and whose output is tiny
+// ([M, K] per type), so the edge list is cut into chunks: one workgroup owns (chunk, 128 x 128 output
+// tile), accumulates its partial on fp32 MFMA and writes it to a workspace; k_wgrad_reduce then adds
+// the partials of a type in chunk order.  Two stages instead of float atomics keeps the result
+// deterministic (bit-identical run to run), like every other reduction in this library.
+//
+// LDS layout is reduction-major ("[edge][m]" and "[edge][k]"): both operands are read from HBM as
+// contiguous rows (d_msg rows, gathered X rows), stored with ds_write_b128 as they are, and the MFMA
+// operand reads walk consecutive floats of one LDS row -- no transposes anywhere.
+#include "dense_common.h"
+
+namespace ptgnn_amd {
+namespace {
+
+constexpr int kMaxTypesW = 64;
+constexpr int WG_LD = 132;            // floats per LDS row: 128 + 4 (rows stay 16-byte aligned)
+constexpr int STEP = 32;              // edges per LDS stage
+constexpr int kTile = 128 * 128;      // floats per partial tile
+
+struct WgradTable {
+  const int64_t *src[kMaxTypesW];
+  const int64_t *dst[kMaxTypesW];     // null when the input has no target-state half
+  int64_t edge_off[kMaxTypesW + 1];   // prefix of edges: global d_msg row of the type's edge 0
+  int32_t chunk_off[kMaxTypesW + 1];  // prefix of edge chunks
+  int32_t num_types;
+};
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 3) void k_edge_wgrad(
+    WgradTable tab, const float *__restrict__ x, int64_t ld_x, int H, int use_dst,
+    const float *__restrict__ gm, int64_t ld_gm, int M, int64_t gm_row_base, int chunk_edges,
+    int mtiles, int ktiles, float *__restrict__ partial, int chunk_base, DropoutParams drop) {
+  __shared__ __attribute__((aligned(16))) float As[STEP * WG_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[STEP * WG_LD];
+
+  const int tiles_per_chunk = mtiles * ktiles;
+  const int64_t total = (int64_t)tab.chunk_off[tab.num_types] * tiles_per_chunk;
+  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile >= total) return;
+  const int chunk = (int)(tile / tiles_per_chunk);
+  const int rem = (int)(tile % tiles_per_chunk);
+  const int mt = rem / ktiles, kt = rem % ktiles;
+  int lo = 0, hi_t = tab.num_types;
+  while (hi_t - lo > 1) {
+    const int mid = (lo + hi_t) >> 1;
+    if (tab.chunk_off[mid] <= chunk) lo = mid; else hi_t = mid;
+  }
+  const int t = lo;
+  const int64_t n_edges = tab.edge_off[t + 1] - tab.edge_off[t];
+  const int64_t e_begin = (int64_t)(chunk - tab.chunk_off[t]) * chunk_edges;
+  const int64_t e_end = e_begin + chunk_edges < n_edges ? e_begin + chunk_edges : n_edges;
+  const int64_t gm_row0 = gm_row_base + tab.edge_off[t];
+  const int K = use_dst ? 2 * H : H;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hi = lane >> 5;
+
+  // staging geometry: thread -> (4 edges of the stage, one float4 column of each operand)
+  const int erow = threadIdx.x >> 5;               // + 8 r
+  const int c4 = (threadIdx.x & 31) * 4;
+  int ca = mt * 128 + c4;                          // d_msg column (clamped: extra columns are never stored)
+  ca = ca <= M - 4 ? ca : M - 4;
+  int kc = kt * 128 + c4;                          // input column
+  kc = kc <= K - 4 ? kc : K - 4;
+  const bool from_dst = kc >= H;
+  const int cb = from_dst ? kc - H : kc;
+  const int64_t *__restrict__ idx = from_dst ? tab.dst[t] : tab.src[t];
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = (int)((e_end - e_begin + STEP - 1) / STEP);
+  // software pipeline: node ids of stage s+2 and rows of stage s+1 are in flight under the MFMAs of
+  // stage s.  (Plain scalars + macros: arrays captured by a lambda ended up in scratch memory.)
+  int64_t nid0, nid1, nid2, nid3;
+  float4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+#define WG_EDGE(S, R) ([&]() -> int64_t {                                   \
+    int64_t e_ = e_begin + (int64_t)(S) * STEP + erow + (R) * 8;            \
+    return e_ < n_edges ? e_ : n_edges - 1; }())
+#define WG_LOAD_IDX(S)                                                       \
+  do {                                                                       \
+    nid0 = idx[WG_EDGE(S, 0)]; nid1 = idx[WG_EDGE(S, 1)];                    \
+    nid2 = idx[WG_EDGE(S, 2)]; nid3 = idx[WG_EDGE(S, 3)];                    \
+  } while (0)
+#define WG_LOAD_ROW(S, R, VA, VB, NID)                                                        \
+  do {                                                                                        \
+    VA = *reinterpret_cast<const float4 *>(gm + (gm_row0 + WG_EDGE(S, R)) * ld_gm + ca);      \
+    VB = *reinterpret_cast<const float4 *>(x + (NID) * ld_x + cb);                            \
+  } while (0)
+#define WG_LOAD_ROWS(S)                                                      \
+  do {                                                                       \
+    WG_LOAD_ROW(S, 0, va0, vb0, nid0); WG_LOAD_ROW(S, 1, va1, vb1, nid1);    \
+    WG_LOAD_ROW(S, 2, va2, vb2, nid2); WG_LOAD_ROW(S, 3, va3, vb3, nid3);    \
+  } while (0)
+#define WG_STORE(S, R, VA, VB)                                                               \
+  do {                                                                                       \
+    const int64_t e_ = e_begin + (int64_t)(S) * STEP + erow + (R) * 8;                       \
+    const bool valid_ = e_ < e_end; /* rows past the chunk must add nothing */              \
+    float4 b_ = VB;                                                                          \
+    if constexpr (DROP) b_ = dropout_apply4(drop, gm_row0 + e_, kc, b_);                     \
+    /* componentwise: `cond ? float4 : float4` becomes a pointer select through scratch */   \
+    const float4 a_ = make_float4(valid_ ? VA.x : 0.f, valid_ ? VA.y : 0.f,                  \
+                                  valid_ ? VA.z : 0.f, valid_ ? VA.w : 0.f);                 \
+    b_ = make_float4(valid_ ? b_.x : 0.f, valid_ ? b_.y : 0.f, valid_ ? b_.z : 0.f,          \
+                     valid_ ? b_.w : 0.f);                                                   \
+    *reinterpret_cast<float4 *>(As + (erow + (R) * 8) * WG_LD + c4) = a_;                    \
+    *reinterpret_cast<float4 *>(Bs + (erow + (R) * 8) * WG_LD + c4) = b_;                    \
+  } while (0)
+  WG_LOAD_IDX(0);
+  WG_LOAD_ROWS(0);
+  if (nsteps > 1) WG_LOAD_IDX(1);
+
+  for (int s = 0; s < nsteps; ++s) {
+    __syncthreads();
+    WG_STORE(s, 0, va0, vb0); WG_STORE(s, 1, va1, vb1);
+    WG_STORE(s, 2, va2, vb2); WG_STORE(s, 3, va3, vb3);
+    __syncthreads();
+    if (s + 1 < nsteps) {
+      WG_LOAD_ROWS(s + 1);
+      if (s + 2 < nsteps) WG_LOAD_IDX(s + 2);
+    }
+    const float *ap = As + hi * WG_LD + wm * 64 + li;
+    const float *bp = Bs + hi * WG_LD + wn * 64 + li;
+#pragma unroll
+    for (int ks = 0; ks < STEP / 2; ++ks) {
+      float a[2], b[2];
+      a[0] = ap[ks * 2 * WG_LD];
+      a[1] = ap[ks * 2 * WG_LD + 32];
+      b[0] = bp[ks * 2 * WG_LD];
+      b[1] = bp[ks * 2 * WG_LD + 32];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#undef WG_EDGE
+#undef WG_LOAD_IDX
+#undef WG_LOAD_ROW
+#undef WG_LOAD_ROWS
+#undef WG_STORE
+  // partial tile: [128 m][128 k] floats; C fragment (i, j): row = (r & 3) + 8 (r >> 2) + 4 hi, col = li
+  float *const out = partial + ((int64_t)(chunk_base + chunk) * tiles_per_chunk + rem) * kTile;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        out[m * 128 + wn * 64 + j * 32 + li] = acc[i][j][r];
+      }
+}
+
+// grad_w[t][m][k .. k+3] = sum over the type's chunks (ascending) of the partial tiles
+__global__ __launch_bounds__(256) void k_wgrad_reduce(WgradTable tab, const float *__restrict__ partial,
+                                                      int chunk_base, int mtiles, int ktiles, int M,
+                                                      int K, float *__restrict__ grad_w, int type_base) {
+  const int kq = K / 4;
+  const int64_t per_type = (int64_t)M * kq;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per_type * tab.num_types) return;
+  const int t = (int)(i / per_type);
+  const int rem = (int)(i % per_type);
+  const int m = rem / kq, k = (rem % kq) * 4;
+  const int tiles_per_chunk = mtiles * ktiles;
+  const int64_t off = (int64_t)((m >> 7) * ktiles + (k >> 7)) * kTile + (m & 127) * 128 + (k & 127);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = tab.chunk_off[t]; c < tab.chunk_off[t + 1]; ++c) {
+    const float4 p = *reinterpret_cast<const float4 *>(
+        partial + (int64_t)(chunk_base + c) * tiles_per_chunk * kTile + off);
+    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+  }
+  *reinterpret_cast<float4 *>(grad_w + ((int64_t)(type_base + t) * M + m) * K + k) = s;
+}
+
+// Edges per chunk: aim at ~1024 workgroups (4 per CU on 256 CUs) so the partial-tile traffic
+// (64 KiB per workgroup) stays ~10 % of the operand reads.
+inline int chunk_edges_for(int64_t num_edges, int mtiles, int ktiles) {
+  int64_t ch = (num_edges * mtiles * ktiles + 1023) / 1024;
+  ch = (ch + STEP - 1) / STEP * STEP;
+  if (ch < 256) ch = 256;
+  if (ch > 8192) ch = 8192;
+  return (int)ch;
+}
+
+}  // namespace
+}  // namespace ptgnn_amd
+
+using namespace ptgnn_amd;
+
+extern "C" size_t ptgnn_amd_edge_wgrad_workspace_bytes(int64_t num_edges, int32_t num_types,
+                                                       int32_t msg_dim, int32_t in_dim) {
+  if (num_edges <= 0 || num_types <= 0 || msg_dim <= 0 || in_dim <= 0) return 0;
+  const int mtiles = (msg_dim + 127) / 128, ktiles = (in_dim + 127) / 128;
+  const int ch = chunk_edges_for(num_edges, mtiles, ktiles);
+  const int64_t chunks = num_edges / ch + num_types;   // upper bound of sum_t ceil(E_t / ch)
+  return (size_t)chunks * mtiles * ktiles * kTile * sizeof(float);
+}
+
+extern "C" int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int32_t state_dim,
+                                              const int64_t *const *src_per_type,
+                                              const int64_t *const *dst_per_type,
+                                              const int64_t *edges_per_type, const float *grad_msg,
+                                              int64_t ld_grad_msg, int32_t num_types, int32_t msg_dim,
+                                              float dropout_p, uint64_t dropout_seed, float *grad_w,
+                                              void *workspace, size_t workspace_bytes, void *stream_) {
+  PTGNN_REQUIRE(num_types >= 0 && state_dim > 0 && msg_dim > 0, PTGNN_AMD_EINVAL, "edge_weight_grad: bad sizes");
+  PTGNN_REQUIRE(state_dim % 4 == 0 && msg_dim % 4 == 0, PTGNN_AMD_EUNSUPPORTED,
+                "edge_weight_grad: needs state_dim %% 4 == 0 and msg_dim %% 4 == 0 (got %d, %d)",
+                state_dim, msg_dim);
+  PTGNN_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, PTGNN_AMD_EINVAL, "edge_weight_grad: bad dropout p");
+  PTGNN_REQUIRE(dropout_p == 0.f || dst_per_type == nullptr, PTGNN_AMD_EUNSUPPORTED,
+                "edge_weight_grad: dropout with a target-state half is not a reference configuration");
+  if (num_types == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(x && src_per_type && edges_per_type && grad_msg && grad_w, PTGNN_AMD_EINVAL,
+                "edge_weight_grad: null pointer");
+  PTGNN_REQUIRE(ld_x % 4 == 0 && ld_grad_msg % 4 == 0 && ld_grad_msg >= msg_dim && aligned16(x) &&
+                    aligned16(grad_msg) && aligned16(grad_w),
+                PTGNN_AMD_EUNSUPPORTED, "edge_weight_grad: rows must be 16-byte aligned");
+  const int use_dst = dst_per_type != nullptr;
+  const int K = state_dim * (use_dst ? 2 : 1);
+  const int mtiles = (msg_dim + 127) / 128, ktiles = (K + 127) / 128;
+  int64_t E = 0;
+  for (int t = 0; t < num_types; ++t) {
+    PTGNN_REQUIRE(edges_per_type[t] >= 0, PTGNN_AMD_EINVAL, "edge_weight_grad: negative edge count");
+    E += edges_per_type[t];
+  }
+  const int ch = chunk_edges_for(E, mtiles, ktiles);
+  PTGNN_REQUIRE(workspace_bytes >= ptgnn_amd_edge_wgrad_workspace_bytes(E, num_types, msg_dim, K) &&
+                    (E == 0 || workspace),
+                PTGNN_AMD_EINVAL, "edge_weight_grad: workspace too small (%zu bytes)", workspace_bytes);
+  const DropoutParams drop = make_dropout(dropout_p, dropout_seed, state_dim);
+  hipStream_t st = (hipStream_t)stream_;
+  int64_t row_base = 0;
+  int64_t chunk_base = 0;
+  for (int t0 = 0; t0 < num_types; t0 += kMaxTypesW) {
+    WgradTable tab;
+    tab.num_types = (num_types - t0 < kMaxTypesW) ? (num_types - t0) : kMaxTypesW;
+    tab.edge_off[0] = 0;
+    tab.chunk_off[0] = 0;
+    for (int t = 0; t < tab.num_types; ++t) {
+      const int64_t n = edges_per_type[t0 + t];
+      PTGNN_REQUIRE(n == 0 || (src_per_type[t0 + t] && (!use_dst || dst_per_type[t0 + t])),
+                    PTGNN_AMD_EINVAL, "edge_weight_grad: null table entry for type %d", t0 + t);
+      tab.src[t] = src_per_type[t0 + t];
+      tab.dst[t] = use_dst ? dst_per_type[t0 + t] : nullptr;
+      tab.edge_off[t + 1] = tab.edge_off[t] + n;
+      const int64_t chunks = tab.chunk_off[t] + (n + ch - 1) / ch;
+      PTGNN_REQUIRE(chunk_base + chunks < ((int64_t)1 << 30), PTGNN_AMD_EUNSUPPORTED,
+                    "edge_weight_grad: too many chunks");
+      tab.chunk_off[t + 1] = (int32_t)chunks;
+    }
+    const int64_t total = (int64_t)tab.chunk_off[tab.num_types] * mtiles * ktiles;
+    if (total > 0) {
+      const unsigned grid = (unsigned)xcd_padded_blocks(total);
+      if (drop.thr != 0)
+        k_edge_wgrad<true><<<grid, 256, 0, st>>>(tab, x, ld_x, state_dim, use_dst, grad_msg, ld_grad_msg,
+                                                 msg_dim, row_base, ch, mtiles, ktiles,
+                                                 (float *)workspace, (int)chunk_base, drop);
+      else
+        k_edge_wgrad<false><<<grid, 256, 0, st>>>(tab, x, ld_x, state_dim, use_dst, grad_msg, ld_grad_msg,
+                                                  msg_dim, row_base, ch, mtiles, ktiles,
+                                                  (float *)workspace, (int)chunk_base, drop);
+      PTGNN_LAUNCH_CHECK();
+    }
+    const int64_t outs = (int64_t)tab.num_types * msg_dim * (K / 4);
+    k_wgrad_reduce<<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(
+        tab, (const float *)workspace, (int)chunk_base, mtiles, ktiles, msg_dim, K, grad_w, t0);
+    PTGNN_LAUNCH_CHECK();
+    row_base += tab.edge_off[tab.num_types];
+    chunk_base += tab.chunk_off[tab.num_types];
+  }
+  return PTGNN_AMD_OK;
+}

@@ -613,3 +613,70 @@ extern "C" int ptgnn_amd_gather_rows_f32(const float *x, int64_t ld_x, const int
   PTGNN_LAUNCH_CHECK();
   return PTGNN_AMD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the segment reduce: spread the output-row gradients back onto the message rows.
+//   d_msg[perm[s], :] = grad[row(s), :]                      sum (mean: the caller pre-divides grad)
+//   d_msg[perm[s], c] = arg[row(s), c] == s ? grad[row(s), c] : 0     max / min (torch_scatter arg_out)
+// One CSR slot per group of dim/4 lanes; the slot -> row map is the plan's expanded rowptr.  Reads of
+// `grad` are row-sequential (slots of a row are adjacent), every message row is written exactly once
+// as a whole row, so there is nothing to zero-fill and nothing to accumulate.
+// ---------------------------------------------------------------------------------------------
+namespace ptgnn_amd {
+namespace {
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_segment_spread(const float *__restrict__ grad, int64_t ld_grad,
+                                                        const int32_t *__restrict__ arg,
+                                                        const int32_t *__restrict__ slot_row,
+                                                        const int32_t *__restrict__ perm,
+                                                        int64_t num_slots, int dim,
+                                                        float *__restrict__ out, int64_t ld_out) {
+  const int q = VEC4 ? dim / 4 : dim;                 // work items per slot
+  const int64_t total = num_slots * q;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int64_t s = i / q;
+    const int c = (int)(i - s * q) * (VEC4 ? 4 : 1);
+    const int64_t row = slot_row[s];
+    const int64_t e = perm[s];
+    if constexpr (VEC4) {
+      float4 g = *reinterpret_cast<const float4 *>(grad + row * ld_grad + c);
+      if (arg) {
+        const int4 a = *reinterpret_cast<const int4 *>(arg + row * dim + c);
+        const int32_t si = (int32_t)s;
+        g.x = a.x == si ? g.x : 0.f; g.y = a.y == si ? g.y : 0.f;
+        g.z = a.z == si ? g.z : 0.f; g.w = a.w == si ? g.w : 0.f;
+      }
+      *reinterpret_cast<float4 *>(out + e * ld_out + c) = g;
+    } else {
+      float g = grad[row * ld_grad + c];
+      if (arg && arg[row * dim + c] != (int32_t)s) g = 0.f;
+      out[e * ld_out + c] = g;
+    }
+  }
+}
+}  // namespace
+}  // namespace ptgnn_amd
+
+extern "C" int ptgnn_amd_segment_spread_f32(const float *grad, int64_t ld_grad, const int32_t *arg,
+                                            const int32_t *slot_row, const int32_t *perm,
+                                            int64_t num_slots, int32_t dim, float *out, int64_t ld_out,
+                                            void *stream_) {
+  PTGNN_REQUIRE(num_slots >= 0 && dim > 0, PTGNN_AMD_EINVAL, "segment_spread: bad sizes");
+  if (num_slots == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(grad && slot_row && perm && out, PTGNN_AMD_EINVAL, "segment_spread: null pointer");
+  PTGNN_REQUIRE(ld_grad >= dim && ld_out >= dim, PTGNN_AMD_EINVAL, "segment_spread: bad leading dimension");
+  const bool vec4 = (dim % 4 == 0) && (ld_grad % 4 == 0) && (ld_out % 4 == 0) && aligned16(grad) &&
+                    aligned16(out) && (!arg || aligned16(arg));
+  const int64_t items = num_slots * (vec4 ? dim / 4 : dim);
+  int64_t blocks = (items + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (vec4)
+    k_segment_spread<true><<<(unsigned)blocks, 256, 0, (hipStream_t)stream_>>>(
+        grad, ld_grad, arg, slot_row, perm, num_slots, dim, out, ld_out);
+  else
+    k_segment_spread<false><<<(unsigned)blocks, 256, 0, (hipStream_t)stream_>>>(
+        grad, ld_grad, arg, slot_row, perm, num_slots, dim, out, ld_out);
+  PTGNN_LAUNCH_CHECK();
+  return PTGNN_AMD_OK;
+}

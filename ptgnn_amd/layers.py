@@ -26,7 +26,8 @@ import torch
 from torch import nn
 
 from ptgnn_amd import _lib, ops
-from ptgnn_amd.scatter import gather_reduce as gather_reduce_autograd, segment_reduce
+from ptgnn_amd.scatter import (edge_linear as edge_linear_autograd, gather_reduce as gather_reduce_autograd,
+                               segment_reduce)
 
 try:  # inside a ptgnn install the layers ARE ptgnn layers
     from ptgnn.neuralmodels.gnn.messagepassing.abstractmessagepassing import (  # type: ignore
@@ -82,6 +83,18 @@ def _prefer_edge_path(num_edges: int, num_nodes: int, num_types: int, state_dim:
     if state_dim % 32 != 0 or msg_dim % 4 != 0 or num_types < 2:
         return False
     return num_edges * EDGE_PATH_BIAS < num_nodes * num_types
+
+
+def _edge_training_ok(state_dim: int, msg_dim: int) -> bool:
+    """The grouped edge GEMM needs its reduction width % 32 == 0: the state width in the forward, the
+    message width in the input-gradient GEMM."""
+    return state_dim % 32 == 0 and msg_dim % 32 == 0
+
+
+def _dropout_seed() -> int:
+    """A fresh 62-bit seed for the hash dropout mask, drawn from torch's CPU generator (so
+    torch.manual_seed makes training runs repeatable) without touching the device."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
 def _check_device(node_states: torch.Tensor):
@@ -201,9 +214,23 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                 agg = ops.gather_reduce(y, plan, M, self.__aggregation_fn)
             return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
 
+        no_feats = self._edge_feature_dimension == 0 and not any(
+            f is not None and f.shape[-1] != 0 for f in edge_features)
+        p = self.__dropout.p if self.training else 0.0
+        M, T = self._message_dimension, len(adjacency_lists)
+        if (no_feats and node_states.dtype == torch.float32 and _edge_training_ok(self.__state_dimension, M)
+                and (p > 0 or _prefer_edge_path(plan.num_edges, num_nodes, T, self.__state_dimension, M))):
+            # training, edge form: grouped per-edge GEMM with the reference's per-edge input dropout
+            # folded in (forward + both gradients on HIP), HIP segment reduce, torch GRU cell
+            msgs = edge_linear_autograd(node_states, plan,
+                                        [l.weight for l in self.__edge_message_transformation_layers],
+                                        False, p, _dropout_seed() if p > 0 else 0)
+            agg = segment_reduce(msgs, plan, self.__aggregation_fn)
+            return gru(agg, node_states)
+
         if self._table_ok(node_states, edge_features):
-            # training without per-edge dropout: torch (rocBLAS) for the dense blocks so autograd owns
-            # them, the HIP kernel (forward + backward) for the aggregation
+            # training without per-edge dropout, few edge types: torch (rocBLAS) for the dense blocks so
+            # autograd owns them, the HIP kernel (forward + backward) for the aggregation
             w = torch.cat([l.weight for l in self.__edge_message_transformation_layers], dim=0)
             y = nn.functional.linear(node_states, w)
             agg = gather_reduce_autograd(y, None, plan, self._message_dimension, self.__aggregation_fn)
@@ -419,10 +446,15 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             return self._aggregate_and_update(ysrc, ydst, plan)
 
         if self._table_ok(node_states, edge_features):
-            # training: dense blocks through torch autograd, aggregation fwd + bwd on the HIP kernel
             plan = ops.plan_for(adjacency_lists, num_nodes)
             H = self.__input_state_dim
             ws = [m.linears[0].weight for m in self.__edge_message_transformation_layers]
+            if _edge_training_ok(H, M) and _prefer_edge_path(plan.num_edges, num_nodes, T, H, M):
+                # training, many sparse edge types: grouped per-edge GEMM forward + backward on HIP
+                # (the edge MLPs of this layer carry no dropout: mlpmessagepassing.py:39-47)
+                msgs = edge_linear_autograd(node_states, plan, ws, self.__use_target_state_as_message_input)
+                return self._update(segment_reduce(msgs, plan, self.__aggregation_fn), False)
+            # training: dense blocks through torch autograd, aggregation fwd + bwd on the HIP kernel
             parts = [w[:, :H] for w in ws]
             if self.__use_target_state_as_message_input:
                 parts += [w[:, H:2 * H] for w in ws]

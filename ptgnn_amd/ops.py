@@ -104,7 +104,8 @@ class GraphPlan:
 
     __slots__ = ("rowptr", "col", "perm", "type_bits", "num_nodes", "num_edges", "num_types",
                  "num_src_rows", "_backward", "_adj", "_adj_refs", "_inv_perm", "_ready", "_waited",
-                 "_hub_tickets", "hub_entries", "hub_count", "__weakref__")
+                 "_hub_tickets", "hub_entries", "hub_count", "_slot_rows", "_ident", "_transposed",
+                 "__weakref__")
 
     def __init__(self, rowptr, col, perm, type_bits, num_nodes, num_edges, num_types):
         self.rowptr, self.col, self.perm = rowptr, col, perm
@@ -119,6 +120,7 @@ class GraphPlan:
         self._waited = set()
         self._hub_tickets = {}
         self.hub_entries = self.hub_count = None   # (chunk, row) pairs of rows > HUB_THRESHOLD
+        self._slot_rows = self._ident = self._transposed = None
 
     def may_have_hubs(self) -> bool:
         """Only plans with more edges than the threshold can contain a hub row (whether they do is
@@ -161,6 +163,42 @@ class GraphPlan:
             inv = self.inverse_perm()
             bp._inv_perm = inv[bp.perm[: self.num_edges].to(torch.int64)].to(torch.int32).contiguous()
         return bp._inv_perm
+
+    def slot_rows(self) -> torch.Tensor:
+        """int32 [E]: destination row of every CSR slot (rowptr expanded); built on the first backward
+        of a minibatch, shared by all layers."""
+        if self._slot_rows is None:
+            self.wait()
+            E = self.num_edges
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+            rows = torch.arange(self.num_nodes, device=self.rowptr.device, dtype=torch.int32)
+            self._slot_rows = torch.repeat_interleave(rows, deg, output_size=E) if E > 0 else rows[:0]
+        return self._slot_rows
+
+    def identity_index(self) -> List[torch.Tensor]:
+        """Per-type views of arange(E) (int64): the "source index" that makes the grouped edge GEMM
+        read its A rows in message order (backward of the message Linear)."""
+        if self._ident is None:
+            if self._adj is None:
+                raise _lib.PtgnnAmdError("this plan was built without keeping its adjacency lists")
+            ar = torch.arange(max(self.num_edges, 1), device=self.rowptr.device, dtype=torch.int64)
+            out, off = [], 0
+            for s_, _ in self._adj:
+                n = int(s_.shape[0])
+                out.append(ar[off: off + n])
+                off += n
+            self._ident = out
+        return self._ident
+
+    def transposed_plan(self) -> "GraphPlan":
+        """rows = source node, col/perm over the same message order: segment-sums per-edge input
+        gradients back onto the source rows."""
+        if self._transposed is None:
+            if self._adj is None:
+                raise _lib.PtgnnAmdError("this plan was built without keeping its adjacency lists")
+            self.wait()
+            self._transposed = build_plan(self._adj, self.num_src_rows, mode=1)
+        return self._transposed
 
     def inverse_perm(self) -> torch.Tensor:
         """original edge position -> CSR slot (int64)."""
@@ -449,9 +487,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 def edge_linear(x: torch.Tensor, adjacency_lists, weights: Sequence[torch.Tensor], use_dst: bool,
-                act: Optional[str] = None) -> torch.Tensor:
+                act: Optional[str] = None, dropout: Optional[Tuple[int, float, int]] = None) -> torch.Tensor:
     """msg[off_t + e] = act([x[src_t[e]] ; x[dst_t[e]] (if use_dst)] W_t^T) for every edge type in one
-    launch; rows in type-major message order.  weights[t] is the type's nn.Linear weight."""
+    launch; rows in type-major message order.  weights[t] is the type's nn.Linear weight.
+    dropout = (mode, p, seed): nn.Dropout(p) on the gathered input rows (mode 1) or on the output rows
+    (mode 2, the input-gradient form) with the hash mask of ptgnn_amd_edge_linear_dropout_f32."""
     lib = _lib.load()
     _require_cuda_f32("x", x)
     x = _rowmajor(x)
@@ -474,6 +514,16 @@ def edge_linear(x: torch.Tensor, adjacency_lists, weights: Sequence[torch.Tensor
     wp = PtrArr(*[w.data_ptr() for w in ws])
     cn = CntArr(*counts)
     K = H * (2 if use_dst else 1)
+    if dropout is not None and dropout[0] != 0 and dropout[1] > 0.0:
+        if use_dst or act is not None:
+            raise _lib.PtgnnAmdError("edge_linear: dropout supports the GGNN form only (no target half, no act)")
+        with _timed("edge_linear", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
+            rc = lib.ptgnn_amd_edge_linear_dropout_f32(
+                x.data_ptr(), _ld(x), H, ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(cn, ctypes.c_void_p),
+                ctypes.cast(wp, ctypes.c_void_p), T, M, msg.data_ptr(), M, int(dropout[0]),
+                float(dropout[1]), int(dropout[2]) & 0xFFFFFFFFFFFFFFFF, _stream(msg))
+        _lib.check(rc, "ptgnn_amd_edge_linear_dropout_f32")
+        return msg[:E] if E > 0 else msg[:0]
     with _timed("edge_linear", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
         rc = lib.ptgnn_amd_edge_linear_f32(x.data_ptr(), _ld(x), H, ctypes.cast(sp, ctypes.c_void_p),
                                            ctypes.cast(dp, ctypes.c_void_p) if use_dst else None,
@@ -482,6 +532,61 @@ def edge_linear(x: torch.Tensor, adjacency_lists, weights: Sequence[torch.Tensor
                                            msg.data_ptr(), M, _stream(msg))
     _lib.check(rc, "ptgnn_amd_edge_linear_f32")
     return msg[:E] if E > 0 else msg[:0]
+
+
+def edge_weight_grad(x: torch.Tensor, adjacency_lists, grad_msg: torch.Tensor, use_dst: bool,
+                     dropout_p: float = 0.0, dropout_seed: int = 0) -> torch.Tensor:
+    """grad_w[t] = grad_msg_t^T . [x[src_t] ; x[dst_t] (if use_dst)]  for all types -> [T, M, K]."""
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    _require_cuda_f32("grad_msg", grad_msg)
+    x, grad_msg = _rowmajor(x), _rowmajor(grad_msg)
+    T, H, M = len(adjacency_lists), x.shape[1], grad_msg.shape[1]
+    K = H * (2 if use_dst else 1)
+    counts = [int(a[0].shape[0]) for a in adjacency_lists]
+    E = sum(counts)
+    if grad_msg.shape[0] != E:
+        raise _lib.PtgnnAmdError("edge_weight_grad: grad_msg rows != number of edges")
+    srcs = [a[0].contiguous() for a in adjacency_lists]
+    dsts = [a[1].contiguous() for a in adjacency_lists]
+    PtrArr, CntArr = ctypes.c_void_p * T, ctypes.c_int64 * T
+    sp = PtrArr(*[s.data_ptr() if s.numel() else None for s in srcs])
+    dp = PtrArr(*[d.data_ptr() if d.numel() else None for d in dsts])
+    cn = CntArr(*counts)
+    grad_w = torch.empty(T, M, K, dtype=torch.float32, device=x.device)
+    ws_bytes = lib.ptgnn_amd_edge_wgrad_workspace_bytes(E, T, M, K)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+    gm_ptr = grad_msg.data_ptr() if E > 0 else x.data_ptr()
+    with _timed("edge_weight_grad", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
+        rc = lib.ptgnn_amd_edge_weight_grad_f32(
+            x.data_ptr(), _ld(x), H, ctypes.cast(sp, ctypes.c_void_p),
+            ctypes.cast(dp, ctypes.c_void_p) if use_dst else None, ctypes.cast(cn, ctypes.c_void_p),
+            gm_ptr, _ld(grad_msg) if E > 0 else M, T, M, float(dropout_p),
+            int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, grad_w.data_ptr(), ws.data_ptr(), ws_bytes, _stream(grad_w))
+    _lib.check(rc, "ptgnn_amd_edge_weight_grad_f32")
+    return grad_w
+
+
+def segment_spread(grad: torch.Tensor, arg: Optional[torch.Tensor], plan: GraphPlan) -> torch.Tensor:
+    """Backward of `segment_reduce` w.r.t. the messages: [N, D] row gradients -> [E, D] in message order
+    (max/min: only the recorded winner slot of each (row, column) receives the gradient)."""
+    lib = _lib.load()
+    _require_cuda_f32("grad", grad)
+    grad = _rowmajor(grad)
+    E, D = plan.num_edges, grad.shape[1]
+    out = torch.empty(E, D, dtype=torch.float32, device=grad.device)
+    if E == 0:
+        return out
+    if arg is not None:
+        arg = arg.contiguous()
+    plan.wait()
+    with _timed("segment_spread", bytes=E * (4.0 * D + 8) + plan.num_nodes * 4.0 * D * (2 if arg is not None else 1)):
+        rc = lib.ptgnn_amd_segment_spread_f32(grad.data_ptr(), _ld(grad),
+                                              arg.data_ptr() if arg is not None else None,
+                                              plan.slot_rows().data_ptr(), plan.perm.data_ptr(), E, D,
+                                              out.data_ptr(), D, _stream(out))
+    _lib.check(rc, "ptgnn_amd_segment_spread_f32")
+    return out
 
 
 def gru_cell(a: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh) -> torch.Tensor:

@@ -39,26 +39,14 @@ class _SegmentReduce(torch.autograd.Function):
         D = grad_out.shape[1]
         if E == 0:
             return grad_out.new_zeros(0, D), None, None
-        # slot -> destination row (expand rowptr), slot -> original edge position (perm)
-        deg = (plan.rowptr[1:] - plan.rowptr[:-1]).to(torch.int64)
-        slot_dst = torch.repeat_interleave(torch.arange(plan.num_nodes, device=grad_out.device), deg,
-                                           output_size=E)
-        perm = plan.perm[:E].to(torch.int64)
         if reduce in ("sum", "add", "mean"):
             g = grad_out
             if reduce == "mean":
+                deg = (plan.rowptr[1:] - plan.rowptr[:-1])
                 g = grad_out / deg.clamp(min=1).to(grad_out.dtype).unsqueeze(1)
-            grad_slots = ops.gather_rows(g, slot_dst)               # [E, D] in CSR slot order
-            grad_msg = torch.empty_like(grad_slots)
-            grad_msg[perm] = grad_slots
-            return grad_msg, None, None
+            return ops.segment_spread(g, None, plan), None, None
         (arg,) = ctx.saved_tensors                                  # [N, D] winning slot or -1
-        grad_msg = grad_out.new_zeros(E * D)
-        valid = arg >= 0
-        slot = arg.clamp(min=0).to(torch.int64)
-        flat = perm[slot] * D + torch.arange(D, device=grad_out.device).unsqueeze(0)
-        grad_msg.index_put_((flat[valid],), grad_out[valid], accumulate=False)
-        return grad_msg.view(E, D), None, None
+        return ops.segment_spread(grad_out, arg, plan), None, None
 
 
 def segment_reduce(messages: torch.Tensor, plan: "ops.GraphPlan", reduce: str) -> torch.Tensor:
@@ -89,6 +77,68 @@ def scatter(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional
     plan = ops.build_plan([(index, index)], int(dim_size))
     res = segment_reduce(src.to(torch.float32), plan, reduce).to(dt)
     return res.squeeze(1) if squeeze else res
+
+
+class _EdgeLinear(torch.autograd.Function):
+    """Per-edge message Linear of ALL edge types as one differentiable op (training form of the fused
+    edge path):  msg[off_t + e] = W_t . Dropout([x[src_t[e]] ; x[dst_t[e]]]).
+
+    forward : grouped per-edge GEMM (edge_gemm.hip), dropout mask regenerated from (seed, row, column);
+    backward: d W_t  = d msg_t^T . in_t              grouped split-edge GEMM (edge_wgrad.hip)
+              d in   = (d msg . W_t) * mask          the same grouped GEMM over an identity index
+              d x    = segment-sum of d in over the source rows (+ over the destination rows for the
+                       target-state half): the HIP segment reduce over the transposed / forward plan.
+    No [E, K] gathered input and no mask tensor is kept between forward and backward.
+    """
+
+    @staticmethod
+    def forward(ctx, x, plan, use_dst, dropout_p, dropout_seed, *weights):
+        adj = plan._adj
+        drop = (1, dropout_p, dropout_seed) if dropout_p > 0.0 else None
+        msg = ops.edge_linear(x, adj, weights, use_dst, dropout=drop)
+        ctx.plan, ctx.use_dst, ctx.drop = plan, use_dst, (dropout_p, dropout_seed)
+        ctx.save_for_backward(x, *weights)
+        return msg
+
+    @staticmethod
+    def backward(ctx, grad_msg):
+        x, *weights = ctx.saved_tensors
+        plan, use_dst = ctx.plan, ctx.use_dst
+        p, seed = ctx.drop
+        adj = plan._adj
+        H = x.shape[1]
+        gm = grad_msg.contiguous()
+        need_x = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[5:])
+        d_x = None
+        d_ws = [None] * len(weights)
+        if need_w:
+            gw = ops.edge_weight_grad(x, adj, gm, use_dst, p, seed)            # [T, M, K]
+            d_ws = [gw[t] if ctx.needs_input_grad[5 + t] else None for t in range(len(weights))]
+        if need_x:
+            if plan.num_edges == 0:
+                d_x = torch.zeros_like(x)
+            else:
+                wt = torch.stack([w.detach() for w in weights]).transpose(1, 2).contiguous()   # [T, K, M]
+                drop = (2, p, seed) if p > 0.0 else None
+                g_in = ops.edge_linear(gm, [(i, i) for i in plan.identity_index()], list(wt.unbind(0)),
+                                       False, dropout=drop)                                   # [E, K]
+                tp = plan.transposed_plan()
+                d_x = ops.gather_reduce(g_in[:, :H] if use_dst else g_in, tp, H, "sum", type_bits=0,
+                                        col=tp.perm)
+                if use_dst:
+                    d_x = d_x + ops.gather_reduce(g_in[:, H:], plan, H, "sum", type_bits=0, col=plan.perm)
+                if d_x.shape[0] != x.shape[0]:   # plans over a halo table: rows past the sources are zero
+                    d_x = torch.nn.functional.pad(d_x, (0, 0, 0, x.shape[0] - d_x.shape[0]))
+        return (d_x, None, None, None, None, *d_ws)
+
+
+def edge_linear(x: torch.Tensor, plan: "ops.GraphPlan", weights, use_dst: bool, dropout_p: float = 0.0,
+                dropout_seed: int = 0) -> torch.Tensor:
+    """Differentiable grouped per-edge Linear over the plan's adjacency lists (see `_EdgeLinear`)."""
+    if plan._adj is None:
+        raise _lib.PtgnnAmdError("edge_linear: the plan must keep its adjacency lists")
+    return _EdgeLinear.apply(x, plan, bool(use_dst), float(dropout_p), int(dropout_seed), *weights)
 
 
 class _GatherReduce(torch.autograd.Function):

@@ -38,7 +38,7 @@ def main(root):
         print("| kernel | calls | total (us) | avg (us) | % |")
         print("|---|---|---|---|---|")
         rows = list(csv.DictReader(open(stats)))
-        for r in rows[:15]:
+        for r in rows[:int(os.environ.get("PROF_TOP", "15"))]:
             print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e3:.1f} | "
                   f"{float(r['AverageNs']) / 1e3:.2f} | {r['Percentage']} |")
     traffic = defaultdict(lambda: {"launches": 0, "fetch_bytes_x2": 0.0, "write_bytes": 0.0})

@@ -11,7 +11,7 @@ from ptgnn_amd import layers as L, ops, workloads  # noqa: E402
 from ptgnn_amd.gnn import GraphNeuralNetwork  # noqa: E402
 
 dev = torch.device("cuda:0")
-for dropout in (0.0, 0.1):
+for dropout in [float(v) for v in os.environ.get("TRAIN_DROPOUTS", "0.0,0.1").split(",")]:
     H, T = 128, 17
     mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234)
     torch.manual_seed(1234)

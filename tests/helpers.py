@@ -105,3 +105,34 @@ def to_cuda_adj(adj):
 
 def empty_feats(adj, device):
     return [torch.empty(a[0].shape[0], 0, device=device) for a in adj]
+
+
+def dropout_keep_scale(seed: int, num_rows: int, width: int, p: float) -> torch.Tensor:
+    """numpy restatement of ptgnn_amd/csrc/dense_common.h `dropout_apply4`: the [num_rows, width] fp32
+    multiplier (0 or 1/(1-p)) the HIP kernels apply to the gathered GGNN message input."""
+    import numpy as np
+
+    def mix32(v):
+        v = v.astype(np.uint32)
+        v ^= v >> np.uint32(16)
+        v = (v * np.uint32(0x21F0AAAD)).astype(np.uint32)
+        v ^= v >> np.uint32(15)
+        v = (v * np.uint32(0x735A2D97)).astype(np.uint32)
+        v ^= v >> np.uint32(15)
+        return v
+
+    assert width % 2 == 0
+    half = width // 2
+    thr = int(p * 65536.0 + 0.5)
+    with np.errstate(over="ignore"):
+        idx = (np.arange(num_rows, dtype=np.uint64)[:, None] * np.uint64(half)
+               + np.arange(half, dtype=np.uint64)[None, :])
+        lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        hi = (idx >> np.uint64(32)).astype(np.uint32)
+        h = mix32(lo ^ np.uint32(seed & 0xFFFFFFFF))
+        h = mix32((h + hi * np.uint32(0x9E3779B9) + np.uint32((seed >> 32) & 0xFFFFFFFF)).astype(np.uint32))
+    keep = np.empty((num_rows, width), dtype=bool)
+    keep[:, 0::2] = (h & np.uint32(0xFFFF)) >= thr
+    keep[:, 1::2] = (h >> np.uint32(16)) >= thr
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return torch.from_numpy(keep.astype(np.float32) * scale)

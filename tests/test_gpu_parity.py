@@ -490,16 +490,135 @@ def test_edge_path_equals_pretransform_path_and_oracle(kind, agg, monkeypatch):
     np.testing.assert_allclose(outs["node"].numpy(), want.numpy(), rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("use_dst", [False, True])
+@pytest.mark.parametrize("H,M", [(32, 64), (128, 128), (64, 200), (160, 36)])
+def test_edge_weight_grad_matches_fp64(use_dst, H, M):
+    """dW_t = d_msg_t^T . [x[src] ; x[dst]] for all types in one call (incl. empty / 1-edge / multi-chunk
+    types) against a float64 evaluation; deterministic run to run."""
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(3 * H + M)
+    n = 900
+    counts = [5000, 0, 129, 1, 128, 777]
+    adj = [(torch.randint(0, n, (c,), generator=g), torch.randint(0, n, (c,), generator=g)) for c in counts]
+    x = torch.randn(n, H, generator=g)
+    gm = torch.randn(sum(counts), M, generator=g)
+    off = np.cumsum([0] + counts)
+    want = torch.stack([gm[off[t]:off[t + 1]].double().t()
+                        @ (torch.cat([x[s], x[d]], -1) if use_dst else x[s]).double()
+                        for t, (s, d) in enumerate(adj)]).float()
+    cadj = to_cuda_adj(adj)
+    got = ops.edge_weight_grad(x.cuda(), cadj, gm.cuda(), use_dst)
+    again = ops.edge_weight_grad(x.cuda(), cadj, gm.cuda(), use_dst)
+    assert torch.equal(got, again)
+    scale = max(1.0, float(want.abs().max()))
+    # relative to the size of the sums (up to 5000-term fp32 dot products)
+    assert float((got.cpu() - want).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_edge_linear_hash_dropout_matches_numpy_restatement(p):
+    """The in-kernel dropout mask (forward, input-gradient and weight-gradient forms) equals the numpy
+    restatement in tests/helpers.py element for element."""
+    from helpers import dropout_keep_scale
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(77)
+    n, H, M, seed = 500, 64, 96, 0x1234_5678_9ABC_DEF
+    counts = [700, 0, 130, 1]
+    E = sum(counts)
+    adj = [(torch.randint(0, n, (c,), generator=g), torch.randint(0, n, (c,), generator=g)) for c in counts]
+    x = torch.randn(n, H, generator=g)
+    ws = [torch.randn(M, H, generator=g) / H ** 0.5 for _ in counts]
+    mask = dropout_keep_scale(seed, E, H, p)
+    frac = float((mask == 0).float().mean())
+    assert abs(frac - p) < 0.02
+    xin = torch.cat([x[s] for s, _ in adj]) * mask                       # Dropout(x_src), message order
+    off = np.cumsum([0] + counts)
+    want_fwd = torch.cat([xin[off[t]:off[t + 1]].double() @ ws[t].double().t() for t in range(len(counts))]).float()
+    cadj, cws = to_cuda_adj(adj), [w.cuda() for w in ws]
+    got_fwd = ops.edge_linear(x.cuda(), cadj, cws, False, dropout=(1, p, seed)).cpu()
+    np.testing.assert_allclose(got_fwd.numpy(), want_fwd.numpy(), rtol=0, atol=TOL)
+    # input-gradient form: (d_msg . W_t) * mask over an identity index
+    gm = torch.randn(E, M, generator=g)
+    want_gin = torch.cat([gm[off[t]:off[t + 1]].double() @ ws[t].double() for t in range(len(counts))]).float() * mask
+    ident = torch.arange(E).cuda()
+    iadj = [(ident[off[t]:off[t + 1]], ident[off[t]:off[t + 1]]) for t in range(len(counts))]
+    got_gin = ops.edge_linear(gm.cuda(), iadj, [w.t().contiguous().cuda() for w in ws], False,
+                              dropout=(2, p, seed)).cpu()
+    np.testing.assert_allclose(got_gin.numpy(), want_gin.numpy(), rtol=0, atol=TOL)
+    # weight-gradient form
+    want_gw = torch.stack([gm[off[t]:off[t + 1]].double().t() @ xin[off[t]:off[t + 1]].double()
+                           for t in range(len(counts))]).float()
+    got_gw = ops.edge_weight_grad(x.cuda(), cadj, gm.cuda(), False, p, seed).cpu()
+    np.testing.assert_allclose(got_gw.numpy(), want_gw.numpy(), rtol=0, atol=1e-5 * max(1.0, float(want_gw.abs().max())))
+
+
+@pytest.mark.parametrize("agg", ["sum", "max"])
+def test_ggnn_training_with_per_edge_dropout_matches_oracle_autograd(agg, monkeypatch):
+    """The reference's shipped training configuration (dropout on the gathered message input,
+    gatedmessagepassing.py:57-61) on the HIP edge path: forward, d x, d W_t and d GRU against the
+    oracle's torch-CPU autograd with the SAME (restated) mask."""
+    from helpers import dropout_keep_scale
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, ops, workloads
+    mb = workloads.batched_graphs(3, 150, 3, 2.2, seed=5)
+    N, H, M, p, seed = mb["num_nodes"], 32, 64, 0.2, 987654321987
+    adj = O.augment_adjacency(mb["adjacency_lists"], N, True, True)
+    T = len(adj)
+    torch.manual_seed(3)
+    layer = L.GatedMessagePassingLayer(H, M, T, agg, dropout_rate=p).train()
+    monkeypatch.setattr(L, "_dropout_seed", lambda: seed)
+    x = workloads.node_states(N, H, seed=6)
+    gout = workloads.node_states(N, H, seed=7)
+    spec = layer.export_weights()
+    E = sum(int(a[0].shape[0]) for a in adj)
+    mask = dropout_keep_scale(seed, E, H, p)
+
+    xo = x.clone().requires_grad_(True)
+    ws = [w.clone().requires_grad_(True) for w in spec["edge_w"]]
+    gru = [spec[k].clone().requires_grad_(True) for k in ("w_ih", "w_hh", "b_ih", "b_hh")]
+    off = np.cumsum([0] + [int(a[0].shape[0]) for a in adj])
+    msgs = torch.cat([O.linear(xo[s] * mask[off[t]:off[t + 1]], ws[t]) for t, (s, _) in enumerate(adj)])
+    agg_o = O.aggregate_messages(msgs, torch.cat([d for _, d in adj]), N, agg)
+    yo = O.gru_cell(agg_o, xo, *gru)
+    yo.backward(gout)
+
+    layer = layer.cuda()
+    xg = x.cuda().requires_grad_(True)
+    cadj = to_cuda_adj(adj)
+    ops.clear_plan_cache()
+    timer = ops.KernelTimer()
+    ops.set_kernel_timer(timer)
+    yg = layer(xg, cadj, None, {}, {}, empty_feats(cadj, "cuda"))
+    yg.backward(gout.cuda())
+    ops.set_kernel_timer(None)
+    used = timer.summary()
+    assert used["edge_linear"]["calls"] == 2 and used["edge_weight_grad"]["calls"] == 1 \
+        and used["segment_spread"]["calls"] == 1, used
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=0, atol=TOL)
+    sc = max(1.0, float(xo.grad.abs().max()))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=0, atol=2e-5 * sc)
+    sd = layer.state_dict(keep_vars=True)
+    for t in range(T):
+        ours = sd[f"_GatedMessagePassingLayer__edge_message_transformation_layers.{t}.weight"].grad
+        sc = max(1.0, float(ws[t].grad.abs().max()))
+        np.testing.assert_allclose(ours.cpu().numpy(), ws[t].grad.numpy(), rtol=0, atol=2e-5 * sc)
+    ours = sd["_GatedMessagePassingLayer__state_update.weight_ih"].grad
+    np.testing.assert_allclose(ours.cpu().numpy(), gru[0].grad.numpy(), rtol=0,
+                               atol=2e-5 * max(1.0, float(gru[0].grad.abs().max())))
+
+
 # ------------------------------------------------------------------------------------------------
 # training: fused aggregation forward + backward (HIP kernel both ways) vs oracle autograd on CPU
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["table", "edge"])
 @pytest.mark.parametrize("kind", ["ggnn", "mlp", "mlp_notarget"])
 @pytest.mark.parametrize("agg", ["sum", "mean", "max", "min"])
-def test_training_gradients_match_oracle_autograd(kind, agg):
+def test_training_gradients_match_oracle_autograd(kind, agg, path, monkeypatch):
     from oracle import mp_oracle as O
     from ptgnn_amd import layers as L, ops, workloads
+    monkeypatch.setattr(L, "EDGE_PATH_BIAS", 1e-9 if path == "edge" else 1e9)
     mb = workloads.batched_graphs(3, 150, 3, 2.2, seed=11)
-    N, H, M = mb["num_nodes"], 32, 48
+    N, H, M = mb["num_nodes"], 32, (64 if path == "edge" else 48)
     adj = O.augment_adjacency(mb["adjacency_lists"], N, True, True)     # T = 7
     T = len(adj)
     torch.manual_seed(21)
@@ -538,6 +657,7 @@ def test_training_gradients_match_oracle_autograd(kind, agg):
     calls = timer.summary()
     n_agg = calls["gather_reduce"]["calls"] + calls.get("gather_reduce_masked", {"calls": 0})["calls"]
     assert n_agg >= 2 and calls["csr_build"]["calls"] == 2       # HIP kernel both ways; fwd + bwd plan
+    assert ("edge_weight_grad" in calls) == (path == "edge"), calls
     np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=0, atol=TOL)
     scale = max(1.0, float(xo.grad.abs().max()))
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=0, atol=2e-5 * scale)
