@@ -94,8 +94,13 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
     return e_ < n_edges ? e_ : n_edges - 1; }())
 #define WG_LOAD_IDX(S)                                                       \
   do {                                                                       \
-    nid0 = idx[WG_EDGE(S, 0)]; nid1 = idx[WG_EDGE(S, 1)];                    \
-    nid2 = idx[WG_EDGE(S, 2)]; nid3 = idx[WG_EDGE(S, 3)];                    \
+    if (idx) { /* uniform: a null index list means "row e of x" (dense weight gradient) */ \
+      nid0 = idx[WG_EDGE(S, 0)]; nid1 = idx[WG_EDGE(S, 1)];                  \
+      nid2 = idx[WG_EDGE(S, 2)]; nid3 = idx[WG_EDGE(S, 3)];                  \
+    } else {                                                                 \
+      nid0 = WG_EDGE(S, 0); nid1 = WG_EDGE(S, 1);                            \
+      nid2 = WG_EDGE(S, 2); nid3 = WG_EDGE(S, 3);                            \
+    }                                                                        \
   } while (0)
 #define WG_LOAD_ROW(S, R, VA, VB, NID)                                                        \
   do {                                                                                        \
@@ -215,13 +220,12 @@ extern "C" size_t ptgnn_amd_edge_wgrad_workspace_bytes(int64_t num_edges, int32_
   return (size_t)chunks * mtiles * ktiles * kTile * sizeof(float);
 }
 
-extern "C" int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int32_t state_dim,
-                                              const int64_t *const *src_per_type,
-                                              const int64_t *const *dst_per_type,
-                                              const int64_t *edges_per_type, const float *grad_msg,
-                                              int64_t ld_grad_msg, int32_t num_types, int32_t msg_dim,
-                                              float dropout_p, uint64_t dropout_seed, float *grad_w,
-                                              void *workspace, size_t workspace_bytes, void *stream_) {
+static int weight_grad_launch(const float *x, int64_t ld_x, int32_t state_dim,
+                              const int64_t *const *src_per_type, const int64_t *const *dst_per_type,
+                              const int64_t *edges_per_type, const float *grad_msg, int64_t ld_grad_msg,
+                              int32_t num_types, int32_t msg_dim, float dropout_p, uint64_t dropout_seed,
+                              float *grad_w, void *workspace, size_t workspace_bytes, void *stream_,
+                              bool identity_rows) {
   PTGNN_REQUIRE(num_types >= 0 && state_dim > 0 && msg_dim > 0, PTGNN_AMD_EINVAL, "edge_weight_grad: bad sizes");
   PTGNN_REQUIRE(state_dim % 4 == 0 && msg_dim % 4 == 0, PTGNN_AMD_EUNSUPPORTED,
                 "edge_weight_grad: needs state_dim %% 4 == 0 and msg_dim %% 4 == 0 (got %d, %d)",
@@ -230,8 +234,8 @@ extern "C" int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int3
   PTGNN_REQUIRE(dropout_p == 0.f || dst_per_type == nullptr, PTGNN_AMD_EUNSUPPORTED,
                 "edge_weight_grad: dropout with a target-state half is not a reference configuration");
   if (num_types == 0) return PTGNN_AMD_OK;
-  PTGNN_REQUIRE(x && src_per_type && edges_per_type && grad_msg && grad_w, PTGNN_AMD_EINVAL,
-                "edge_weight_grad: null pointer");
+  PTGNN_REQUIRE(x && (src_per_type || identity_rows) && edges_per_type && grad_msg && grad_w,
+                PTGNN_AMD_EINVAL, "edge_weight_grad: null pointer");
   PTGNN_REQUIRE(ld_x % 4 == 0 && ld_grad_msg % 4 == 0 && ld_grad_msg >= msg_dim && aligned16(x) &&
                     aligned16(grad_msg) && aligned16(grad_w),
                 PTGNN_AMD_EUNSUPPORTED, "edge_weight_grad: rows must be 16-byte aligned");
@@ -258,9 +262,9 @@ extern "C" int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int3
     tab.chunk_off[0] = 0;
     for (int t = 0; t < tab.num_types; ++t) {
       const int64_t n = edges_per_type[t0 + t];
-      PTGNN_REQUIRE(n == 0 || (src_per_type[t0 + t] && (!use_dst || dst_per_type[t0 + t])),
+      PTGNN_REQUIRE(n == 0 || identity_rows || (src_per_type[t0 + t] && (!use_dst || dst_per_type[t0 + t])),
                     PTGNN_AMD_EINVAL, "edge_weight_grad: null table entry for type %d", t0 + t);
-      tab.src[t] = src_per_type[t0 + t];
+      tab.src[t] = identity_rows ? nullptr : src_per_type[t0 + t];
       tab.dst[t] = use_dst ? dst_per_type[t0 + t] : nullptr;
       tab.edge_off[t + 1] = tab.edge_off[t] + n;
       const int64_t chunks = tab.chunk_off[t] + (n + ch - 1) / ch;
@@ -289,4 +293,29 @@ extern "C" int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int3
     chunk_base += tab.chunk_off[tab.num_types];
   }
   return PTGNN_AMD_OK;
+}
+
+extern "C" int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int32_t state_dim,
+                                              const int64_t *const *src_per_type,
+                                              const int64_t *const *dst_per_type,
+                                              const int64_t *edges_per_type, const float *grad_msg,
+                                              int64_t ld_grad_msg, int32_t num_types, int32_t msg_dim,
+                                              float dropout_p, uint64_t dropout_seed, float *grad_w,
+                                              void *workspace, size_t workspace_bytes, void *stream_) {
+  return weight_grad_launch(x, ld_x, state_dim, src_per_type, dst_per_type, edges_per_type, grad_msg,
+                            ld_grad_msg, num_types, msg_dim, dropout_p, dropout_seed, grad_w, workspace,
+                            workspace_bytes, stream_, false);
+}
+
+// grad_w [n_out, k] = grad_y^T [n_out, rows] . x [rows, k]: the same split-row GEMM with the identity
+// row map (nn.Linear / nn.GRUCell weight gradients; rocBLAS runs this long-reduction TN shape at
+// ~23 TFLOP/s on MI355X, profiles/r01_notes.md).
+extern "C" int ptgnn_amd_linear_weight_grad_f32(const float *x, int64_t ld_x, int32_t k,
+                                                const float *grad_y, int64_t ld_grad_y, int64_t rows,
+                                                int32_t n_out, float *grad_w, void *workspace,
+                                                size_t workspace_bytes, void *stream_) {
+  PTGNN_REQUIRE(rows >= 0, PTGNN_AMD_EINVAL, "linear_weight_grad: negative row count");
+  const int64_t counts[1] = {rows};
+  return weight_grad_launch(x, ld_x, k, nullptr, nullptr, counts, grad_y, ld_grad_y, 1, n_out, 0.f, 0,
+                            grad_w, workspace, workspace_bytes, stream_, true);
 }

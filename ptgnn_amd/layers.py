@@ -25,7 +25,7 @@ from typing import Dict, List, Optional, Tuple, Union
 import torch
 from torch import nn
 
-from ptgnn_amd import _lib, ops
+from ptgnn_amd import _lib, dense, ops
 from ptgnn_amd.scatter import (edge_linear as edge_linear_autograd, gather_reduce as gather_reduce_autograd,
                                segment_reduce)
 
@@ -226,15 +226,15 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                                         [l.weight for l in self.__edge_message_transformation_layers],
                                         False, p, _dropout_seed() if p > 0 else 0)
             agg = segment_reduce(msgs, plan, self.__aggregation_fn)
-            return gru(agg, node_states)
+            return dense.gru_cell(gru, agg, node_states)
 
         if self._table_ok(node_states, edge_features):
             # training without per-edge dropout, few edge types: torch (rocBLAS) for the dense blocks so
             # autograd owns them, the HIP kernel (forward + backward) for the aggregation
             w = torch.cat([l.weight for l in self.__edge_message_transformation_layers], dim=0)
-            y = nn.functional.linear(node_states, w)
+            y = dense.linear(node_states, w)
             agg = gather_reduce_autograd(y, None, plan, self._message_dimension, self.__aggregation_fn)
-            return gru(agg, node_states)
+            return dense.gru_cell(gru, agg, node_states)
 
         # general per-edge path (per-edge dropout / edge features): message order = type-major
         all_messages = []
@@ -246,7 +246,7 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
             all_messages.append(lin(self.__dropout(inp)))
         messages = torch.cat(all_messages, dim=0)
         agg = segment_reduce(messages.to(torch.float32), plan, self.__aggregation_fn).to(messages.dtype)
-        return gru(agg, node_states)
+        return dense.gru_cell(gru, agg, node_states)
 
     def forward_sharded(self, node_states: torch.Tensor, shard) -> torch.Tensor:
         """One layer over a dst-range shard (ptgnn_amd/sharded.py): `node_states` are this rank's
@@ -418,7 +418,7 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
                 if self._dense_act is not None and not tanh:
                     x = self._dense_act(x)
             else:
-                x = self._dense(x)
+                x = dense.linear(x, self._dense.weight, self._dense.bias)
                 if self._dense_act is not None:
                     x = self._dense_act(x)
         return self._dropout(x)
@@ -458,7 +458,7 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             parts = [w[:, :H] for w in ws]
             if self.__use_target_state_as_message_input:
                 parts += [w[:, H:2 * H] for w in ws]
-            y = nn.functional.linear(node_states, torch.cat(parts, dim=0))
+            y = dense.linear(node_states, torch.cat(parts, dim=0))
             ysrc = y[:, :T * M]
             ydst = y[:, T * M:] if self.__use_target_state_as_message_input else None
             agg = gather_reduce_autograd(ysrc, ydst, plan, M, self.__aggregation_fn)

@@ -567,6 +567,29 @@ def edge_weight_grad(x: torch.Tensor, adjacency_lists, grad_msg: torch.Tensor, u
     return grad_w
 
 
+def linear_weight_grad(x: torch.Tensor, grad_y: torch.Tensor) -> torch.Tensor:
+    """grad_w [n_out, k] = grad_y^T . x  (weight gradient of y = x W^T), deterministic split-row MFMA GEMM."""
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    _require_cuda_f32("grad_y", grad_y)
+    x, grad_y = _rowmajor(x), _rowmajor(grad_y)
+    rows, k = x.shape
+    n_out = grad_y.shape[1]
+    if grad_y.shape[0] != rows:
+        raise _lib.PtgnnAmdError("linear_weight_grad: x and grad_y row counts differ")
+    if rows == 0:
+        return torch.zeros(n_out, k, dtype=torch.float32, device=x.device)
+    grad_w = torch.empty(n_out, k, dtype=torch.float32, device=x.device)
+    ws_bytes = lib.ptgnn_amd_edge_wgrad_workspace_bytes(rows, 1, n_out, k)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+    with _timed("linear_weight_grad", flops=2.0 * rows * k * n_out, bytes=4.0 * (rows * k + rows * n_out + n_out * k)):
+        rc = lib.ptgnn_amd_linear_weight_grad_f32(x.data_ptr(), _ld(x), k, grad_y.data_ptr(), _ld(grad_y),
+                                                  rows, n_out, grad_w.data_ptr(), ws.data_ptr(), ws_bytes,
+                                                  _stream(grad_w))
+    _lib.check(rc, "ptgnn_amd_linear_weight_grad_f32")
+    return grad_w
+
+
 def segment_spread(grad: torch.Tensor, arg: Optional[torch.Tensor], plan: GraphPlan) -> torch.Tensor:
     """Backward of `segment_reduce` w.r.t. the messages: [N, D] row gradients -> [E, D] in message order
     (max/min: only the recorded winner slot of each (row, column) receives the gradient)."""

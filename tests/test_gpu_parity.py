@@ -782,3 +782,38 @@ def test_pooling_over_sorted_index_matches_oracle(pool):
     else:
         np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=2e-5, atol=2e-4)
     assert float(got[2].abs().sum()) == 0.0                # empty graph -> 0
+
+
+# ------------------------------------------------------------------------------------------------
+# differentiable dense blocks (training): Linear / GRUCell on the HIP kernels vs torch-CPU autograd
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,k,n_out", [(5000, 128, 384), (777, 64, 36), (1, 32, 4), (0, 32, 8)])
+def test_linear_weight_grad_matches_fp64(rows, k, n_out):
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(rows + k)
+    x, gy = torch.randn(rows, k, generator=g), torch.randn(rows, n_out, generator=g)
+    want = (gy.double().t() @ x.double()).float()
+    got = ops.linear_weight_grad(x.cuda(), gy.cuda())
+    assert torch.equal(got, ops.linear_weight_grad(x.cuda(), gy.cuda()))
+    assert float((got.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_dense_linear_and_gru_autograd_match_torch_cpu():
+    from ptgnn_amd import dense
+    torch.manual_seed(5)
+    n, m, h = 3000, 64, 96
+    cell = torch.nn.GRUCell(m, h)
+    lin = torch.nn.Linear(h, 40)
+    a, hx, gout = torch.randn(n, m), torch.randn(n, h), torch.randn(n, 40)
+    a1, h1 = a.clone().requires_grad_(True), hx.clone().requires_grad_(True)
+    lin(cell(a1, h1)).backward(gout)
+    want = [a1.grad, h1.grad] + [p.grad.clone() for p in list(cell.parameters()) + list(lin.parameters())]
+    cell.zero_grad(); lin.zero_grad()
+    cell, lin = cell.cuda(), lin.cuda()
+    a2, h2 = a.cuda().requires_grad_(True), hx.cuda().requires_grad_(True)
+    y = dense.linear(dense.gru_cell(cell, a2, h2), lin.weight, lin.bias)
+    y.backward(gout.cuda())
+    got = [a2.grad, h2.grad] + [p.grad for p in list(cell.parameters()) + list(lin.parameters())]
+    for g_, w_ in zip(got, want):
+        np.testing.assert_allclose(g_.cpu().numpy(), w_.numpy(), rtol=0,
+                                   atol=2e-5 * max(1.0, float(w_.abs().max())))
