@@ -239,12 +239,14 @@ int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int32_t state_d
                                    float dropout_p, uint64_t dropout_seed, float *grad_w,
                                    void *workspace, size_t workspace_bytes, void *stream);
 
-/* Dense form: grad_w [n_out, k] = grad_y^T . x over `rows` rows (autograd of nn.Linear / nn.GRUCell
- * weights, gatedmessagepassing.py:25, mlpmessagepassing.py:60-63).  Workspace:
+/* Dense form: grad_w [n_out, k] = grad_y^T . x over `rows` rows, and (grad_b non-null) the bias
+ * gradient grad_b [n_out] = column sums of grad_y from the same pass (autograd of nn.Linear /
+ * nn.GRUCell parameters, gatedmessagepassing.py:25, mlpmessagepassing.py:60-63).  Workspace:
  * ptgnn_amd_edge_wgrad_workspace_bytes(rows, 1, n_out, k). */
 int ptgnn_amd_linear_weight_grad_f32(const float *x, int64_t ld_x, int32_t k, const float *grad_y,
                                      int64_t ld_grad_y, int64_t rows, int32_t n_out, float *grad_w,
-                                     void *workspace, size_t workspace_bytes, void *stream);
+                                     float *grad_b /* nullable */, void *workspace,
+                                     size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Backward of the segment reduce w.r.t. the message matrix (the autograd torch_scatter supplies

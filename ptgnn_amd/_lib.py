@@ -40,7 +40,7 @@ SIGNATURES = {
     "ptgnn_amd_edge_wgrad_workspace_bytes": (_c.c_size_t, [_i64, _i32, _i32, _i32]),
     "ptgnn_amd_edge_weight_grad_f32": (_c.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                                   _c.c_float, _c.c_uint64, _vp, _vp, _c.c_size_t, _vp]),
-    "ptgnn_amd_linear_weight_grad_f32": (_c.c_int, [_vp, _i64, _i32, _vp, _i64, _i64, _i32, _vp, _vp,
+    "ptgnn_amd_linear_weight_grad_f32": (_c.c_int, [_vp, _i64, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _vp,
                                                     _c.c_size_t, _vp]),
     "ptgnn_amd_segment_spread_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "ptgnn_amd_gru_cell_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,

@@ -34,11 +34,14 @@ struct WgradTable {
   int32_t num_types;
 };
 
-template <bool DROP>
+// COLSUM: additionally emit the column sums of d_msg (= the bias gradient of a dense Linear) from the
+// A tiles already in LDS, for the k-tile-0 workgroups.
+template <bool DROP, bool COLSUM>
 __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
     WgradTable tab, const float *__restrict__ x, int64_t ld_x, int H, int use_dst,
     const float *__restrict__ gm, int64_t ld_gm, int M, int64_t gm_row_base, int chunk_edges,
-    int mtiles, int ktiles, float *__restrict__ partial, int chunk_base, DropoutParams drop) {
+    int mtiles, int ktiles, float *__restrict__ partial, int chunk_base, DropoutParams drop,
+    float *__restrict__ colsum_partial) {
   __shared__ __attribute__((aligned(16))) float As[STEP * WG_LD];
   __shared__ __attribute__((aligned(16))) float Bs[STEP * WG_LD];
 
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
   WG_LOAD_ROWS(0);
   if (nsteps > 1) WG_LOAD_IDX(1);
 
+  float colsum = 0.f;
   for (int s = 0; s < nsteps; ++s) {
     __syncthreads();
     WG_STORE(s, 0, va0, vb0); WG_STORE(s, 1, va1, vb1);
@@ -138,6 +142,17 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
     if (s + 1 < nsteps) {
       WG_LOAD_ROWS(s + 1);
       if (s + 2 < nsteps) WG_LOAD_IDX(s + 2);
+    }
+    if constexpr (COLSUM) {
+      if (kt == 0 && threadIdx.x < 128) {
+        float cs0 = 0.f, cs1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < STEP; e += 2) {
+          cs0 += As[e * WG_LD + threadIdx.x];
+          cs1 += As[(e + 1) * WG_LD + threadIdx.x];
+        }
+        colsum += cs0 + cs1;
+      }
     }
     const float *ap = As + hi * WG_LD + wm * 64 + li;
     const float *bp = Bs + hi * WG_LD + wn * 64 + li;
@@ -161,6 +176,10 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
 #undef WG_LOAD_ROW
 #undef WG_LOAD_ROWS
 #undef WG_STORE
+  if constexpr (COLSUM) {
+    if (kt == 0 && threadIdx.x < 128)
+      colsum_partial[((int64_t)(chunk_base + chunk) * mtiles + mt) * 128 + threadIdx.x] = colsum;
+  }
   // partial tile: [128 m][128 k] floats; C fragment (i, j): row = (r & 3) + 8 (r >> 2) + 4 hi, col = li
   float *const out = partial + ((int64_t)(chunk_base + chunk) * tiles_per_chunk + rem) * kTile;
 #pragma unroll
@@ -174,26 +193,51 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
       }
 }
 
-// grad_w[t][m][k .. k+3] = sum over the type's chunks (ascending) of the partial tiles
+// grad_w[t][m][k .. k+3] = sum of the type's partial tiles.  Eight lanes share one output float4: lane
+// `sub` adds chunks sub, sub+8, ... in ascending order, then the eight sums meet in a fixed xor
+// butterfly -- a fixed summation order, so the result is bit-identical run to run.
+constexpr int kSplit = 8;
 __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradTable tab, const float *__restrict__ partial,
                                                       int chunk_base, int mtiles, int ktiles, int M,
                                                       int K, float *__restrict__ grad_w, int type_base) {
   const int kq = K / 4;
   const int64_t per_type = (int64_t)M * kq;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= per_type * tab.num_types) return;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = gid / kSplit;
+  const int sub = (int)(gid % kSplit);
+  if (i >= per_type * tab.num_types) return;      // whole 8-lane groups leave together
   const int t = (int)(i / per_type);
   const int rem = (int)(i % per_type);
   const int m = rem / kq, k = (rem % kq) * 4;
   const int tiles_per_chunk = mtiles * ktiles;
   const int64_t off = (int64_t)((m >> 7) * ktiles + (k >> 7)) * kTile + (m & 127) * 128 + (k & 127);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int c = tab.chunk_off[t]; c < tab.chunk_off[t + 1]; ++c) {
+  for (int c = tab.chunk_off[t] + sub; c < tab.chunk_off[t + 1]; c += kSplit) {
     const float4 p = *reinterpret_cast<const float4 *>(
         partial + (int64_t)(chunk_base + c) * tiles_per_chunk * kTile + off);
     s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
   }
-  *reinterpret_cast<float4 *>(grad_w + ((int64_t)(type_base + t) * M + m) * K + k) = s;
+#pragma unroll
+  for (int d = 1; d < kSplit; d <<= 1) {
+    s.x += __shfl_xor(s.x, d); s.y += __shfl_xor(s.y, d);
+    s.z += __shfl_xor(s.z, d); s.w += __shfl_xor(s.w, d);
+  }
+  if (sub == 0) *reinterpret_cast<float4 *>(grad_w + ((int64_t)(type_base + t) * M + m) * K + k) = s;
+}
+
+// grad_b[m] = sum over chunks of the column-sum partials (dense form: one "type")
+__global__ __launch_bounds__(256) void k_colsum_reduce(const float *__restrict__ colsum_partial,
+                                                       int num_chunks, int mtiles, int M,
+                                                       float *__restrict__ grad_b) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int m = gid / kSplit, sub = gid % kSplit;
+  if (m >= M) return;
+  float s = 0.f;
+  for (int c = sub; c < num_chunks; c += kSplit)
+    s += colsum_partial[((int64_t)c * mtiles + (m >> 7)) * 128 + (m & 127)];
+#pragma unroll
+  for (int d = 1; d < kSplit; d <<= 1) s += __shfl_xor(s, d);
+  if (sub == 0) grad_b[m] = s;
 }
 
 // Edges per chunk: aim at ~1024 workgroups (4 per CU on 256 CUs) so the partial-tile traffic
@@ -217,7 +261,7 @@ extern "C" size_t ptgnn_amd_edge_wgrad_workspace_bytes(int64_t num_edges, int32_
   const int mtiles = (msg_dim + 127) / 128, ktiles = (in_dim + 127) / 128;
   const int ch = chunk_edges_for(num_edges, mtiles, ktiles);
   const int64_t chunks = num_edges / ch + num_types;   // upper bound of sum_t ceil(E_t / ch)
-  return (size_t)chunks * mtiles * ktiles * kTile * sizeof(float);
+  return (size_t)chunks * mtiles * (ktiles * kTile + 128) * sizeof(float);   // tiles + column-sum partials
 }
 
 static int weight_grad_launch(const float *x, int64_t ld_x, int32_t state_dim,
@@ -225,7 +269,7 @@ static int weight_grad_launch(const float *x, int64_t ld_x, int32_t state_dim,
                               const int64_t *edges_per_type, const float *grad_msg, int64_t ld_grad_msg,
                               int32_t num_types, int32_t msg_dim, float dropout_p, uint64_t dropout_seed,
                               float *grad_w, void *workspace, size_t workspace_bytes, void *stream_,
-                              bool identity_rows) {
+                              bool identity_rows, float *grad_b) {
   PTGNN_REQUIRE(num_types >= 0 && state_dim > 0 && msg_dim > 0, PTGNN_AMD_EINVAL, "edge_weight_grad: bad sizes");
   PTGNN_REQUIRE(state_dim % 4 == 0 && msg_dim % 4 == 0, PTGNN_AMD_EUNSUPPORTED,
                 "edge_weight_grad: needs state_dim %% 4 == 0 and msg_dim %% 4 == 0 (got %d, %d)",
@@ -251,10 +295,13 @@ static int weight_grad_launch(const float *x, int64_t ld_x, int32_t state_dim,
   PTGNN_REQUIRE(workspace_bytes >= ptgnn_amd_edge_wgrad_workspace_bytes(E, num_types, msg_dim, K) &&
                     (E == 0 || workspace),
                 PTGNN_AMD_EINVAL, "edge_weight_grad: workspace too small (%zu bytes)", workspace_bytes);
+  PTGNN_REQUIRE(!grad_b || (identity_rows && num_types == 1 && dropout_p == 0.f), PTGNN_AMD_EINVAL,
+                "edge_weight_grad: column sums are a dense-form output");
   const DropoutParams drop = make_dropout(dropout_p, dropout_seed, state_dim);
   hipStream_t st = (hipStream_t)stream_;
   int64_t row_base = 0;
   int64_t chunk_base = 0;
+  const int64_t total_chunk_bound = E / ch + num_types;   // as in ptgnn_amd_edge_wgrad_workspace_bytes
   for (int t0 = 0; t0 < num_types; t0 += kMaxTypesW) {
     WgradTable tab;
     tab.num_types = (num_types - t0 < kMaxTypesW) ? (num_types - t0) : kMaxTypesW;
@@ -275,17 +322,25 @@ static int weight_grad_launch(const float *x, int64_t ld_x, int32_t state_dim,
     const int64_t total = (int64_t)tab.chunk_off[tab.num_types] * mtiles * ktiles;
     if (total > 0) {
       const unsigned grid = (unsigned)xcd_padded_blocks(total);
-      if (drop.thr != 0)
-        k_edge_wgrad<true><<<grid, 256, 0, st>>>(tab, x, ld_x, state_dim, use_dst, grad_msg, ld_grad_msg,
-                                                 msg_dim, row_base, ch, mtiles, ktiles,
-                                                 (float *)workspace, (int)chunk_base, drop);
-      else
-        k_edge_wgrad<false><<<grid, 256, 0, st>>>(tab, x, ld_x, state_dim, use_dst, grad_msg, ld_grad_msg,
-                                                  msg_dim, row_base, ch, mtiles, ktiles,
-                                                  (float *)workspace, (int)chunk_base, drop);
+      float *const colsum_ws = (float *)workspace + total_chunk_bound * mtiles * ktiles * kTile;
+#define PTGNN_WGRAD_LAUNCH(DROP, COLSUM)                                                              \
+  k_edge_wgrad<DROP, COLSUM><<<grid, 256, 0, st>>>(tab, x, ld_x, state_dim, use_dst, grad_msg,         \
+                                                   ld_grad_msg, msg_dim, row_base, ch, mtiles, ktiles, \
+                                                   (float *)workspace, (int)chunk_base, drop, colsum_ws)
+      if (grad_b) PTGNN_WGRAD_LAUNCH(false, true);
+      else if (drop.thr != 0) PTGNN_WGRAD_LAUNCH(true, false);
+      else PTGNN_WGRAD_LAUNCH(false, false);
+#undef PTGNN_WGRAD_LAUNCH
       PTGNN_LAUNCH_CHECK();
+      if (grad_b) {
+        k_colsum_reduce<<<(unsigned)((msg_dim * kSplit + 255) / 256), 256, 0, st>>>(
+            colsum_ws, tab.chunk_off[tab.num_types], mtiles, msg_dim, grad_b);
+        PTGNN_LAUNCH_CHECK();
+      }
+    } else if (grad_b) {
+      PTGNN_HIP(hipMemsetAsync(grad_b, 0, sizeof(float) * msg_dim, st));
     }
-    const int64_t outs = (int64_t)tab.num_types * msg_dim * (K / 4);
+    const int64_t outs = (int64_t)tab.num_types * msg_dim * (K / 4) * kSplit;
     k_wgrad_reduce<<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(
         tab, (const float *)workspace, (int)chunk_base, mtiles, ktiles, msg_dim, K, grad_w, t0);
     PTGNN_LAUNCH_CHECK();
@@ -304,7 +359,7 @@ extern "C" int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int3
                                               void *workspace, size_t workspace_bytes, void *stream_) {
   return weight_grad_launch(x, ld_x, state_dim, src_per_type, dst_per_type, edges_per_type, grad_msg,
                             ld_grad_msg, num_types, msg_dim, dropout_p, dropout_seed, grad_w, workspace,
-                            workspace_bytes, stream_, false);
+                            workspace_bytes, stream_, false, nullptr);
 }
 
 // grad_w [n_out, k] = grad_y^T [n_out, rows] . x [rows, k]: the same split-row GEMM with the identity
@@ -312,10 +367,10 @@ extern "C" int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int3
 // ~23 TFLOP/s on MI355X, profiles/r01_notes.md).
 extern "C" int ptgnn_amd_linear_weight_grad_f32(const float *x, int64_t ld_x, int32_t k,
                                                 const float *grad_y, int64_t ld_grad_y, int64_t rows,
-                                                int32_t n_out, float *grad_w, void *workspace,
-                                                size_t workspace_bytes, void *stream_) {
+                                                int32_t n_out, float *grad_w, float *grad_b,
+                                                void *workspace, size_t workspace_bytes, void *stream_) {
   PTGNN_REQUIRE(rows >= 0, PTGNN_AMD_EINVAL, "linear_weight_grad: negative row count");
   const int64_t counts[1] = {rows};
   return weight_grad_launch(x, ld_x, k, nullptr, nullptr, counts, grad_y, ld_grad_y, 1, n_out, 0.f, 0,
-                            grad_w, workspace, workspace_bytes, stream_, true);
+                            grad_w, workspace, workspace_bytes, stream_, true, grad_b);
 }

@@ -35,9 +35,11 @@ class _Linear(torch.autograd.Function):
         d_x = d_w = d_b = None
         if ctx.needs_input_grad[0]:
             d_x = ops.linear(g, weight.detach().t().contiguous())
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            d_w = ops.linear_weight_grad(x, g)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            res = ops.linear_weight_grad(x, g, want_bias=want_b)      # bias gradient rides the same pass
+            d_w, d_b = res if want_b else (res, None)
+        elif want_b:
             d_b = g.sum(dim=0)
         return d_x, d_w, d_b
 
@@ -55,6 +57,9 @@ def gru_cell(cell: torch.nn.GRUCell, a: torch.Tensor, h: torch.Tensor) -> torch.
     kernels, the gate non-linearities through torch's fused pointwise GRU op and its autograd."""
     if not (_kernel_dims_ok(a, cell.weight_ih) and _kernel_dims_ok(h, cell.weight_hh) and cell.bias):
         return cell(a, h)
-    gi = _Linear.apply(a, cell.weight_ih, None)
-    gh = _Linear.apply(h, cell.weight_hh, None)
-    return torch.ops.aten._thnn_fused_gru_cell(gi, gh, h, cell.bias_ih, cell.bias_hh)[0]
+    # biases go into the gate GEMMs (fused epilogue forward, column sums of the weight-gradient pass
+    # backward): the gate math  r, z = sigmoid(gi + gh),  n = tanh(gi_n + r * gh_n)  is unchanged because
+    # b_hn sits inside the r * (.) product either way (torch.nn.GRUCell definition)
+    gi = _Linear.apply(a, cell.weight_ih, cell.bias_ih)
+    gh = _Linear.apply(h, cell.weight_hh, cell.bias_hh)
+    return torch.ops.aten._thnn_fused_gru_cell(gi, gh, h, None, None)[0]

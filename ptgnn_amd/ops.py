@@ -567,8 +567,9 @@ def edge_weight_grad(x: torch.Tensor, adjacency_lists, grad_msg: torch.Tensor, u
     return grad_w
 
 
-def linear_weight_grad(x: torch.Tensor, grad_y: torch.Tensor) -> torch.Tensor:
-    """grad_w [n_out, k] = grad_y^T . x  (weight gradient of y = x W^T), deterministic split-row MFMA GEMM."""
+def linear_weight_grad(x: torch.Tensor, grad_y: torch.Tensor, want_bias: bool = False):
+    """grad_w [n_out, k] = grad_y^T . x  (weight gradient of y = x W^T), deterministic split-row MFMA GEMM;
+    with `want_bias` also grad_b [n_out] = column sums of grad_y from the same pass -> (grad_w, grad_b)."""
     lib = _lib.load()
     _require_cuda_f32("x", x)
     _require_cuda_f32("grad_y", grad_y)
@@ -578,16 +579,19 @@ def linear_weight_grad(x: torch.Tensor, grad_y: torch.Tensor) -> torch.Tensor:
     if grad_y.shape[0] != rows:
         raise _lib.PtgnnAmdError("linear_weight_grad: x and grad_y row counts differ")
     if rows == 0:
-        return torch.zeros(n_out, k, dtype=torch.float32, device=x.device)
+        gw = torch.zeros(n_out, k, dtype=torch.float32, device=x.device)
+        return (gw, torch.zeros(n_out, dtype=torch.float32, device=x.device)) if want_bias else gw
     grad_w = torch.empty(n_out, k, dtype=torch.float32, device=x.device)
+    grad_b = torch.empty(n_out, dtype=torch.float32, device=x.device) if want_bias else None
     ws_bytes = lib.ptgnn_amd_edge_wgrad_workspace_bytes(rows, 1, n_out, k)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
     with _timed("linear_weight_grad", flops=2.0 * rows * k * n_out, bytes=4.0 * (rows * k + rows * n_out + n_out * k)):
         rc = lib.ptgnn_amd_linear_weight_grad_f32(x.data_ptr(), _ld(x), k, grad_y.data_ptr(), _ld(grad_y),
-                                                  rows, n_out, grad_w.data_ptr(), ws.data_ptr(), ws_bytes,
-                                                  _stream(grad_w))
+                                                  rows, n_out, grad_w.data_ptr(),
+                                                  grad_b.data_ptr() if want_bias else None,
+                                                  ws.data_ptr(), ws_bytes, _stream(grad_w))
     _lib.check(rc, "ptgnn_amd_linear_weight_grad_f32")
-    return grad_w
+    return (grad_w, grad_b) if want_bias else grad_w
 
 
 def segment_spread(grad: torch.Tensor, arg: Optional[torch.Tensor], plan: GraphPlan) -> torch.Tensor:

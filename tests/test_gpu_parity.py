@@ -793,9 +793,11 @@ def test_linear_weight_grad_matches_fp64(rows, k, n_out):
     g = torch.Generator().manual_seed(rows + k)
     x, gy = torch.randn(rows, k, generator=g), torch.randn(rows, n_out, generator=g)
     want = (gy.double().t() @ x.double()).float()
-    got = ops.linear_weight_grad(x.cuda(), gy.cuda())
+    got, got_b = ops.linear_weight_grad(x.cuda(), gy.cuda(), want_bias=True)
     assert torch.equal(got, ops.linear_weight_grad(x.cuda(), gy.cuda()))
     assert float((got.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    want_b = gy.double().sum(0).float()
+    assert float((got_b.cpu() - want_b).abs().max()) <= 1e-5 * max(1.0, float(want_b.abs().max()))
 
 
 def test_dense_linear_and_gru_autograd_match_torch_cpu():
