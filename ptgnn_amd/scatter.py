@@ -56,9 +56,8 @@ def segment_reduce(messages: torch.Tensor, plan: "ops.GraphPlan", reduce: str) -
     return _SegmentReduce.apply(messages, plan, reduce)
 
 
-def scatter(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional[torch.Tensor] = None,
-            dim_size: Optional[int] = None, reduce: str = "sum") -> torch.Tensor:
-    """torch_scatter.scatter for the layout the ptgnn hot path uses: 2-D (or 1-D) `src`, 1-D int64
+def _prepare(src: torch.Tensor, index: torch.Tensor, dim: int, out, dim_size):
+    """Common argument handling of the torch_scatter-shaped entry points: 2-D (or 1-D) `src`, 1-D int64
     `index` along dim 0.  Anything else raises (no silent fallback)."""
     if out is not None:
         raise _lib.PtgnnAmdError("ptgnn_amd.scatter: the `out=` form is not supported")
@@ -72,10 +71,101 @@ def scatter(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional
                                  f"dim 0 (got src {tuple(src.shape)}, index {tuple(index.shape)}, dim {dim})")
     if dim_size is None:
         dim_size = int(index.max()) + 1 if index.numel() > 0 else 0
-    dt = src.dtype
-    # torch_scatter semantics: a plan whose "source" column is unused; (index, index) gives dst=index
+    # torch_scatter semantics: a plan whose "source" column is unused; (index, index) gives dst = index
     plan = ops.build_plan([(index, index)], int(dim_size))
-    res = segment_reduce(src.to(torch.float32), plan, reduce).to(dt)
+    return src, squeeze, plan
+
+
+def scatter(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional[torch.Tensor] = None,
+            dim_size: Optional[int] = None, reduce: str = "sum") -> torch.Tensor:
+    """torch_scatter.scatter for the layout the ptgnn hot path uses (abstractmessagepassing.py:44-50,
+    pna_aggregation.py:28-45, varsizedsummary.py:35)."""
+    src2, squeeze, plan = _prepare(src, index, dim, out, dim_size)
+    res = segment_reduce(src2.to(torch.float32), plan, reduce).to(src.dtype)
+    return res.squeeze(1) if squeeze else res
+
+
+def scatter_sum(src, index, dim: int = -1, out=None, dim_size: Optional[int] = None) -> torch.Tensor:
+    """torch_scatter.scatter_sum (varsizedsummary.py:59,76,108,174; selfattmessagepassing.py:61)."""
+    return scatter(src, index, dim, out, dim_size, "sum")
+
+
+scatter_add = scatter_sum
+
+
+def scatter_mean(src, index, dim: int = -1, out=None, dim_size: Optional[int] = None) -> torch.Tensor:
+    """torch_scatter.scatter_mean (graphnorm.py:36-41)."""
+    return scatter(src, index, dim, out, dim_size, "mean")
+
+
+def _scatter_minmax(src, index, dim, out, dim_size, reduce):
+    src2, squeeze, plan = _prepare(src, index, dim, out, dim_size)
+    x = src2.to(torch.float32)
+    res = segment_reduce(x, plan, reduce).to(src.dtype)
+    E = x.shape[0]
+    with torch.no_grad():   # torch_scatter's arg_out: position of the winner in `src`, E for empty segments
+        if E == 0:
+            arg = torch.zeros(plan.num_nodes, x.shape[1], dtype=torch.int64, device=x.device)
+        else:
+            _, slot = ops.gather_reduce(x.detach(), plan, x.shape[1], reduce, return_arg=True, type_bits=0,
+                                        col=plan.perm)
+            pos = plan.perm[:E].to(torch.int64)[slot.clamp(min=0).to(torch.int64)]
+            arg = torch.where(slot >= 0, pos, torch.full_like(pos, E))
+    if squeeze:
+        res, arg = res.squeeze(1), arg.squeeze(1)
+    return res, arg
+
+
+def scatter_max(src, index, dim: int = -1, out=None, dim_size: Optional[int] = None):
+    """torch_scatter.scatter_max -> (values, argmax) (varmisuse.py:86)."""
+    return _scatter_minmax(src, index, dim, out, dim_size, "max")
+
+
+def scatter_min(src, index, dim: int = -1, out=None, dim_size: Optional[int] = None):
+    return _scatter_minmax(src, index, dim, out, dim_size, "min")
+
+
+class _GatherRows(torch.autograd.Function):
+    """x[index] with the HIP row gather; backward = the HIP segment-sum over the index's plan."""
+
+    @staticmethod
+    def forward(ctx, x, index, plan):
+        ctx.plan = plan
+        return ops.gather_rows(x, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.segment_reduce(g.contiguous(), ctx.plan, "sum"), None, None
+
+
+def scatter_log_softmax(src, index, dim: int = -1, eps: float = 1e-12,
+                        dim_size: Optional[int] = None) -> torch.Tensor:
+    """torch_scatter.composite.scatter_log_softmax (varsizedsummary.py:57,106,158; varmisuse.py:79;
+    grucopydecoder.py:100):  src - max_seg - log(sum_seg exp(src - max_seg) + eps)."""
+    src2, squeeze, plan = _prepare(src, index, dim, None, dim_size)
+    x = src2.to(torch.float32)
+    if x.shape[0] == 0:
+        return src.clone()
+    with torch.no_grad():   # the shift is a constant of the (shift-invariant) function
+        shift = ops.gather_rows(ops.segment_reduce(x.detach(), plan, "max"), index)
+    rec = x - shift
+    total = segment_reduce(rec.exp(), plan, "sum")
+    res = (rec - _GatherRows.apply((total + eps).log(), index, plan)).to(src.dtype)
+    return res.squeeze(1) if squeeze else res
+
+
+def scatter_softmax(src, index, dim: int = -1, eps: float = 1e-12,
+                    dim_size: Optional[int] = None) -> torch.Tensor:
+    """torch_scatter.composite.scatter_softmax:  exp(src - max_seg) / (sum_seg exp(src - max_seg) + eps)."""
+    src2, squeeze, plan = _prepare(src, index, dim, None, dim_size)
+    x = src2.to(torch.float32)
+    if x.shape[0] == 0:
+        return src.clone()
+    with torch.no_grad():
+        shift = ops.gather_rows(ops.segment_reduce(x.detach(), plan, "max"), index)
+    e = (x - shift).exp()
+    total = segment_reduce(e, plan, "sum")
+    res = (e / (_GatherRows.apply(total, index, plan) + eps)).to(src.dtype)
     return res.squeeze(1) if squeeze else res
 
 
