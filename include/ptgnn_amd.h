@@ -178,6 +178,20 @@ int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int64_t ld_x, 
                          void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Minibatch assembly on the device (GraphNeuralNetworkModel.extend_minibatch_with / finalize_minibatch,
+ * graphneuralnetwork.py:386-493: per-graph `adj + nodes_in_mb_so_far`, np.concatenate, int64 tensors,
+ * the node_to_graph_idx generator at :440-443): one launch turns the RAW per-graph int32 arrays
+ * (one staging buffer) into every int64 index tensor of the minibatch.
+ *   out[i] = (i < n_in ? in[i] : 0) + seg_add[s]   for  seg_start[s] <= i < seg_start[s+1]
+ *   in int32 [n_in] device; seg_start int64 [num_segments + 1] (seg_start[0] = 0, last = n_out),
+ *   seg_add int64 [num_segments]; out int64 [n_out].  Elements past n_in are "fill" segments
+ *   (node_to_graph_idx, reference_node_graph_idx).  Bit-exact integer work.
+ * ---------------------------------------------------------------------------------------- */
+int ptgnn_amd_batch_offsets_i64(const int32_t *in, int64_t n_in, const int64_t *seg_start,
+                                const int64_t *seg_add, int32_t num_segments, int64_t n_out,
+                                int64_t *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-edge message GEMM, every edge type in ONE launch (grouped GEMM with gathered A rows):
  *   msg[off_t + e, :] = act( [ x[src_t[e], :] ; x[dst_t[e], :] (if dst_per_type) ] W_t^T ),  e < E_t
  * rows in the reference's message order (type-major, then edge order) = the matrix

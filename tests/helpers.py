@@ -136,3 +136,26 @@ def dropout_keep_scale(seed: int, num_rows: int, width: int, p: float) -> torch.
     keep[:, 1::2] = (h >> np.uint32(16)) >= thr
     scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
     return torch.from_numpy(keep.astype(np.float32) * scale)
+
+
+def golden_batcher_graphs(g):
+    """The tensorized graphs of tests/golden/batcher.npz as (adjacency_lists, num_nodes, reference_nodes)."""
+    T0 = len(g["edge_type_order"])
+    graphs = []
+    for gi in range(int(g["num_graphs_in"])):
+        refs = {k.split(".")[-1]: g[k] for k in g.files if k.startswith(f"g{gi}.ref.")}
+        graphs.append(([(g[f"g{gi}.adj.{t}.src"], g[f"g{gi}.adj.{t}.dst"]) for t in range(T0)],
+                       int(g[f"g{gi}.num_nodes"]), refs))
+    return T0, graphs
+
+
+def replay_minibatches(builder_cls, T0, graphs, stop_after, finalize):
+    """The reference's minibatch loop (abstractneuralmodel.py:290-319) over a MinibatchBuilder."""
+    out, b = [], builder_cls(T0, stop_after)
+    for adj, n, refs in graphs:
+        if not b.extend(adj, n, refs):
+            out.append(finalize(b))
+            b = builder_cls(T0, stop_after)
+    if len(b):
+        out.append(finalize(b))
+    return out

@@ -968,3 +968,67 @@ def test_dense_linear_and_gru_autograd_match_torch_cpu():
     for g_, w_ in zip(got, want):
         np.testing.assert_allclose(g_.cpu().numpy(), w_.numpy(), rtol=0,
                                    atol=2e-5 * max(1.0, float(w_.abs().max())))
+
+
+# ------------------------------------------------------------------------------------------------
+# device-side minibatch assembly (graphneuralnetwork.py:386-493) -- integer work, bit-exact
+# ------------------------------------------------------------------------------------------------
+def test_minibatch_builder_matches_reference_golden_bit_exact():
+    from helpers import golden_batcher_graphs, replay_minibatches
+    from ptgnn_amd.batching import MinibatchBuilder
+    g = load_golden("batcher")
+    T0, graphs = golden_batcher_graphs(g)
+    mbs = replay_minibatches(MinibatchBuilder, T0, graphs, int(g["stop_after"]), lambda b: b.finalize("cuda"))
+    assert len(mbs) == int(g["num_minibatches"])
+    for bi, mb in enumerate(mbs):
+        assert mb["num_graphs"] == int(g[f"mb{bi}.num_graphs"])
+        assert mb["node_to_graph_idx"].dtype == torch.int64 and mb["node_to_graph_idx"].is_cuda
+        np.testing.assert_array_equal(mb["node_to_graph_idx"].cpu().numpy(), g[f"mb{bi}.node_to_graph_idx"])
+        for t in range(T0):
+            s, d = mb["adjacency_lists"][t]
+            assert s.dtype == torch.int64 and d.dtype == torch.int64
+            np.testing.assert_array_equal(s.cpu().numpy(), g[f"mb{bi}.adj.{t}.src"])
+            np.testing.assert_array_equal(d.cpu().numpy(), g[f"mb{bi}.adj.{t}.dst"])
+        for k in mb["reference_node_ids"]:
+            np.testing.assert_array_equal(mb["reference_node_ids"][k].cpu().numpy(), g[f"mb{bi}.ref_ids.{k}"])
+            np.testing.assert_array_equal(mb["reference_node_graph_idx"][k].cpu().numpy(),
+                                          g[f"mb{bi}.ref_gidx.{k}"])
+
+
+def test_minibatch_builder_large_batch_equals_oracle_and_feeds_the_layers():
+    """Graph2Class-sized batch (48 graphs, T0 = 8): device assembly == the oracle's restatement of the
+    reference batcher bit for bit, and its tensors drive a layer directly."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L
+    from ptgnn_amd.batching import MinibatchBuilder
+    rng = np.random.RandomState(7)
+    T0, graphs = 8, []
+    for _ in range(48):
+        n = int(rng.randint(1500, 3500))
+        adj = []
+        for t in range(T0):
+            e = int(rng.randint(0, 2 * n)) if t != 5 else 0          # one edge type with no edges at all
+            adj.append((rng.randint(0, n, e).astype(np.int32), rng.randint(0, n, e).astype(np.int32)))
+        graphs.append({"num_nodes": n, "adjacency_lists": adj,
+                       "reference_nodes": {"supernodes": rng.randint(0, n, 20).astype(np.int32)}})
+    total = sum(gr["num_nodes"] for gr in graphs)
+    (want,) = list(O.batch_graphs(graphs, T0, total))         # the node budget is hit by the last graph
+    b = MinibatchBuilder(T0, total)
+    for i, gr in enumerate(graphs):
+        assert b.extend(gr["adjacency_lists"], gr["num_nodes"], gr["reference_nodes"]) == (i < 47)
+    mb = b.finalize("cuda")
+    assert mb["num_graphs"] == want["num_graphs"] == 48
+    np.testing.assert_array_equal(mb["node_to_graph_idx"].cpu().numpy(), want["node_to_graph_idx"].numpy())
+    for t in range(T0):
+        for side in (0, 1):
+            np.testing.assert_array_equal(mb["adjacency_lists"][t][side].cpu().numpy(),
+                                          want["adjacency_lists"][t][side].numpy())
+    for k in ("reference_node_ids", "reference_node_graph_idx"):
+        np.testing.assert_array_equal(mb[k]["supernodes"].cpu().numpy(), want[k]["supernodes"].numpy())
+    off = np.concatenate([[0], np.cumsum([gr["num_nodes"] for gr in graphs])])
+    N = int(off[-1])
+    layer = L.GatedMessagePassingLayer(32, 32, T0, "sum").cuda().eval()
+    with torch.no_grad():
+        y = layer(torch.randn(N, 32, device="cuda"), mb["adjacency_lists"], mb["node_to_graph_idx"], {}, {},
+                  empty_feats(mb["adjacency_lists"], "cuda"))
+    assert tuple(y.shape) == (N, 32) and bool(torch.isfinite(y).all())

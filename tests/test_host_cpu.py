@@ -134,3 +134,41 @@ def test_product_package_never_imports_the_oracle():
     for f in pathlib.Path(ROOT, "ptgnn_amd").rglob("*.py"):
         src = f.read_text()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_minibatch_builder_host_packing_matches_reference_golden():
+    """The host half of the device batcher (segment table + staging order), evaluated with the kernel's
+    formula in numpy, reproduces the reference's finalize_minibatch layout bit for bit."""
+    import numpy as np
+    from conftest import load_golden
+    from helpers import golden_batcher_graphs, replay_minibatches
+    from ptgnn_amd.batching import MinibatchBuilder
+    g = load_golden("batcher")
+    T0, graphs = golden_batcher_graphs(g)
+    packs = replay_minibatches(MinibatchBuilder, T0, graphs, int(g["stop_after"]), lambda b: b.pack())
+    assert len(packs) == int(g["num_minibatches"])
+    for bi, pk in enumerate(packs):
+        vals = pk.evaluate_on_host()
+        assert vals.dtype == np.int64 and pk.num_graphs == int(g[f"mb{bi}.num_graphs"])
+
+        def view(name):
+            b, e = pk.layout[name]
+            return vals[b:e]
+        np.testing.assert_array_equal(view("node_to_graph_idx"), g[f"mb{bi}.node_to_graph_idx"])
+        for t in range(T0):
+            np.testing.assert_array_equal(view(f"adj.{t}.src"), g[f"mb{bi}.adj.{t}.src"])
+            np.testing.assert_array_equal(view(f"adj.{t}.dst"), g[f"mb{bi}.adj.{t}.dst"])
+        for k in ("supernodes", "slot"):
+            np.testing.assert_array_equal(view(f"ref_ids.{k}"), g[f"mb{bi}.ref_ids.{k}"])
+            np.testing.assert_array_equal(view(f"ref_gidx.{k}"), g[f"mb{bi}.ref_gidx.{k}"])
+
+
+def test_minibatch_builder_refuses_cpu():
+    import numpy as np
+    import pytest
+    from ptgnn_amd import _lib
+    from ptgnn_amd.batching import MinibatchBuilder
+    b = MinibatchBuilder(1)
+    b.extend([(np.zeros(2, np.int32), np.ones(2, np.int32))], 3, {})
+    with pytest.raises(_lib.PtgnnAmdError):
+        b.finalize("cpu")
