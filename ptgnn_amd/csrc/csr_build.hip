@@ -39,6 +39,34 @@ struct TypeTable {
 // mode 1: rows = src,            payload = (dst << type_bits) | type   (transposed plan)
 // mode 2: rows = src * T + type, payload = dst                         (backward of the message table:
 //         row r of the [N*T, M] gradient view sums the output gradients of its out-edges)
+struct EdgeRec {
+  uint32_t key;
+  int32_t packed;
+};
+
+// edge e of the type-major concatenation -> (plan row, col payload)
+__device__ __forceinline__ EdgeRec edge_record(const TypeTable &tab, int64_t e, int32_t type_bits, int mode,
+                                               int total_types) {
+  int lo = 0, hi = tab.num_types;   // binary search for the type (<= 6 steps; table lives in SGPRs)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tab.offset[mid] <= e) lo = mid; else hi = mid;
+  }
+  const int64_t i = e - tab.offset[lo];
+  int64_t s = tab.src[lo][i], d = tab.dst[lo][i];
+  const int64_t ty = tab.type_base + lo;
+  EdgeRec r;
+  if (mode == 2) {
+    r.key = (uint32_t)(s * total_types + ty);
+    r.packed = (int32_t)d;
+  } else {
+    if (mode == 1) { const int64_t t = s; s = d; d = t; }
+    r.key = (uint32_t)d;
+    r.packed = (int32_t)((s << type_bits) | ty);
+  }
+  return r;
+}
+
 __global__ __launch_bounds__(256) void k_pack(TypeTable tab, int32_t type_bits, int mode, int total_types,
                                               uint32_t *__restrict__ keys,
                                               int32_t *__restrict__ pos,
@@ -148,6 +176,203 @@ __global__ __launch_bounds__(kSortBlock) void k_radix_scatter(
   }
 }
 
+// ---- two-level plan build for minibatch-sized graphs (rows <= 2^18, <= 64 edge types) -------------
+// The LSD sort above needs 2 x (histogram, scan, scatter) + pack + finish + hub list = 11 dependent
+// launches whose 4-byte scatters land two-at-a-time in random cache lines.  Rows are node ids, i.e.
+// roughly uniformly populated, so:
+//   k_msd_hist     per-1024-edge block histogram of the HIGH row bits, straight from the int64 lists
+//   k_msd_scan     per-digit exclusive scan over the blocks + digit totals          (one WG per digit)
+//   k_msd_scatter  stable scatter of 16-byte records (row, position, payload) into <= 512 buckets of
+//                  2^low_bits consecutive rows each
+//   k_msd_buckets  one workgroup per bucket: histogram of the LOW bits = the in-degrees -> rowptr and
+//                  the hub list directly; stable counting sort of the bucket into col / perm
+// 4 launches, keys never materialised, the second level works inside a few-KiB window of the output.
+// Stability of both levels = the order of a numpy stable argsort (tests: bit-exact).
+constexpr int kMsdBlock = 1024;
+
+// exclusive scan of v over threads 0 .. 511 of a 1024-thread block (tmp: 8 ints of LDS); returns the
+// exclusive prefix, *total (LDS broadcast slot tmp[8]) gets the grand total
+__device__ __forceinline__ int block_scan_512(int v, int *tmp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (wave < 8 && lane == 63) tmp[wave] = inc;
+  __syncthreads();
+  int prior = 0;
+  if (wave < 8)
+    for (int w = 0; w < wave; ++w) prior += tmp[w];
+  return prior + inc - v;
+}
+
+__global__ __launch_bounds__(kMsdBlock) void k_msd_hist(TypeTable tab, int32_t type_bits, int mode,
+                                                        int total_types, int64_t n, int low_bits,
+                                                        int bins, int32_t *__restrict__ hist,
+                                                        int64_t nblocks, int32_t *hub_count) {
+  __shared__ int lh[kMaxBins];
+  for (int j = threadIdx.x; j < bins; j += kMsdBlock) lh[j] = 0;
+  if (hub_count && blockIdx.x == 0 && threadIdx.x == 0) *hub_count = 0;
+  __syncthreads();
+  const int64_t e = blockIdx.x * (int64_t)kMsdBlock + threadIdx.x;
+  if (e < n) atomicAdd(&lh[edge_record(tab, e, type_bits, mode, total_types).key >> low_bits], 1);
+  __syncthreads();
+  for (int j = threadIdx.x; j < bins; j += kMsdBlock) hist[(int64_t)j * nblocks + blockIdx.x] = lh[j];
+}
+
+// hist[d][0 .. nblocks) -> exclusive prefix in place; totals[d] = row sum.  One 256-thread WG per digit.
+__global__ __launch_bounds__(256) void k_msd_scan(int32_t *__restrict__ hist, int64_t nblocks,
+                                                  int32_t *__restrict__ totals) {
+  __shared__ int wsum[4];
+  __shared__ int carry_s;
+  int32_t *row = hist + (int64_t)blockIdx.x * nblocks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nblocks; base += 256) {
+    const int64_t j = base + threadIdx.x;
+    const int v = j < nblocks ? row[j] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int prior = carry_s;
+    for (int w = 0; w < wave; ++w) prior += wsum[w];
+    if (j < nblocks) row[j] = prior + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = prior + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+// stable rank of this lane's digit inside a 1024-thread block: (earlier waves' count, rank in wave)
+// via wave ballots + a [16][bins] LDS table; returns the block-local exclusive rank contribution
+// wave_cnt[wave][digit] + rank (valid lanes only) and leaves per-digit block totals in `run_out`
+// for threads < bins.
+__device__ __forceinline__ int block_stable_rank(bool valid, int digit, int bits, int bins, int *wave_cnt,
+                                                 int *run_out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = threadIdx.x; j < (kMsdBlock / 64) * bins; j += kMsdBlock) wave_cnt[j] = 0;
+  unsigned long long same = __ballot(valid);
+  for (int b = 0; b < bits; ++b) {
+    const bool bit = (digit >> b) & 1;
+    const unsigned long long bal = __ballot(bit);
+    same &= bit ? bal : ~bal;
+  }
+  const int rank = __popcll(same & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (valid && rank == 0) wave_cnt[wave * bins + digit] = __popcll(same);
+  __syncthreads();
+  int run = 0;
+  for (int d = threadIdx.x; d < bins; d += kMsdBlock) {     // bins <= 512 < block: one digit per thread
+    for (int w = 0; w < kMsdBlock / 64; ++w) {
+      const int t = wave_cnt[w * bins + d];
+      wave_cnt[w * bins + d] = run;
+      run += t;
+    }
+  }
+  *run_out = run;
+  __syncthreads();
+  return valid ? wave_cnt[wave * bins + digit] + rank : 0;
+}
+
+__global__ __launch_bounds__(kMsdBlock) void k_msd_scatter(TypeTable tab, int32_t type_bits, int mode,
+                                                           int total_types, int64_t n, int low_bits,
+                                                           int high_bits, int bins,
+                                                           const int32_t *__restrict__ hist_prefix,
+                                                           const int32_t *__restrict__ totals,
+                                                           int64_t nblocks, int4 *__restrict__ recs) {
+  __shared__ int wave_cnt[(kMsdBlock / 64) * kMaxBins];
+  __shared__ int base[kMaxBins];
+  __shared__ int tmp[8];
+  {
+    const int v = threadIdx.x < bins ? totals[threadIdx.x] : 0;
+    const int ex = block_scan_512(v, tmp);
+    if (threadIdx.x < bins) base[threadIdx.x] = ex;
+  }
+  const int64_t e = blockIdx.x * (int64_t)kMsdBlock + threadIdx.x;
+  const bool valid = e < n;
+  EdgeRec r{0u, 0};
+  if (valid) r = edge_record(tab, e, type_bits, mode, total_types);
+  const int digit = (int)(r.key >> low_bits);
+  int run;
+  const int local = block_stable_rank(valid, digit, high_bits, bins, wave_cnt, &run);   // syncs inside
+  if (valid) {
+    const int64_t pos = (int64_t)base[digit] + hist_prefix[(int64_t)digit * nblocks + blockIdx.x] + local;
+    recs[pos] = make_int4((int)r.key, (int)e, r.packed, 0);
+  }
+}
+
+__global__ __launch_bounds__(kMsdBlock) void k_msd_buckets(
+    const int4 *__restrict__ recs, const int32_t *__restrict__ totals, int bins, int low_bits,
+    int64_t num_rows, int64_t num_edges, int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
+    int32_t *__restrict__ perm, int32_t hub_threshold, int32_t hub_chunk, int32_t *__restrict__ hub_entries,
+    int32_t *__restrict__ hub_count) {
+  __shared__ int wave_cnt[(kMsdBlock / 64) * kMaxBins];
+  __shared__ int offs[kMaxBins];
+  __shared__ int tmp[8];
+  __shared__ int bucket_start_s;
+  const int b = blockIdx.x;
+  const int lbins = 1 << low_bits, mask = lbins - 1;
+  {   // where this bucket starts in the record array: prefix of the digit totals
+    const int v = threadIdx.x < bins ? totals[threadIdx.x] : 0;
+    const int ex = block_scan_512(v, tmp);
+    if (threadIdx.x == b) bucket_start_s = ex;
+  }
+  for (int j = threadIdx.x; j < lbins; j += kMsdBlock) offs[j] = 0;
+  __syncthreads();
+  const int s = bucket_start_s, e = s + totals[b];
+  for (int i = s + threadIdx.x; i < e; i += kMsdBlock) atomicAdd(&offs[recs[i].x & mask], 1);
+  __syncthreads();
+  {   // in-degrees -> rowptr (+ hub rows); offs becomes the running write cursor of each row
+    const int deg = threadIdx.x < lbins ? offs[threadIdx.x] : 0;
+    __syncthreads();
+    const int ex = block_scan_512(deg, tmp);
+    const int64_t row = ((int64_t)b << low_bits) + threadIdx.x;
+    if (threadIdx.x < lbins) {
+      offs[threadIdx.x] = ex;
+      if (row < num_rows) {
+        rowptr[row] = s + ex;
+        if (row == num_rows - 1) rowptr[num_rows] = (int32_t)num_edges;
+        if (hub_entries && hub_threshold > 0 && deg > hub_threshold) {
+          const int beg = s + ex, end = beg + deg;
+          const int c0 = beg / hub_chunk, c1 = (end - 1) / hub_chunk;
+          const int at = atomicAdd(hub_count, c1 - c0 + 1);
+          for (int c = c0; c <= c1; ++c) {
+            hub_entries[2 * (at + c - c0)] = c;
+            hub_entries[2 * (at + c - c0) + 1] = (int32_t)row;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int cb = s; cb < e; cb += kMsdBlock) {
+    const int i = cb + threadIdx.x;
+    const bool valid = i < e;
+    int4 r = make_int4(0, 0, 0, 0);
+    if (valid) r = recs[i];
+    const int digit = r.x & mask;
+    int run;
+    const int local = block_stable_rank(valid, digit, low_bits, lbins, wave_cnt, &run);   // syncs inside
+    if (valid) {
+      const int pos = s + offs[digit] + local;
+      col[pos] = r.z;
+      if (perm) perm[pos] = r.y;
+    }
+    __syncthreads();
+    if (threadIdx.x < lbins) offs[threadIdx.x] += run;
+    // the next iteration's block_stable_rank synchronises before offs is read again
+  }
+}
+
 // (chunk, row) pairs of every row longer than `threshold`, appended in arbitrary order (consumers
 // treat the pairs independently); *count must be 0 on entry.
 __global__ __launch_bounds__(256) void k_hub_list(const int32_t *__restrict__ rowptr, int64_t num_rows,
@@ -207,11 +432,20 @@ bool use_rocprim_sort(int64_t num_edges) {
   static int v = -1;
   if (v < 0) {
     const char *e = getenv("PTGNN_AMD_SORT");
-    v = !e ? 0 : (strcmp(e, "rocprim") == 0 ? 1 : (strcmp(e, "custom") == 0 ? 2 : 0));
+    v = !e ? 0 : (strcmp(e, "rocprim") == 0 ? 1 : (strcmp(e, "custom") == 0 || strcmp(e, "lsd") == 0 ? 2 : 0));
   }
   if (v == 1) return true;
-  if (v == 2) return false;
+  if (v == 2 || v == 3) return false;
   return num_edges > ((int64_t)4 << 20);
+}
+
+// two-level build: needs every row id in 18 bits (high digit <= 9 bits over <= 9-bit buckets) and one
+// type table; PTGNN_AMD_SORT=lsd forces the flat LSD sort for A/B runs
+bool use_msd_build(int64_t num_edges, int64_t num_rows, int num_types) {
+  const char *e = getenv("PTGNN_AMD_SORT");
+  if (e && strcmp(e, "msd") != 0) return false;
+  return num_edges > 0 && num_edges <= ((int64_t)4 << 20) && num_rows <= ((int64_t)1 << 18) &&
+         num_types <= kMaxTypes;
 }
 
 int end_bit_for(int64_t num_nodes) {
@@ -311,6 +545,51 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
   int32_t *pos_in = (int32_t *)(ws + L.pos_in), *pos_out = (int32_t *)(ws + L.pos_out);
   int32_t *packed = (int32_t *)(ws + L.packed);
 
+  if (use_msd_build(num_edges, num_nodes, num_types)) {
+    TypeTable tab;
+    tab.num_types = num_types;
+    tab.type_base = 0;
+    tab.offset[0] = 0;
+    for (int t = 0; t < num_types; ++t) {
+      tab.src[t] = src_per_type[t];
+      tab.dst[t] = dst_per_type[t];
+      tab.offset[t + 1] = tab.offset[t] + edges_per_type[t];
+    }
+    const int total_bits = end_bit_for(num_nodes);
+    // buckets of ~4096 edges on average keep every CU busy in the second level; <= 9 bits per level
+    int low_bits = 0;
+    while (low_bits < 9 && low_bits < total_bits &&
+           (((int64_t)2 << low_bits) * num_edges <= (int64_t)4096 * num_nodes)) ++low_bits;
+    if (low_bits < 3) low_bits = total_bits < 3 ? total_bits : 3;
+    if (total_bits - low_bits > 9) low_bits = total_bits - 9;
+    const int high_bits = total_bits - low_bits;
+    const int bins = (int)((num_nodes + ((int64_t)1 << low_bits) - 1) >> low_bits);
+    const int64_t nblocks = (num_edges + kMsdBlock - 1) / kMsdBlock;
+    int32_t *hist = (int32_t *)(ws + L.hist), *totals = (int32_t *)(ws + L.hist_scan);
+    int4 *recs = (int4 *)ws;   // 16 B/edge over the (unused) key/pos/payload buffers of the LSD path
+    const bool hubs = hub_entries && hub_count && hub_threshold > 0;
+    k_msd_hist<<<(unsigned)nblocks, kMsdBlock, 0, stream>>>(tab, type_bits, swap_src_dst, num_types, num_edges,
+                                                            low_bits, bins, hist, nblocks,
+                                                            hubs ? hub_count : nullptr);
+    PTGNN_LAUNCH_CHECK();
+    k_msd_scan<<<(unsigned)bins, 256, 0, stream>>>(hist, nblocks, totals);
+    PTGNN_LAUNCH_CHECK();
+    k_msd_scatter<<<(unsigned)nblocks, kMsdBlock, 0, stream>>>(tab, type_bits, swap_src_dst, num_types,
+                                                               num_edges, low_bits, high_bits, bins, hist,
+                                                               totals, nblocks, recs);
+    PTGNN_LAUNCH_CHECK();
+    k_msd_buckets<<<(unsigned)bins, kMsdBlock, 0, stream>>>(recs, totals, bins, low_bits, num_nodes, num_edges,
+                                                            rowptr, col, perm, hubs ? hub_threshold : 0, 1024,
+                                                            hub_entries, hub_count);
+    PTGNN_LAUNCH_CHECK();
+    if (max_degree) {
+      PTGNN_HIP(hipMemsetAsync(max_degree, 0, sizeof(int32_t), stream));
+      const int64_t mb = (num_nodes + 255) / 256;
+      k_max_degree<<<(unsigned)(mb < 1024 ? mb : 1024), 256, 0, stream>>>(rowptr, num_nodes, max_degree);
+      PTGNN_LAUNCH_CHECK();
+    }
+    return PTGNN_AMD_OK;
+  }
   if (num_edges > 0) {
     int64_t base = 0;
     for (int t0 = 0; t0 < num_types; t0 += kMaxTypes) {
