@@ -45,8 +45,13 @@ def parse():
                    help="run the dst-range-sharded code path (process group, halo all-to-all) even at N=1")
     p.add_argument("--cut-edges", action="store_true",
                    help="N>1: ONE random graph over all ranks ((N-1)/N of the edges cut, halo all-to-all per "
-                        "layer) instead of the default disjoint union of per-rank graphs")
-    return p.parse_args()
+                        "layer) instead of the default one-graph-per-rank partition")
+    p.add_argument("--global-ids", action="store_true",
+                   help="N>1: the per-rank graphs as ONE disjoint-union batch with global node ids, split by "
+                        "ptgnn_amd.sharded (no-cut detection = one all-reduce per minibatch)")
+    a = p.parse_args()
+    a.force_sharded = a.force_sharded or a.global_ids or a.cut_edges   # all three need the process group
+    return a
 
 
 def dist_setup(args):
@@ -87,14 +92,18 @@ def max_over_ranks(seconds, world, dev):
 # workloads
 # ------------------------------------------------------------------------------------------------
 def make_cfg2(dev, rank, world, force_sharded=False, cut_edges=False):
-    """configs[1]; for world > 1 every rank owns its own 200k-node destination range."""
+    """configs[1].  world > 1, default: the path partitions over whole graphs (a minibatch is a disjoint
+    union, graphneuralnetwork.py:418-423; the reference's own multi-GPU mode hands whole graphs to
+    ranks, distributedtrainer.py:250-297), so every rank runs the single-GPU step on ITS OWN 200k-node
+    graph with rank-local node ids: no data-path collective (weak scaling).  `force_sharded` /
+    `cut_edges` go through ptgnn_amd.sharded with global ids instead."""
     from ptgnn_amd import layers as L, workloads
     N, E, H = 200_000, 1_100_000, 128
     torch.manual_seed(1234)
     layer = L.MlpMessagePassingLayer(H, H, H, 1, "sum").to(dev).eval()
-    if world == 1 and not force_sharded:
-        adj = workloads.random_graph(N, E)
-        x = workloads.node_states(N, H)
+    if not force_sharded and not cut_edges:
+        adj = workloads.random_graph(N, E, seed=1234 + rank)
+        x = workloads.node_states(N, H, seed=1234 + rank)
         state = {"adj": [(s.to(dev), d.to(dev)) for s, d in adj], "x": x.to(dev), "cpu_adj": adj, "cpu_x": x}
     else:
         from ptgnn_amd import sharded
@@ -104,7 +113,10 @@ def make_cfg2(dev, rank, world, force_sharded=False, cut_edges=False):
     if "adj" not in state:
         desc += (f" per GPU; one graph of {world} x 200k nodes, sources uniform over all ranks "
                  f"({world - 1}/{world} of the edges cut)" if cut_edges else
-                 f" per GPU; disjoint union of {world} such graphs, dst-range partition on graph boundaries")
+                 f" per GPU; disjoint union of {world} such graphs with global ids, dst-range partition on "
+                 "graph boundaries found by ptgnn_amd.sharded")
+    elif world > 1:
+        desc += f" per GPU; {world} independent graphs, one per GPU (partition over whole graphs)"
     state.update(layer=layer, N=N, E=E, H=H, layers_per_step=1, desc=desc)
     return state
 
@@ -305,7 +317,7 @@ def main():
     _lib.load()
 
     if args.workload == "cfg2":
-        st = make_cfg2(dev, rank, world, args.force_sharded, args.cut_edges)
+        st = make_cfg2(dev, rank, world, args.force_sharded or args.global_ids, args.cut_edges)
         step = lambda: step_cfg2(st, world)  # noqa: E731
     else:
         if world > 1:
@@ -333,7 +345,8 @@ def main():
         "config": {"workload": st["desc"], "nodes_per_gpu": st["N"], "edges_per_gpu": st["E"],
                    "hidden": st["H"], "mp_layers_per_step": layers, "mode": "forward (inference), fp32",
                    "plan_build_in_step": True,
-                   "parallelism": "single GPU" if "adj" in st else (
+                   "parallelism": ("single GPU" if world == 1 else
+                                   f"{world} GPUs x whole graphs, no data-path collective") if "adj" in st else (
                        f"dst-range shard x{world} + halo all-to-all per layer" if st.get("cut_edges") else
                        f"dst-range shard x{world} on graph boundaries (no cut edges => no data-path collective)")},
         "nodes_per_sec_per_layer": round(st["N"] * world / (seconds / args.steps / layers), 1),
@@ -341,15 +354,20 @@ def main():
         "roofline": roof, "kernels": ktab,
     }
 
-    if world > 1 and args.workload == "cfg2" and not args.cut_edges and not args.no_secondary:
-        # the same weak-scaling shard with cut edges: exercises the RCCL halo all-to-all every layer
-        st_cut = make_cfg2(dev, rank, world, True, True)
+    if world > 1 and args.workload == "cfg2" and "adj" in st and not args.no_secondary:
+        # the same weak-scaling work through ptgnn_amd.sharded: (a) global ids, partition on graph boundaries
+        # (one all-reduce per minibatch, no per-layer exchange); (b) cut edges: RCCL halo all-to-all per layer
         k2 = max(5, args.steps // 2)
-        sec_cut, _ = timed_region(lambda: step_cfg2(st_cut, world), k2, 2, world, dev)
-        result["cut_edges_variant"] = {
-            "workload": st_cut["desc"], "ms_per_step": round(sec_cut / k2 * 1e3, 4),
-            "edges_per_sec_per_layer": round(st_cut["E"] * world / (sec_cut / k2), 1)}
-        del st_cut
+        for key, cut in (("global_ids_variant", False), ("cut_edges_variant", True)):
+            try:   # secondary numbers must never cost the primary line
+                st2 = make_cfg2(dev, rank, world, True, cut)
+                sec2, _ = timed_region(lambda: step_cfg2(st2, world), k2, 2, world, dev)
+                result[key] = {"workload": st2["desc"], "ms_per_step": round(sec2 / k2 * 1e3, 4),
+                               "edges_per_sec_per_layer": round(st2["E"] * world / (sec2 / k2), 1)}
+                del st2
+            except Exception as exc:  # noqa: BLE001
+                result[key] = {"error": f"{type(exc).__name__}: {exc}"}
+                break              # ranks may have diverged: do not enter another collective section
     if rank == 0 and world == 1 and not args.force_sharded:
         if args.workload == "cfg2" and not args.no_secondary:
             st3 = make_cfg3(dev)
