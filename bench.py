@@ -46,6 +46,9 @@ def parse():
     p.add_argument("--cut-edges", action="store_true",
                    help="N>1: ONE random graph over all ranks ((N-1)/N of the edges cut, halo all-to-all per "
                         "layer) instead of the default one-graph-per-rank partition")
+    p.add_argument("--sharded-variants", action="store_true",
+                   help="N>1: after the primary measurement also time the two ptgnn_amd.sharded variants "
+                        "(global ids / cut edges) and report them as secondary entries")
     p.add_argument("--global-ids", action="store_true",
                    help="N>1: the per-rank graphs as ONE disjoint-union batch with global node ids, split by "
                         "ptgnn_amd.sharded (no-cut detection = one all-reduce per minibatch)")
@@ -354,7 +357,7 @@ def main():
         "roofline": roof, "kernels": ktab,
     }
 
-    if world > 1 and args.workload == "cfg2" and "adj" in st and not args.no_secondary:
+    if world > 1 and args.workload == "cfg2" and "adj" in st and args.sharded_variants:
         # the same weak-scaling work through ptgnn_amd.sharded: (a) global ids, partition on graph boundaries
         # (one all-reduce per minibatch, no per-layer exchange); (b) cut edges: RCCL halo all-to-all per layer
         k2 = max(5, args.steps // 2)
