@@ -393,6 +393,13 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints a banner through C stdio, which is block-buffered on a pipe and would otherwise land
+    # AFTER the JSON line at process exit: drain it first so the JSON is the last line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
