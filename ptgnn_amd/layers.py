@@ -253,10 +253,19 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
         rows; one all-to-all of halo rows, then the same fused kernels as `forward`."""
         _check_device(node_states)
         feats = [None] * len(shard.local_adj)
-        if not self._fused_ok(node_states, feats):
-            raise _lib.PtgnnAmdError("forward_sharded supports the fused inference path only "
-                                     "(no grad, no active dropout, no edge features)")
         assert len(shard.local_adj) == len(self.__edge_message_transformation_layers)
+        if not self._fused_ok(node_states, feats):
+            if not self._table_ok(node_states, feats):
+                raise _lib.PtgnnAmdError("forward_sharded: per-edge dropout / edge features are not "
+                                         "supported on a sharded graph")
+            # training: table form with the differentiable halo exchange (backward = transposed exchange)
+            w = torch.cat([l.weight for l in self.__edge_message_transformation_layers], dim=0)
+            if w.shape[0] <= w.shape[1]:
+                y = shard.exchange_autograd(dense.linear(node_states, w))
+            else:
+                y = dense.linear(shard.exchange_autograd(node_states), w)
+            agg = gather_reduce_autograd(y, None, shard.plan, self._message_dimension, self.__aggregation_fn)
+            return dense.gru_cell(self.__state_update, agg, node_states)
         w = self._stacked_edge_weights()
         TM, H = w.shape
         if TM <= H:   # ship message-table rows: no wider than the state, and no duplicated GEMM work
@@ -388,11 +397,24 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
         all-to-all, the destination term W_t^d x_v is purely local."""
         _check_device(node_states)
         feats = [None] * len(shard.local_adj)
-        if not self._fused_ok(node_states, feats):
-            raise _lib.PtgnnAmdError("forward_sharded supports the fused inference path only "
-                                     "(no grad, string aggregation, single-Linear edge transform)")
         assert len(shard.local_adj) == len(self.__edge_message_transformation_layers)
         T, M, H = len(shard.local_adj), self._message_dimension, self.__input_state_dim
+        if not self._fused_ok(node_states, feats):
+            if not self._table_ok(node_states, feats):
+                raise _lib.PtgnnAmdError("forward_sharded needs a string aggregation and single-Linear edge "
+                                         "transforms without edge features")
+            # training: table form with the differentiable halo exchange (backward = transposed exchange)
+            ws = [m.linears[0].weight for m in self.__edge_message_transformation_layers]
+            w_src = torch.cat([w[:, :H] for w in ws], dim=0)
+            if T * M <= H:
+                ysrc = shard.exchange_autograd(dense.linear(node_states, w_src))
+            else:
+                ysrc = dense.linear(shard.exchange_autograd(node_states), w_src)
+            ydst = None
+            if self.__use_target_state_as_message_input:
+                ydst = dense.linear(node_states, torch.cat([w[:, H:2 * H] for w in ws], dim=0))
+            agg = gather_reduce_autograd(ysrc, ydst, shard.plan, M, self.__aggregation_fn)
+            return self._update(agg, False)
         w = self._stacked_edge_weights()
         w_src = w[: T * M]
         if T * M <= H:

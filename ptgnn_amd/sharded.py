@@ -172,9 +172,46 @@ class ShardedGraph:
         table[: self.n_local].copy_(rows_local)
         return self.exchange_into(table)
 
+    def exchange_autograd(self, rows_local: torch.Tensor) -> torch.Tensor:
+        """Differentiable `exchange`: backward is the transposed exchange -- the halo rows'
+        gradients travel back to their owners over the same all-to-all with the splits swapped and are
+        segment-summed onto the owners' rows (a row sent to several peers collects all of them)."""
+        return _HaloExchange.apply(rows_local, self)
+
+    def _send_plan(self):
+        """Plan that sums returned gradient rows by the local row they belong to (built once per shard)."""
+        if getattr(self, "_sp", None) is None:
+            self._sp = ops.build_plan([(self.send_ids, self.send_ids)], self.n_local)
+        return self._sp
+
     @property
     def halo_bytes_per_row_exchange(self) -> int:
         return 4 * sum(self.recv_splits)
+
+
+class _HaloExchange(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows_local, shard):
+        ctx.shard = shard
+        return shard.exchange(rows_local)
+
+    @staticmethod
+    def backward(ctx, g):
+        sh = ctx.shard
+        g = g.contiguous()
+        d_own = g[: sh.n_local]
+        if sh.n_halo == 0 and sum(sh.send_splits) == 0:
+            return d_own, None
+        back = torch.empty(sum(sh.send_splits), g.shape[1], dtype=g.dtype, device=g.device)
+        dist.all_to_all_single(back, g[sh.n_local:].contiguous(), sh.send_splits, sh.recv_splits,
+                               group=sh.group)
+        if back.shape[0] == 0:
+            return d_own, None
+        if g.is_cuda:   # deterministic segment-sum on the HIP kernel
+            extra = ops.segment_reduce(back, sh._send_plan(), "sum")
+        else:           # gloo/CPU tests of the host logic only
+            extra = torch.zeros_like(d_own).index_add_(0, sh.send_ids, back)
+        return d_own + extra, None
 
 
 # ------------------------------------------------------------------------------------------------

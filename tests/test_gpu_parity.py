@@ -5,6 +5,8 @@ modules, and -- at BASELINE.json config-2 size -- through size-independent prope
 Bars: integer/index outputs bit-exact; max/min aggregation bit-exact; fp32 sums bit-exact where the
 fold order is the reference's (segment reduce) and |delta| <= 1e-5 for full layers (north_star).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1032,3 +1034,45 @@ def test_minibatch_builder_large_batch_equals_oracle_and_feeds_the_layers():
         y = layer(torch.randn(N, 32, device="cuda"), mb["adjacency_lists"], mb["node_to_graph_idx"], {}, {},
                   empty_feats(mb["adjacency_lists"], "cuda"))
     assert tuple(y.shape) == (N, 32) and bool(torch.isfinite(y).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# sharded TRAINING (table form + differentiable halo exchange) on the RCCL path at world = 1
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["ggnn", "mlp"])
+def test_sharded_training_equals_unsharded_training_world1(kind, monkeypatch):
+    import socket
+    import torch.distributed as dist
+    from ptgnn_amd import layers as L, ops, sharded
+    monkeypatch.setattr(L, "EDGE_PATH_BIAS", 1e9)         # both runs take the table form
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, H, T = 2000, 64, 3
+        g = torch.Generator().manual_seed(23)
+        adj = [(torch.randint(0, n, (c,), generator=g).cuda(), torch.randint(0, n, (c,), generator=g).cuda())
+               for c in (5000, 0, 2500)]
+        x = torch.randn(n, H, generator=g).cuda()
+        gout = torch.randn(n, H, generator=g).cuda()
+        torch.manual_seed(4)
+        layer = (L.GatedMessagePassingLayer(H, H, T, "max") if kind == "ggnn"
+                 else L.MlpMessagePassingLayer(H, H, H, T, "sum")).cuda().train()
+        grads = []
+        for mode in ("plain", "sharded"):
+            layer.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            ops.clear_plan_cache()
+            if mode == "plain":
+                y = layer(xi, adj, None, {}, {}, empty_feats(adj, "cuda"))
+            else:
+                shard = sharded.ShardedGraph.build(adj, (0, n))
+                y = layer.forward_sharded(xi, shard)
+            y.backward(gout)
+            grads.append([y.detach(), xi.grad] + [p.grad.clone() for p in layer.parameters()])
+        assert torch.equal(grads[0][0], grads[1][0])       # forward: same kernels, same order
+        for a, b in zip(*grads):   # the MLP layer's sharded form splits the src / dst GEMMs: fp32 re-association
+            sc = max(1.0, float(a.abs().max()))
+            assert float((a - b).abs().max()) <= 1e-5 * sc
+    finally:
+        dist.destroy_process_group()

@@ -135,3 +135,54 @@ def test_balanced_ranges_follow_edge_mass():
     assert r[0][1] - r[0][0] < 10          # the first rank gets only a few hub rows
     w = [float((deg[a:b] + 1).sum()) for a, b in r]
     assert max(w) / (sum(w) / 4) < 1.6
+
+
+def _worker_exchange_grad(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ptgnn_amd import sharded
+        n = 240
+        adj, x = _global_graph(n, [900, 300], 11)
+        ranges = [(p * n // world, (p + 1) * n // world) for p in range(world)]
+        lo, hi = ranges[rank]
+        mine = [(s[(d >= lo) & (d < hi)], d[(d >= lo) & (d < hi)]) for s, d in adj]
+        shard = sharded.ShardedGraph.build(mine, (lo, hi), build_plan=False, all_ranges=ranges)
+        coef = torch.linspace(0.5, 2.0, n).unsqueeze(1) * torch.ones(1, x.shape[1])
+        xl = x[lo:hi].clone().requires_grad_(True)
+        table = shard.exchange_autograd(xl)
+        rows = torch.cat([torch.arange(lo, hi), shard.need_ids])
+        ((rank + 1.0) * table * coef[rows]).sum().backward()
+        # expected: own use + every peer that lists the row among its halo rows
+        weight = torch.full((n,), 0.0)
+        weight[lo:hi] += rank + 1.0
+        for p, (plo, phi) in enumerate(ranges):
+            if p == rank:
+                continue
+            srcs = torch.cat([s[(d >= plo) & (d < phi)] for s, d in adj])
+            need = torch.unique(srcs[(srcs < plo) | (srcs >= phi)])
+            need = need[(need >= lo) & (need < hi)]
+            weight[need] += p + 1.0
+        want = (weight.unsqueeze(1) * coef)[lo:hi]
+        np.testing.assert_allclose(xl.grad.numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+        out_q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        out_q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_backward_is_the_transposed_exchange(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_exchange_grad, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert r[1] == "ok", r[1]
