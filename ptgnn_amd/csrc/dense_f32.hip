@@ -389,365 +389,6 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
 }
 
 // ---------------------------------------------------------------------------------------------
-// linear, persistent with a SOFTWARE-PIPELINED EPILOGUE ("pp").  The r01 ablations show the
-// one-shot kernel loses 22-27 % to its epilogue even when the output folds onto an L2-resident
-// window (so it is the epilogue's own LDS/store instruction stream, not HBM), and co-resident
-// workgroups convoy into lockstep so nobody's MFMAs cover it.  Here each wave keeps TWO accumulator
-// sets: while tile i+1 accumulates into one, tile i's fragments are drained from the other in
-// two halves -- slab writes, float4 read-back and global stores threaded between the MFMA groups of
-// tile i+1's first K-chunks -- so every wave issues one uniform MFMA-dense stream and lockstep no
-// longer matters.  The next chunk (also across tile boundaries) is prefetched into registers.
-// ---------------------------------------------------------------------------------------------
-template <bool ALIGNED, int ACT, int NJ>
-__global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void k_linear_pp(
-    const float *__restrict__ x, int64_t rows, int K, int64_t ld_x, const float *__restrict__ w,
-    int n_out, const float *__restrict__ bias, float *__restrict__ y, int64_t ld_y,
-    int64_t num_tiles, int col_tiles, int vec_store) {
-  constexpr int BN = 64 * NJ;
-  constexpr int B_FLOATS = BN * LDS_LD;
-  constexpr int SLAB_LD = 32 * NJ + 4;
-  constexpr int SLAB_FLOATS = 32 * SLAB_LD;
-  __shared__ __attribute__((aligned(16))) float smem[TILE_FLOATS + B_FLOATS + 4 * SLAB_FLOATS];
-  float *const As = smem, *const Bs = smem + TILE_FLOATS;
-  float *const slab = smem + TILE_FLOATS + B_FLOATS + (threadIdx.x >> 6) * SLAB_FLOATS;  // wave-private
-
-  const TileWalk walk((uint32_t)num_tiles);
-  const int nchunks = (K + BK - 1) / BK;
-  const uint32_t ntiles_mine = walk.count();
-  if (ntiles_mine == 0) return;
-  const int64_t total = (int64_t)ntiles_mine * nchunks;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, hi = lane >> 5;
-  constexpr int LPRW = 8 * NJ, RPI = 64 / LPRW, NIT = 32 / RPI;  // read-back geometry of a half
-  const int c4 = (lane % LPRW) * 4, rsub = lane / LPRW;
-
-  f32x16 acc[2][2][NJ];  // [tile parity][i][j]
-#pragma unroll
-  for (int p = 0; p < 2; ++p)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][i][j][r] = 0.f;
-
-  Stager<128, ALIGNED, RowClamp> sa;
-  Stager<BN, ALIGNED, RowClamp> sb;
-  TileCursor ld, cp;
-  ld.init(walk, col_tiles);
-  cp.init(walk, col_tiles);
-  int64_t ld_left = total;
-  auto issue_load = [&]() {  // past the end the cursor parks on the last chunk (harmless re-load)
-    sa.load(x, ld_x, ld.chunk * BK, K, RowClamp{(int64_t)ld.row_tile * 128, rows});
-    sb.load(w, K, ld.chunk * BK, K, RowClamp{(int64_t)ld.col_tile * BN, n_out});
-    if (--ld_left > 0) ld.advance(walk, col_tiles, nchunks);
-  };
-
-  // the tile whose fragments sit in acc[parity ^ 1], waiting to be drained
-  int64_t prev_row0 = 0;
-  int prev_col0 = 0;
-  bool has_prev = false;
-  float4 dreg[NIT];
-
-  const float *ap = As + (wm * 64 + li) * LDS_LD + hi;
-  const float *bp = Bs + (wn * 32 * NJ + li) * LDS_LD + hi;
-
-  auto run_tile = [&](auto PAR) {
-    constexpr int P = decltype(PAR)::value;
-    auto mfma_range = [&](int k0, int k1) {
-#pragma unroll
-      for (int ks = k0; ks < k1; ++ks) {
-        float a[2], b[NJ];
-        a[0] = ap[ks * 2];
-        a[1] = ap[32 * LDS_LD + ks * 2];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + ks * 2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[P][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[P][i][j], 0, 0, 0);
-      }
-    };
-    // the three drain steps of half `h` of the previous tile (C fragment: col = lane & 31,
-    // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
-    auto drain_write = [&](auto H) {
-      constexpr int h = decltype(H)::value;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[P ^ 1][h][j][r];
-          acc[P ^ 1][h][j][r] = 0.f;
-        }
-      __builtin_amdgcn_wave_barrier();
-    };
-    auto drain_read = [&]() {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it)
-        dreg[it] = *reinterpret_cast<const float4 *>(slab + (it * RPI + rsub) * SLAB_LD + c4);
-      __builtin_amdgcn_wave_barrier();
-    };
-    auto drain_store = [&](int h) {
-      const int gcol = prev_col0 + wn * 32 * NJ + c4;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias) {
-        if (gcol + 0 < n_out) bv.x = bias[gcol + 0];
-        if (gcol + 1 < n_out) bv.y = bias[gcol + 1];
-        if (gcol + 2 < n_out) bv.z = bias[gcol + 2];
-        if (gcol + 3 < n_out) bv.w = bias[gcol + 3];
-      }
-      const int64_t rbase = prev_row0 + wm * 64 + h * 32;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int64_t grow = rbase + it * RPI + rsub;
-        float4 v = dreg[it];
-        v.x = act_apply<ACT>(v.x + bv.x);
-        v.y = act_apply<ACT>(v.y + bv.y);
-        v.z = act_apply<ACT>(v.z + bv.z);
-        v.w = act_apply<ACT>(v.w + bv.w);
-        if (grow < rows) {
-          float *dst = y + grow * ld_y + gcol;
-          if ((vec_store & 1) && gcol + 3 < n_out) {
-            *reinterpret_cast<float4 *>(dst) = v;
-          } else {
-            if (gcol + 0 < n_out) dst[0] = v.x;
-            if (gcol + 1 < n_out) dst[1] = v.y;
-            if (gcol + 2 < n_out) dst[2] = v.z;
-            if (gcol + 3 < n_out) dst[3] = v.w;
-          }
-        }
-      }
-    };
-
-    const int64_t row0 = (int64_t)cp.row_tile * 128;
-    const int col0 = (int)cp.col_tile * BN;
-    for (int c = 0; c < nchunks; ++c) {
-      lds_barrier();  // everyone is done reading the previous chunk's operands
-      sa.store(As);
-      sb.store(Bs);
-      lds_barrier();
-      issue_load();   // next chunk (possibly the next tile's first) lands under the MFMAs
-      const bool d0 = has_prev && c == 0;
-      const bool d1 = has_prev && c == (nchunks > 1 ? 1 : 0);
-      if (d0) drain_write(std::integral_constant<int, 0>{});
-      mfma_range(0, 4);
-      if (d0) drain_read();
-      mfma_range(4, 8);
-      if (d0) drain_store(0);
-      if (d1) drain_write(std::integral_constant<int, 1>{});
-      mfma_range(8, 12);
-      if (d1) drain_read();
-      mfma_range(12, 16);
-      if (d1) drain_store(1);
-      cp.advance(walk, col_tiles, nchunks);
-    }
-    prev_row0 = row0;
-    prev_col0 = col0;
-    has_prev = true;
-  };
-
-  issue_load();
-  for (uint32_t ti = 0; ti < ntiles_mine; ti += 2) {
-    run_tile(std::integral_constant<int, 0>{});
-    if (ti + 1 >= ntiles_mine) break;
-    run_tile(std::integral_constant<int, 1>{});
-  }
-
-  // drain the last tile (nothing left to hide it behind)
-  const int lastp = (int)((ntiles_mine - 1) & 1);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] =
-            lastp ? acc[1][h][j][r] : acc[0][h][j][r];
-    __builtin_amdgcn_wave_barrier();
-    const int gcol = prev_col0 + wn * 32 * NJ + c4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) {
-      if (gcol + 0 < n_out) bv.x = bias[gcol + 0];
-      if (gcol + 1 < n_out) bv.y = bias[gcol + 1];
-      if (gcol + 2 < n_out) bv.z = bias[gcol + 2];
-      if (gcol + 3 < n_out) bv.w = bias[gcol + 3];
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int64_t grow = prev_row0 + wm * 64 + h * 32 + it * RPI + rsub;
-      float4 v = *reinterpret_cast<const float4 *>(slab + (it * RPI + rsub) * SLAB_LD + c4);
-      v.x = act_apply<ACT>(v.x + bv.x);
-      v.y = act_apply<ACT>(v.y + bv.y);
-      v.z = act_apply<ACT>(v.z + bv.z);
-      v.w = act_apply<ACT>(v.w + bv.w);
-      if (grow < rows) {
-        float *dst = y + grow * ld_y + gcol;
-        if ((vec_store & 1) && gcol + 3 < n_out) {
-          *reinterpret_cast<float4 *>(dst) = v;
-        } else {
-          if (gcol + 0 < n_out) dst[0] = v.x;
-          if (gcol + 1 < n_out) dst[1] = v.y;
-          if (gcol + 2 < n_out) dst[2] = v.z;
-          if (gcol + 3 < n_out) dst[3] = v.w;
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// linear, barrier-free variant: every wave stages ITS OWN operands (A 64 x 32, B 32NJ x 32 per
-// K-chunk) into a wave-private LDS region, so there is no s_barrier anywhere and the waves of a CU
-// are fully decoupled pipelines (a wave's LDS ops execute in order, which is all the ordering the
-// write -> read -> overwrite cycle needs).  Costs 2x the L2->LDS staging traffic of the shared-tile
-// kernels (A is staged by both column-waves, B by both row-waves; the duplicate mostly hits the
-// CU's vector L1) in exchange for removing the barrier convoys that hold the shared-tile variants
-// at ~57 % MFMA-busy (profiles/r01_notes.md).
-// ---------------------------------------------------------------------------------------------
-template <bool ALIGNED, int ACT, int NJ>
-__global__ __launch_bounds__(256, (NJ == 1 ? 3 : 2)) void k_linear_wp(
-    const float *__restrict__ x, int64_t rows, int K, int64_t ld_x, const float *__restrict__ w,
-    int n_out, const float *__restrict__ bias, float *__restrict__ y, int64_t ld_y,
-    int64_t num_tiles, int col_tiles, int vec_store) {
-  constexpr int BN = 64 * NJ;                 // workgroup tile 128 x BN, wave tile 64 x 32NJ
-  constexpr int WA = 64 * LDS_LD, WB = 32 * NJ * LDS_LD;
-  constexpr int SLAB_LD = 32 * NJ + 4;
-  static_assert(32 * SLAB_LD <= WA + WB, "epilogue slab must fit the wave's operand region");
-  __shared__ __attribute__((aligned(16))) float smem[4 * (WA + WB)];
-
-  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  if (tile >= num_tiles) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, hi = lane >> 5;
-  const int64_t row0 = (tile / col_tiles) * 128 + wm * 64;      // this WAVE's tile origin
-  const int col0 = (int)(tile % col_tiles) * BN + wn * 32 * NJ;
-  float *const As = smem + wave * (WA + WB), *const Bs = As + WA;
-
-  f32x16 acc[2][NJ];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // per-lane staging: part r covers tile row (lane + 64 r) >> 3, columns ((lane & 7) * 4 ..+3)
-  constexpr int PA = 8, PB = 4 * NJ;
-  float4 ra[PA], rb[PB];
-  const int srow = lane >> 3, sc4 = (lane & 7) * 4;
-  auto load_chunk = [&](int k0) {
-    const int kk = k0 + sc4;
-    const int kc = kk < K ? kk : 0;  // ALIGNED: a float4 is entirely inside or outside K
-#pragma unroll
-    for (int r = 0; r < PA; ++r) {
-      int64_t gr = row0 + srow + r * 8;
-      gr = gr < rows ? gr : rows - 1;
-      const float *p = x + gr * ld_x;
-      if (ALIGNED) ra[r] = *reinterpret_cast<const float4 *>(p + kc);
-      else ra[r] = make_float4(p[kk + 0 < K ? kk + 0 : 0], p[kk + 1 < K ? kk + 1 : 0],
-                               p[kk + 2 < K ? kk + 2 : 0], p[kk + 3 < K ? kk + 3 : 0]);
-    }
-#pragma unroll
-    for (int r = 0; r < PB; ++r) {
-      int gc = col0 + srow + r * 8;
-      gc = gc < n_out ? gc : n_out - 1;
-      const float *p = w + (int64_t)gc * K;
-      if (ALIGNED) rb[r] = *reinterpret_cast<const float4 *>(p + kc);
-      else rb[r] = make_float4(p[kk + 0 < K ? kk + 0 : 0], p[kk + 1 < K ? kk + 1 : 0],
-                               p[kk + 2 < K ? kk + 2 : 0], p[kk + 3 < K ? kk + 3 : 0]);
-    }
-  };
-  auto store_chunk = [&](int k0) {
-    const int kv = K - (k0 + sc4);  // zero the K tail exactly
-#pragma unroll
-    for (int r = 0; r < PA; ++r) {
-      float *q = As + (srow + r * 8) * LDS_LD + sc4;
-      q[0] = kv > 0 ? ra[r].x : 0.f; q[1] = kv > 1 ? ra[r].y : 0.f;
-      q[2] = kv > 2 ? ra[r].z : 0.f; q[3] = kv > 3 ? ra[r].w : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < PB; ++r) {
-      float *q = Bs + (srow + r * 8) * LDS_LD + sc4;
-      q[0] = kv > 0 ? rb[r].x : 0.f; q[1] = kv > 1 ? rb[r].y : 0.f;
-      q[2] = kv > 2 ? rb[r].z : 0.f; q[3] = kv > 3 ? rb[r].w : 0.f;
-    }
-  };
-
-  const int nchunks = (K + BK - 1) / BK;
-  load_chunk(0);
-  const float *ap = As + li * LDS_LD + hi;
-  const float *bp = Bs + li * LDS_LD + hi;
-  for (int c = 0; c < nchunks; ++c) {
-    store_chunk(c * BK);                       // in-order LDS: lands after the previous chunk's reads
-    __builtin_amdgcn_wave_barrier();
-    load_chunk((c + 1 < nchunks ? c + 1 : c) * BK);   // next chunk in flight under the MFMAs
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      float a[2], b[NJ];
-      a[0] = ap[ks * 2];
-      a[1] = ap[32 * LDS_LD + ks * 2];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + ks * 2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-
-  // ---- epilogue through the wave's own LDS region (no barrier) ----
-  float *const slab = As;
-  constexpr int LPRW = 8 * NJ, RPI = 64 / LPRW;
-  const int c4 = (lane % LPRW) * 4, rsub = lane / LPRW;
-  const int gcol = col0 + c4;
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bias) {
-    if (gcol + 0 < n_out) bv.x = bias[gcol + 0];
-    if (gcol + 1 < n_out) bv.y = bias[gcol + 1];
-    if (gcol + 2 < n_out) bv.z = bias[gcol + 2];
-    if (gcol + 3 < n_out) bv.w = bias[gcol + 3];
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
-      const int rl = it * RPI + rsub;
-      const int64_t grow = row0 + i * 32 + rl;
-      float4 v = *reinterpret_cast<const float4 *>(slab + rl * SLAB_LD + c4);
-      v.x = act_apply<ACT>(v.x + bv.x);
-      v.y = act_apply<ACT>(v.y + bv.y);
-      v.z = act_apply<ACT>(v.z + bv.z);
-      v.w = act_apply<ACT>(v.w + bv.w);
-      if (grow < rows) {
-        float *dst = y + grow * ld_y + gcol;
-        if ((vec_store & 1) && gcol + 3 < n_out) {
-          *reinterpret_cast<float4 *>(dst) = v;
-        } else {
-          if (gcol + 0 < n_out) dst[0] = v.x;
-          if (gcol + 1 < n_out) dst[1] = v.y;
-          if (gcol + 2 < n_out) dst[2] = v.z;
-          if (gcol + 3 < n_out) dst[3] = v.w;
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // fused GRU cell
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -875,7 +516,9 @@ int num_compute_units() {
 
 // tuning knobs (developer experiments; defaults are what profiles/ measured best):
 //   PTGNN_AMD_LINEAR_NJ=1|2   tile 128x64 | 128x128          (default: by n_out)
-//   PTGNN_AMD_LINEAR_MODE=0|1|2  one-shot shared tile | persistent | wave-private staging
+//   PTGNN_AMD_LINEAR_MODE=0|1  one-shot shared tile (default) | persistent tile walk
+//   (two further variants -- wave-private operand staging and an epilogue software-pipelined under the
+//    next tile's K loop -- were measured slower and removed; numbers in profiles/r01_notes.md)
 static int linear_nj() {  // 0 = heuristic
   static int nj = -1;
   if (nj < 0) {
@@ -937,9 +580,8 @@ extern "C" int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int
 #else
   const int ablate = 0;
 #endif
-  const int mode = linear_mode();  // 0 shared-tile one-shot, 1 persistent, 2 wave-private staging
-  const bool persistent = mode == 1 || mode == 3;
-  const unsigned grid = persistent ? persistent_grid(num_tiles, mode == 3 ? (linear_bpc(0) > 0 && getenv("PTGNN_AMD_LINEAR_BPC") ? linear_bpc(nj) : (nj == 1 ? 3 : 2)) : linear_bpc(nj))
+  const bool persistent = linear_mode() == 1;   // 0 shared-tile one-shot (default), 1 persistent
+  const unsigned grid = persistent ? persistent_grid(num_tiles, linear_bpc(nj))
                                    : (unsigned)xcd_padded_blocks(num_tiles);
   const bool al = (k % 4 == 0) && (ld_x % 4 == 0) && aligned16(x) && aligned16(w);
   const int vec_store = ((ld_y % 4 == 0) && aligned16(y) ? 1 : 0) | ((bias && aligned16(bias) && n_out % 4 == 0) ? 2 : 0);
@@ -953,12 +595,6 @@ extern "C" int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int
     if (persistent)                                                                            \
       k_linear<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y, ld_y,   \
                                                   num_tiles, col_tiles, vec_store, stagger);   \
-    else if (mode == 3)                                                                        \
-      k_linear_pp<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y, ld_y,  \
-                                                     num_tiles, col_tiles, vec_store);         \
-    else if (mode == 2)                                                                        \
-      k_linear_wp<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y,      \
-                                                     ld_y, num_tiles, col_tiles, vec_store);   \
     else                                                                                       \
       k_linear_tlp<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y, ld_y, \
                                                       num_tiles, col_tiles, vec_store, ablate); \
