@@ -47,7 +47,8 @@ def ref_csr(adj, num_nodes, transposed=False):
 # ------------------------------------------------------------------------------------------------
 # plan (integer work: bit exact)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("case", ["random3", "one_empty_type", "all_empty", "hub", "single", "many_types"])
+@pytest.mark.parametrize("case", ["random3", "one_empty_type", "all_empty", "hub", "single", "many_types",
+                                  "types_over_table", "rows_over_2p18", "dense_tiny", "one_row_graph"])
 @pytest.mark.parametrize("transposed", [False, True])
 def test_csr_build_bit_exact(case, transposed):
     from ptgnn_amd import ops
@@ -62,7 +63,16 @@ def test_csr_build_bit_exact(case, transposed):
         "hub": [(ri(20000), torch.full((20000,), 7, dtype=torch.int64)), (ri(100), ri(100))],
         "single": [(ri(1), ri(1))],
         "many_types": [(ri(50 + 13 * t), ri(50 + 13 * t)) for t in range(23)],
+        # > 64 edge types: the flat LSD path with its chunked type tables
+        "types_over_table": [(ri(20 + 3 * t), ri(20 + 3 * t)) for t in range(70)],
+        # row ids beyond 18 bits: outside the two-level build's envelope
+        "rows_over_2p18": [(torch.randint(0, 300_000, (40_000,), generator=g),
+                            torch.randint(0, 300_000, (40_000,), generator=g))],
+        # 750 edges per row: every bucket of the two-level build spans many 1024-edge chunks
+        "dense_tiny": [(torch.randint(0, 40, (30_000,), generator=g), torch.randint(0, 40, (30_000,), generator=g))],
+        "one_row_graph": [(torch.zeros(5, dtype=torch.int64), torch.zeros(5, dtype=torch.int64))],
     }[case]
+    n = {"rows_over_2p18": 300_000, "dense_tiny": 40, "one_row_graph": 1}.get(case, n)
     plan = ops.build_plan(to_cuda_adj(adj), n, transposed=transposed)
     rowptr, col, perm, tb = ref_csr(adj, n, transposed)
     E = len(col)
@@ -1076,3 +1086,45 @@ def test_sharded_training_equals_unsharded_training_world1(kind, monkeypatch):
             assert float((a - b).abs().max()) <= 1e-5 * sc
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# HIP graph capture: the whole layer stack (plan build included) is capturable -- no host sync,
+# no allocation outside torch's pools -- and replays bit-identically on new node states
+# ------------------------------------------------------------------------------------------------
+def test_forward_is_hip_graph_capturable():
+    from ptgnn_amd import layers as L, ops, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    mb = workloads.batched_graphs(3, 900, 2, 7.0, seed=9)          # a PPI-sized minibatch (~3k nodes)
+    N, H, T = mb["num_nodes"], 64, 5
+    torch.manual_seed(1)
+    net = GraphNeuralNetwork([L.GatedMessagePassingLayer(H, H, T, "sum"),
+                              L.MlpMessagePassingLayer(H, H, H, T, "max")], torch.nn.Identity(),
+                             True, True).cuda().eval()
+    adj = to_cuda_adj(mb["adjacency_lists"])
+    n2g = mb["node_to_graph_idx"].cuda()
+    x_static = workloads.node_states(N, H, seed=1).cuda()
+
+    def fwd():
+        ops.clear_plan_cache()
+        return net(node_data={"input": x_static}, adjacency_lists=adj, edge_feature_data=[],
+                   node_to_graph_idx=n2g, reference_node_ids={}, reference_node_graph_idx={},
+                   num_graphs=mb["num_graphs"]).output_node_representations
+
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fwd()                                               # warm-up outside capture
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            y_static = fwd()
+        for seed in (2, 3):
+            x_new = workloads.node_states(N, H, seed=seed).cuda()
+            x_static.copy_(x_new)
+            graph.replay()
+            got = y_static.clone()
+            want = fwd()
+            assert torch.equal(got, want)
