@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from ptgnn_amd import ops
-from ptgnn_amd.layers import AbstractMessagePassingLayer
+from ptgnn_amd.layers import AbstractMessagePassingLayer, forward_scope
 
 try:
     from ptgnn.neuralmodels.gnn.structs import GnnOutput  # type: ignore
@@ -132,13 +132,14 @@ class GraphNeuralNetwork(ModuleWithMetrics):
             # one sort for the whole stack; layers find it through the identity-keyed plan cache
             ops.plan_for(adjacency_lists, node_representations.shape[0])
         all_states = [node_representations]
-        for mp_layer in self.__message_passing_layers:                # :122-131
-            node_representations = mp_layer(
-                node_states=node_representations, adjacency_lists=adjacency_lists,
-                node_to_graph_idx=node_to_graph_idx, reference_node_ids=reference_node_ids,
-                reference_node_graph_idx=reference_node_graph_idx,
-                edge_features=edge_feature_embeddings)
-            all_states.append(node_representations)
+        with forward_scope():   # tied layers share their stacked weights within this forward
+            for mp_layer in self.__message_passing_layers:            # :122-131
+                node_representations = mp_layer(
+                    node_states=node_representations, adjacency_lists=adjacency_lists,
+                    node_to_graph_idx=node_to_graph_idx, reference_node_ids=reference_node_ids,
+                    reference_node_graph_idx=reference_node_graph_idx,
+                    edge_features=edge_feature_embeddings)
+                all_states.append(node_representations)
         if return_all_states:
             node_representations = torch.cat(all_states, dim=-1)
         return node_representations

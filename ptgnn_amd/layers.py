@@ -20,6 +20,7 @@ Everything else (training with grad, per-edge dropout, edge features, deeper edg
 aggregation modules) takes the general per-edge path: torch dense ops on the GPU plus the HIP
 segment-reduce seam with its autograd rule (ptgnn_amd/scatter.py).  Neither path runs on the CPU.
 """
+import contextlib
 from typing import Dict, List, Optional, Tuple, Union
 
 import torch
@@ -62,6 +63,35 @@ except Exception:  # standalone (e.g. the GPU box): identical interface
             raise NotImplementedError
 
 Adj = List[Tuple[torch.Tensor, torch.Tensor]]
+
+
+# Tensors derived from parameters that may be shared by the layer calls of ONE forward pass (e.g. the
+# stacked per-type weights of a tied GGNN layer that the Typilus stack applies seven times): inside a
+# `forward_scope()` -- ptgnn_amd.gnn.GraphNeuralNetwork opens one around its layer loop -- they are built
+# once, so autograd accumulates one stacked gradient per use instead of T small ones.  Outside a scope
+# nothing is cached (the autograd graph of a cached tensor must not outlive its forward).
+_FORWARD_SCOPE: Optional[dict] = None
+
+
+@contextlib.contextmanager
+def forward_scope():
+    global _FORWARD_SCOPE
+    outer = _FORWARD_SCOPE
+    if outer is None:
+        _FORWARD_SCOPE = {}
+    try:
+        yield
+    finally:
+        _FORWARD_SCOPE = outer
+
+
+def _scoped(key, make):
+    if _FORWARD_SCOPE is None or not torch.is_grad_enabled():
+        return make()
+    val = _FORWARD_SCOPE.get(key)
+    if val is None:
+        val = _FORWARD_SCOPE[key] = make()
+    return val
 
 
 def _versions(params) -> Tuple:
@@ -222,9 +252,9 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                 and (p > 0 or _prefer_edge_path(plan.num_edges, num_nodes, T, self.__state_dimension, M))):
             # training, edge form: grouped per-edge GEMM with the reference's per-edge input dropout
             # folded in (forward + both gradients on HIP), HIP segment reduce, torch GRU cell
-            msgs = edge_linear_autograd(node_states, plan,
-                                        [l.weight for l in self.__edge_message_transformation_layers],
-                                        False, p, _dropout_seed() if p > 0 else 0)
+            w_stack = _scoped((id(self), "edge_w"), lambda: torch.stack(
+                [l.weight for l in self.__edge_message_transformation_layers]))
+            msgs = edge_linear_autograd(node_states, plan, w_stack, False, p, _dropout_seed() if p > 0 else 0)
             agg = segment_reduce(msgs, plan, self.__aggregation_fn)
             return dense.gru_cell(gru, agg, node_states)
 
@@ -474,7 +504,8 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             if _edge_training_ok(H, M) and _prefer_edge_path(plan.num_edges, num_nodes, T, H, M):
                 # training, many sparse edge types: grouped per-edge GEMM forward + backward on HIP
                 # (the edge MLPs of this layer carry no dropout: mlpmessagepassing.py:39-47)
-                msgs = edge_linear_autograd(node_states, plan, ws, self.__use_target_state_as_message_input)
+                w_stack = _scoped((id(self), "edge_w"), lambda: torch.stack(ws))
+                msgs = edge_linear_autograd(node_states, plan, w_stack, self.__use_target_state_as_message_input)
                 return self._update(segment_reduce(msgs, plan, self.__aggregation_fn), False)
             # training: dense blocks through torch autograd, aggregation fwd + bwd on the HIP kernel
             parts = [w[:, :H] for w in ws]

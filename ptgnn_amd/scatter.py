@@ -182,34 +182,31 @@ class _EdgeLinear(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, plan, use_dst, dropout_p, dropout_seed, *weights):
+    def forward(ctx, x, plan, use_dst, dropout_p, dropout_seed, w_stack):
         adj = plan._adj
         drop = (1, dropout_p, dropout_seed) if dropout_p > 0.0 else None
-        msg = ops.edge_linear(x, adj, weights, use_dst, dropout=drop)
+        msg = ops.edge_linear(x, adj, list(w_stack.unbind(0)), use_dst, dropout=drop)
         ctx.plan, ctx.use_dst, ctx.drop = plan, use_dst, (dropout_p, dropout_seed)
-        ctx.save_for_backward(x, *weights)
+        ctx.save_for_backward(x, w_stack)
         return msg
 
     @staticmethod
     def backward(ctx, grad_msg):
-        x, *weights = ctx.saved_tensors
+        x, w_stack = ctx.saved_tensors
         plan, use_dst = ctx.plan, ctx.use_dst
         p, seed = ctx.drop
         adj = plan._adj
         H = x.shape[1]
         gm = grad_msg.contiguous()
         need_x = ctx.needs_input_grad[0]
-        need_w = any(ctx.needs_input_grad[5:])
-        d_x = None
-        d_ws = [None] * len(weights)
-        if need_w:
-            gw = ops.edge_weight_grad(x, adj, gm, use_dst, p, seed)            # [T, M, K]
-            d_ws = [gw[t] if ctx.needs_input_grad[5 + t] else None for t in range(len(weights))]
+        d_x = d_w = None
+        if ctx.needs_input_grad[5]:
+            d_w = ops.edge_weight_grad(x, adj, gm, use_dst, p, seed)           # [T, M, K], one tensor
         if need_x:
             if plan.num_edges == 0:
                 d_x = torch.zeros_like(x)
             else:
-                wt = torch.stack([w.detach() for w in weights]).transpose(1, 2).contiguous()   # [T, K, M]
+                wt = w_stack.detach().transpose(1, 2).contiguous()                             # [T, K, M]
                 drop = (2, p, seed) if p > 0.0 else None
                 g_in = ops.edge_linear(gm, [(i, i) for i in plan.identity_index()], list(wt.unbind(0)),
                                        False, dropout=drop)                                   # [E, K]
@@ -220,15 +217,18 @@ class _EdgeLinear(torch.autograd.Function):
                     d_x = d_x + ops.gather_reduce(g_in[:, H:], plan, H, "sum", type_bits=0, col=plan.perm)
                 if d_x.shape[0] != x.shape[0]:   # plans over a halo table: rows past the sources are zero
                     d_x = torch.nn.functional.pad(d_x, (0, 0, 0, x.shape[0] - d_x.shape[0]))
-        return (d_x, None, None, None, None, *d_ws)
+        return d_x, None, None, None, None, d_w
 
 
 def edge_linear(x: torch.Tensor, plan: "ops.GraphPlan", weights, use_dst: bool, dropout_p: float = 0.0,
                 dropout_seed: int = 0) -> torch.Tensor:
-    """Differentiable grouped per-edge Linear over the plan's adjacency lists (see `_EdgeLinear`)."""
+    """Differentiable grouped per-edge Linear over the plan's adjacency lists (see `_EdgeLinear`).
+    `weights`: the per-type nn.Linear weights as a list, or already stacked [T, M, K] (a stack shared by
+    the tied layers of a forward makes autograd accumulate ONE [T, M, K] gradient per use instead of T)."""
     if plan._adj is None:
         raise _lib.PtgnnAmdError("edge_linear: the plan must keep its adjacency lists")
-    return _EdgeLinear.apply(x, plan, bool(use_dst), float(dropout_p), int(dropout_seed), *weights)
+    w_stack = weights if isinstance(weights, torch.Tensor) else torch.stack(list(weights))
+    return _EdgeLinear.apply(x, plan, bool(use_dst), float(dropout_p), int(dropout_seed), w_stack)
 
 
 class _GatherReduce(torch.autograd.Function):
