@@ -16,9 +16,18 @@ dropout inactive, no edge features, single-Linear edge transform) takes the fuse
 using  Linear_t(x_src) == (X W_t^T)[src]  (a bias-free Linear commutes with the row gather) and,
 for the MLP layer with target state,  W_t [x_u ; x_v] = W_t^s x_u + W_t^d x_v.
 
-Everything else (training with grad, per-edge dropout, edge features, deeper edge MLPs, custom
-aggregation modules) takes the general per-edge path: torch dense ops on the GPU plus the HIP
-segment-reduce seam with its autograd rule (ptgnn_amd/scatter.py).  Neither path runs on the CPU.
+With many sparse edge types the per-node table is replaced by ONE grouped per-edge GEMM over all types
+(edge_gemm.hip), picked per minibatch.
+
+Training (grad required) runs on the same kernels: the edge form is one autograd node
+(ptgnn_amd/scatter.py `edge_linear`: grouped GEMM forward, split-edge weight-gradient GEMM, input
+gradient through the same grouped GEMM + HIP segment-sum) with the GGNN layer's per-edge dropout folded
+in as a counter-based hash mask; the table form differentiates through `scatter.gather_reduce` (backward
+= the gather-reduce kernel over a backward plan); GRU / Linear blocks are `ptgnn_amd/dense.py` nodes.
+
+Edge features, deeper edge MLPs, custom aggregation modules and widths the kernels do not tile take the
+general per-edge path: torch dense ops on the GPU plus the HIP segment-reduce seam with its autograd
+rule.  No path runs on the CPU.
 """
 import contextlib
 from typing import Dict, List, Optional, Tuple, Union
