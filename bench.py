@@ -1,19 +1,24 @@
 #!/usr/bin/env python
-"""bench.py -- edges/s per message-passing layer on MI355X (BASELINE.json metric).
+"""bench.py -- edges/s (and nodes/s) per message-passing layer on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one minibatch whose inputs are already resident in
 HBM: build the graph plan (dst-sorted CSR) for that minibatch + every message-passing layer of the
 workload.  Nothing is cached across steps (the plan cache is cleared each step).
 
-Primary workload (N=1): BASELINE.json configs[1] -- synthetic random graph, 200k nodes / 1.1M
-edges, one MLP-MP layer, hidden 128, sum aggregation, fp32.  The Graph2Class-style batch
-(configs[2], 8 GGNN layers, T=17) is measured in the same run and reported under "graph2class".
-For N>1 the graph is sharded by destination-node range (weak scaling: every rank owns 200k
-nodes and their 1.1M in-edges, sources uniform over all N*200k nodes) with one RCCL all-to-all of
-de-duplicated halo rows per layer.
+Primary workload: the batch BASELINE.json quotes its metric on -- the Graph2Class-style batch of
+configs[2] (48 graphs, ~116k nodes, 8 raw -> 17 edge types, Typilus GGNN stack: 8 GGNN layers,
+hidden 128, max aggregation, fp32, forward).  `value` = E / t_layer (edges per second per message-passing
+layer, E counted after reverse + self augmentation).  At N=1 the same run also reports configs[1]
+(synthetic 200k-node / 1.1M-edge graph, one MLP-MP layer) under "config2", the training step of the
+Graph2Class stack under "graph2class_train", and the CPU restatement under "cpu_baseline".
+
+N>1: the path partitions over whole graphs (a minibatch is a disjoint union; the reference's own
+multi-GPU mode hands whole graphs to ranks), so every rank runs the single-GPU step on ITS OWN
+Graph2Class batch: no data-path collective, weak scaling.  `--workload cfg2 --sharded-variants` times the
+dst-range-sharded code path (ptgnn_amd.sharded: halo all-to-all over RCCL) as secondary entries.
 
 Prints ONE JSON line on rank 0.
 """
@@ -38,7 +43,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
+    p.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--force-sharded", action="store_true",
@@ -80,6 +85,15 @@ def barrier_sync(world):
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
+
+
+def sum_over_ranks(value, world, dev):
+    if world == 1:
+        return value
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
 
 
 def max_over_ranks(seconds, world, dev):
@@ -136,21 +150,25 @@ def step_cfg2(st, world):
         return sharded.layer_forward(st["layer"], st)
 
 
-def make_cfg3(dev):
+def make_cfg3(dev, rank=0):
+    """configs[2]; every rank builds its own batch of 48 graphs (seed + rank)."""
     from ptgnn_amd import layers as L, workloads
     from ptgnn_amd.gnn import GraphNeuralNetwork
     H = 128
-    mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234)
+    mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234 + rank)
     T = 17
     torch.manual_seed(1234)
     ggnn = L.GatedMessagePassingLayer(H, H, T, "max")
     r1 = L.ConcatResidualLayer(H)
     last = L.GatedMessagePassingLayer(2 * H, H, T, "max")
     mods = [r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last]
+    specs = ([{"kind": "residual_origin", "name": "r1"}] + [ggnn.export_weights()] * 7
+             + [{"kind": "residual_concat", "name": "r1"}, last.export_weights()])
     net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).to(dev).eval()
     N = mb["num_nodes"]
     E_raw = sum(int(a[0].shape[0]) for a in mb["adjacency_lists"])
-    return {"net": net, "x": workloads.node_states(N, H, seed=5).to(dev),
+    x_cpu = workloads.node_states(N, H, seed=5 + rank)
+    return {"net": net, "x": x_cpu.to(dev), "cpu_x": x_cpu, "cpu_adj": mb["adjacency_lists"], "specs": specs,
             "adj": [(s.to(dev), d.to(dev)) for s, d in mb["adjacency_lists"]],
             "n2g": mb["node_to_graph_idx"].to(dev),
             "refs": {k: v.to(dev) for k, v in mb["reference_node_ids"].items()},
@@ -311,6 +329,28 @@ def cpu_baseline_cfg2(st):
                       "torch-CPU fp32 restatement of the reference layer (oracle/mp_oracle.py)"}
 
 
+def cpu_baseline_cfg3(st):
+    """The CPU restatement of the reference path (oracle = 'port') on this box's host cores over the SAME
+    Graph2Class batch and weights: one untimed + up to two timed 8-layer forwards (bounded to ~30 s)."""
+    from oracle import mp_oracle as O
+    ts = []
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True)
+        first = time.perf_counter() - t0
+        for _ in range(2 if first < 10.0 else 1):
+            t0 = time.perf_counter()
+            O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True)
+            ts.append(time.perf_counter() - t0)
+    best = min(ts)
+    layers = st["layers_per_step"]
+    return {"value": round(st["E"] / (best / layers), 1), "unit": "edges/s", "cores": torch.get_num_threads(),
+            "kind": "port", "host_cpus": os.cpu_count(),
+            "sample": f"the full Graph2Class batch (N={st['N']}, E={st['E']}), {layers}-layer GGNN stack forward, "
+                      f"1 untimed + {len(ts)} timed, best = {best:.3f}s; torch-CPU fp32 restatement of the "
+                      "reference layers (oracle/mp_oracle.py)"}
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
@@ -323,15 +363,16 @@ def main():
         st = make_cfg2(dev, rank, world, args.force_sharded or args.global_ids, args.cut_edges)
         step = lambda: step_cfg2(st, world)  # noqa: E731
     else:
-        if world > 1:
-            raise SystemExit("cfg3 is a single-GPU workload (whole graphs; shard by graph = replicas)")
-        st = make_cfg3(dev)
+        if args.force_sharded:
+            raise SystemExit("the sharded variants are cfg2 runs: add --workload cfg2")
+        st = make_cfg3(dev, rank)
         step = lambda: step_cfg3(st)  # noqa: E731
 
     seconds, summary = timed_region(step, args.steps, args.warmup, world, dev)
     ms_per_step = seconds / args.steps * 1e3
     layers = st["layers_per_step"]
-    edges_all_ranks = st["E"] * world
+    edges_all_ranks = sum_over_ranks(st["E"], world, dev)      # per-rank batches differ in size
+    nodes_all_ranks = sum_over_ranks(st["N"], world, dev)
     value = edges_all_ranks / (seconds / args.steps / layers)
     ktab = kernel_table(summary)
     dominant = max(ktab, key=lambda k: ktab[k]["total_ms"])
@@ -349,13 +390,16 @@ def main():
                    "hidden": st["H"], "mp_layers_per_step": layers, "mode": "forward (inference), fp32",
                    "plan_build_in_step": True,
                    "parallelism": ("single GPU" if world == 1 else
-                                   f"{world} GPUs x whole graphs, no data-path collective") if "adj" in st else (
+                                   f"{world} GPUs x whole graphs (one batch per GPU), no data-path collective")
+                   if "adj" in st else (
                        f"dst-range shard x{world} + halo all-to-all per layer" if st.get("cut_edges") else
                        f"dst-range shard x{world} on graph boundaries (no cut edges => no data-path collective)")},
-        "nodes_per_sec_per_layer": round(st["N"] * world / (seconds / args.steps / layers), 1),
+        "nodes_per_sec_per_layer": round(nodes_all_ranks / (seconds / args.steps / layers), 1),
         "edges_per_sec_readme_convention": round(edges_all_ranks / (seconds / args.steps), 1),
         "roofline": roof, "kernels": ktab,
     }
+    if args.workload == "cfg3":
+        result["vs_readme_v100_inference_2527k"] = round(result["edges_per_sec_readme_convention"] / world / 2.527e6, 2)
 
     if world > 1 and args.workload == "cfg2" and "adj" in st and args.sharded_variants:
         # the same weak-scaling work through ptgnn_amd.sharded: (a) global ids, partition on graph boundaries
@@ -372,23 +416,34 @@ def main():
                 result[key] = {"error": f"{type(exc).__name__}: {exc}"}
                 break              # ranks may have diverged: do not enter another collective section
     if rank == 0 and world == 1 and not args.force_sharded:
-        if args.workload == "cfg2" and not args.no_secondary:
-            st3 = make_cfg3(dev)
-            k3 = max(10, args.steps // 2)
-            sec3, sum3 = timed_region(lambda: step_cfg3(st3), k3, 3, 1, dev)
-            result["graph2class"] = {
-                "workload": st3["desc"], "ms_per_forward": round(sec3 / k3 * 1e3, 4),
-                "edges_per_sec_per_layer": round(st3["E"] / (sec3 / k3 / 8), 1),
-                "nodes_per_sec_per_layer": round(st3["N"] / (sec3 / k3 / 8), 1),
-                "edges_per_sec_readme_convention": round(st3["E"] / (sec3 / k3), 1),
-                "vs_readme_v100_inference_2527k": round(st3["E"] / (sec3 / k3) / 2.527e6, 2),
-                "kernels": kernel_table(sum3)}
-            del st3
+        if not args.no_secondary:
+            if args.workload == "cfg3":    # configs[1]: the synthetic 200k / 1.1M graph, one MLP-MP layer
+                st2 = make_cfg2(dev, 0, 1)
+                k2 = max(10, args.steps)
+                sec2, sum2 = timed_region(lambda: step_cfg2(st2, 1), k2, 3, 1, dev)
+                kt2 = kernel_table(sum2)
+                result["config2"] = {
+                    "workload": st2["desc"], "ms_per_step": round(sec2 / k2 * 1e3, 4),
+                    "edges_per_sec_per_layer": round(st2["E"] / (sec2 / k2), 1),
+                    "nodes_per_sec_per_layer": round(st2["N"] / (sec2 / k2), 1), "kernels": kt2}
+                del st2
+            else:
+                st3 = make_cfg3(dev)
+                k3 = max(10, args.steps // 2)
+                sec3, sum3 = timed_region(lambda: step_cfg3(st3), k3, 3, 1, dev)
+                result["graph2class"] = {
+                    "workload": st3["desc"], "ms_per_forward": round(sec3 / k3 * 1e3, 4),
+                    "edges_per_sec_per_layer": round(st3["E"] / (sec3 / k3 / 8), 1),
+                    "nodes_per_sec_per_layer": round(st3["N"] / (sec3 / k3 / 8), 1),
+                    "edges_per_sec_readme_convention": round(st3["E"] / (sec3 / k3), 1),
+                    "vs_readme_v100_inference_2527k": round(st3["E"] / (sec3 / k3) / 2.527e6, 2),
+                    "kernels": kernel_table(sum3)}
+                del st3
             torch.cuda.empty_cache()
             result["graph2class_train"] = [train_cfg3(dev, 0.0), train_cfg3(dev, 0.1)]
             torch.cuda.empty_cache()
-        if args.workload == "cfg2" and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_cfg2(st)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_cfg2(st) if args.workload == "cfg2" else cpu_baseline_cfg3(st)
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
         dist.barrier()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + separate PMC passes of bench.py.
-# Usage: scripts/gpu_profile.sh <tag> [bench args...]
+# Usage: scripts/gpu_profile.sh <tag> [bench args...]   (bench default workload = cfg3; pass --workload cfg2 for config 2)
 set -u
 TAG=${1:-r01}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
