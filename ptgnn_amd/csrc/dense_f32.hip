@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(256, 2) void k_gru(const float *__restrict__ a, int64_t ld_a,
+__global__ __launch_bounds__(256, 3) void k_gru(const float *__restrict__ a, int64_t ld_a,
                                                 const float *__restrict__ h, int64_t ld_h,
                                                 const float *__restrict__ w_ih,
                                                 const float *__restrict__ w_hh,
@@ -415,9 +415,8 @@ __global__ __launch_bounds__(256, 2) void k_gru(const float *__restrict__ a, int
   const int li = lane & 31, hi = lane >> 5;
 
   f32x16 acc_r, acc_z, acc_in, acc_hn;
-  float hprev[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_in[r] = 0.f; acc_hn[r] = 0.f; hprev[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_in[r] = 0.f; acc_hn[r] = 0.f; }
 
   Stager<128, ALIGNED, RowClamp> sa;
   Stager<96, ALIGNED, GateRows> sb;
@@ -437,39 +436,37 @@ __global__ __launch_bounds__(256, 2) void k_gru(const float *__restrict__ a, int
     }
   };
   issue(0);
-  for (int c = 0; c < total; ++c) {
+  const float *arow = As + (wave * 32) * LDS_LD;
+  const float *ap = arow + li * LDS_LD + hi;
+  const float *bp = Bs + li * LDS_LD + hi;
+  for (int c = 0; c < chunks0; ++c) {
     __syncthreads();
     sa.store(As);
     sb.store(Bs);
     __syncthreads();
     if (c + 1 < total) issue(c + 1);
-    const float *arow = As + (wave * 32) * LDS_LD;
-    const float *ap = arow + li * LDS_LD + hi;
-    const float *bp = Bs + li * LDS_LD + hi;
-    if (c < chunks0) {
 #pragma unroll
-      for (int ks = 0; ks < BK / 2; ++ks) {
-        const float av = ap[ks * 2];
-        const float br = bp[ks * 2], bz = bp[32 * LDS_LD + ks * 2], bn = bp[64 * LDS_LD + ks * 2];
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bz, acc_z, 0, 0, 0);
-        acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bn, acc_in, 0, 0, 0);
-      }
-    } else {
-      if ((c - chunks0) * BK == j0) {
-        // this K-chunk of h IS h[rows, j0 .. j0+31]: keep the epilogue's h values (C layout)
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const float av = ap[ks * 2];
+      const float br = bp[ks * 2], bz = bp[32 * LDS_LD + ks * 2], bn = bp[64 * LDS_LD + ks * 2];
+      acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br, acc_r, 0, 0, 0);
+      acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bz, acc_z, 0, 0, 0);
+      acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bn, acc_in, 0, 0, 0);
+    }
+  }
+  for (int c = chunks0; c < total; ++c) {
+    __syncthreads();
+    sa.store(As);
+    sb.store(Bs);
+    __syncthreads();
+    if (c + 1 < total) issue(c + 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          hprev[r] = arow[((r & 3) + 8 * (r >> 2) + 4 * hi) * LDS_LD + li];
-      }
-#pragma unroll
-      for (int ks = 0; ks < BK / 2; ++ks) {
-        const float av = ap[ks * 2];
-        const float br = bp[ks * 2], bz = bp[32 * LDS_LD + ks * 2], bn = bp[64 * LDS_LD + ks * 2];
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bz, acc_z, 0, 0, 0);
-        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bn, acc_hn, 0, 0, 0);
-      }
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const float av = ap[ks * 2];
+      const float br = bp[ks * 2], bz = bp[32 * LDS_LD + ks * 2], bn = bp[64 * LDS_LD + ks * 2];
+      acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br, acc_r, 0, 0, 0);
+      acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bz, acc_z, 0, 0, 0);
+      acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bn, acc_hn, 0, 0, 0);
     }
   }
 
@@ -478,6 +475,16 @@ __global__ __launch_bounds__(256, 2) void k_gru(const float *__restrict__ a, int
   if (j >= H) return;
   const float bir = b_ih[j], biz = b_ih[H + j], bin = b_ih[2 * H + j];
   const float bhr = b_hh[j], bhz = b_hh[H + j], bhn = b_hh[2 * H + j];
+  // the previous state of this lane's 16 output elements: re-read from global memory (L2-hot -- the K
+  // loop just streamed these rows) instead of holding 16 more registers across the whole K loop; rows
+  // past the end are clamped, their results are never stored
+  float hprev[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    row = row < n ? row : n - 1;
+    hprev[r] = h[row * ld_h + j];
+  }
   // torch.nn.GRUCell: gi = W_ih x + b_ih, gh = W_hh h + b_hh
   float res[16];
 #pragma unroll
