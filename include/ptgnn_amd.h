@@ -263,6 +263,23 @@ int ptgnn_amd_linear_weight_grad_f32(const float *x, int64_t ld_x, int32_t k, co
                                      size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training form of the fused GRU cell (autograd of nn.GRUCell, gatedmessagepassing.py:25,69).
+ * ptgnn_amd_gru_cell_train_f32: as ptgnn_amd_gru_cell_f32, additionally writes
+ *   gates [n, 4*hd] = [ r | z | n | gh_n ]  (gh_n = W_hn h + b_hn) for the backward.
+ * ptgnn_amd_gru_cell_backward_gates_f32: the gate math's backward,
+ *   d_gi [n, 3hd], d_gh [n, 3hd] (gradients of the two gate pre-activations, gate order r, z, n) and
+ *   d_h [n, hd] = grad_out * z (the direct path); the GEMM halves follow with ptgnn_amd_linear_f32 /
+ *   ptgnn_amd_linear_weight_grad_f32.  Requires hd % 4 == 0 and 16-byte aligned rows.
+ * ---------------------------------------------------------------------------------------- */
+int ptgnn_amd_gru_cell_train_f32(const float *a, int64_t ld_a, const float *h, int64_t ld_h,
+                                 const float *w_ih, const float *w_hh, const float *b_ih,
+                                 const float *b_hh, int64_t n, int32_t m, int32_t hd, float *out,
+                                 int64_t ld_out, float *gates, void *stream);
+int ptgnn_amd_gru_cell_backward_gates_f32(const float *grad_out, int64_t ld_grad_out, const float *gates,
+                                          const float *h, int64_t ld_h, int64_t n, int32_t hd,
+                                          float *d_gi, float *d_gh, float *d_h, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Backward of the segment reduce w.r.t. the message matrix (the autograd torch_scatter supplies
  * behind abstractmessagepassing.py:44-50):
  *   out[perm[s], :] = grad[slot_row[s], :]                                   sum / mean (pre-scaled)

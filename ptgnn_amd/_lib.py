@@ -46,6 +46,10 @@ SIGNATURES = {
     "ptgnn_amd_segment_spread_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "ptgnn_amd_gru_cell_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                           _vp, _i64, _vp]),
+    "ptgnn_amd_gru_cell_train_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
+                                                _vp, _i64, _vp, _vp]),
+    "ptgnn_amd_gru_cell_backward_gates_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp,
+                                                         _vp]),
     "ptgnn_amd_gather_rows_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
 }
 

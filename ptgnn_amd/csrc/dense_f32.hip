@@ -401,7 +401,8 @@ __global__ __launch_bounds__(256, 3) void k_gru(const float *__restrict__ a, int
                                                 const float *__restrict__ b_ih,
                                                 const float *__restrict__ b_hh, int64_t n, int M,
                                                 int H, float *__restrict__ out, int64_t ld_out,
-                                                int64_t num_tiles, int col_tiles) {
+                                                int64_t num_tiles, int col_tiles,
+                                                float *__restrict__ gates) {
   constexpr int B_FLOATS = 96 * LDS_LD;
   __shared__ __attribute__((aligned(16))) float smem[TILE_FLOATS + B_FLOATS];
   float *const As = smem, *const Bs = smem + TILE_FLOATS;
@@ -487,12 +488,30 @@ __global__ __launch_bounds__(256, 3) void k_gru(const float *__restrict__ a, int
   }
   // torch.nn.GRUCell: gi = W_ih x + b_ih, gh = W_hh h + b_hh
   float res[16];
+  if (gates) {
+    // training: keep r, z, n and gh_n = W_hn h + b_hn ([n, 4H], gate-major) for the backward
+    // (ptgnn_amd_gru_cell_backward_gates_f32); same arithmetic as the inference branch below
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float rg_ = sigmoidf_((acc_r[r] + bir) + bhr);
-    const float zg = sigmoidf_((acc_z[r] + biz) + bhz);
-    const float ng = tanhf((acc_in[r] + bin) + rg_ * (acc_hn[r] + bhn));
-    res[r] = (1.0f - zg) * ng + zg * hprev[r];
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float rg_ = sigmoidf_((acc_r[r] + bir) + bhr);
+      const float zg = sigmoidf_((acc_z[r] + biz) + bhz);
+      const float hn = acc_hn[r] + bhn;
+      const float ng = tanhf((acc_in[r] + bin) + rg_ * hn);
+      res[r] = (1.0f - zg) * ng + zg * hprev[r];
+      if (row < n) {
+        float *gp = gates + row * (int64_t)(4 * H) + j;
+        gp[0] = rg_; gp[H] = zg; gp[2 * H] = ng; gp[3 * H] = hn;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float rg_ = sigmoidf_((acc_r[r] + bir) + bhr);
+      const float zg = sigmoidf_((acc_z[r] + biz) + bhz);
+      const float ng = tanhf((acc_in[r] + bin) + rg_ * (acc_hn[r] + bhn));
+      res[r] = (1.0f - zg) * ng + zg * hprev[r];
+    }
   }
   float *dst = out + (row0 + wave * 32 + 4 * hi) * ld_out + j;
   if (row0 + 128 <= n) {  // interior tile: straight-line stores (2 x 128 B per wave-instruction)
@@ -504,6 +523,54 @@ __global__ __launch_bounds__(256, 3) void k_gru(const float *__restrict__ a, int
       const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (row < n) out[row * ld_out + j] = res[r];
     }
+  }
+}
+
+// Backward of the GRU gate math (everything between the two gate GEMMs and h'):
+//   h' = (1 - z) n + z h,  n = tanh(gi_n + r gh_n),  r, z = sigmoid(gi + gh)
+//   d_n = g (1 - z), d_z = g (h - n), d_h(direct) = g z, d_npre = d_n (1 - n^2),
+//   d_gi = [d_r r(1-r), d_z z(1-z), d_npre],  d_gh = [same, same, d_npre r],  d_r = d_npre gh_n
+// One thread per 4 hidden units of one row; 7 reads + 7 writes of H floats per row: HBM-bound.
+__global__ __launch_bounds__(256) void k_gru_gates_backward(const float *__restrict__ g, int64_t ld_g,
+                                                            const float *__restrict__ gates,
+                                                            const float *__restrict__ h, int64_t ld_h,
+                                                            int64_t n, int H, float *__restrict__ d_gi,
+                                                            float *__restrict__ d_gh,
+                                                            float *__restrict__ d_h) {
+  const int q = H / 4;
+  const int64_t total = n * q;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / q;
+    const int c = (int)(i - row * q) * 4;
+    const float4 gv = *reinterpret_cast<const float4 *>(g + row * ld_g + c);
+    const float4 hv = *reinterpret_cast<const float4 *>(h + row * ld_h + c);
+    const float *gp = gates + row * (int64_t)(4 * H) + c;
+    const float4 r = *reinterpret_cast<const float4 *>(gp);
+    const float4 z = *reinterpret_cast<const float4 *>(gp + H);
+    const float4 nn = *reinterpret_cast<const float4 *>(gp + 2 * H);
+    const float4 hn = *reinterpret_cast<const float4 *>(gp + 3 * H);
+    float4 o_r, o_z, o_n, o_hn, o_h;
+#define PTGNN_GRU_BWD(C)                                         \
+    {                                                            \
+      const float dn = gv.C * (1.0f - z.C);                      \
+      const float dz = gv.C * (hv.C - nn.C);                     \
+      const float dnp = dn * (1.0f - nn.C * nn.C);               \
+      o_h.C = gv.C * z.C;                                        \
+      o_n.C = dnp;                                               \
+      o_hn.C = dnp * r.C;                                        \
+      o_r.C = (dnp * hn.C) * (r.C * (1.0f - r.C));               \
+      o_z.C = dz * (z.C * (1.0f - z.C));                         \
+    }
+    PTGNN_GRU_BWD(x) PTGNN_GRU_BWD(y) PTGNN_GRU_BWD(z) PTGNN_GRU_BWD(w)
+#undef PTGNN_GRU_BWD
+    float *gi = d_gi + row * (int64_t)(3 * H) + c, *gh = d_gh + row * (int64_t)(3 * H) + c;
+    *reinterpret_cast<float4 *>(gi) = o_r;
+    *reinterpret_cast<float4 *>(gi + H) = o_z;
+    *reinterpret_cast<float4 *>(gi + 2 * H) = o_n;
+    *reinterpret_cast<float4 *>(gh) = o_r;
+    *reinterpret_cast<float4 *>(gh + H) = o_z;
+    *reinterpret_cast<float4 *>(gh + 2 * H) = o_hn;
+    *reinterpret_cast<float4 *>(d_h + row * (int64_t)H + c) = o_h;
   }
 }
 
@@ -620,10 +687,9 @@ extern "C" int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int
   return PTGNN_AMD_OK;
 }
 
-extern "C" int ptgnn_amd_gru_cell_f32(const float *a, int64_t ld_a, const float *h, int64_t ld_h,
-                                      const float *w_ih, const float *w_hh, const float *b_ih,
-                                      const float *b_hh, int64_t n, int32_t m, int32_t hd,
-                                      float *out, int64_t ld_out, void *stream_) {
+static int gru_launch(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const float *w_ih,
+                      const float *w_hh, const float *b_ih, const float *b_hh, int64_t n, int32_t m,
+                      int32_t hd, float *out, int64_t ld_out, float *gates, void *stream_) {
   PTGNN_REQUIRE(n >= 0 && m > 0 && hd > 0, PTGNN_AMD_EINVAL, "gru_cell: bad sizes");
   if (n == 0) return PTGNN_AMD_OK;
   PTGNN_REQUIRE(a && h && w_ih && w_hh && b_ih && b_hh && out, PTGNN_AMD_EINVAL, "gru_cell: null");
@@ -638,10 +704,46 @@ extern "C" int ptgnn_amd_gru_cell_f32(const float *a, int64_t ld_a, const float 
                   aligned16(a) && aligned16(h) && aligned16(w_ih) && aligned16(w_hh);
   if (al)
     k_gru<true><<<grid, 256, 0, (hipStream_t)stream_>>>(a, ld_a, h, ld_h, w_ih, w_hh, b_ih, b_hh, n, m, hd,
-                                                        out, ld_out, num_tiles, col_tiles);
+                                                        out, ld_out, num_tiles, col_tiles, gates);
   else
     k_gru<false><<<grid, 256, 0, (hipStream_t)stream_>>>(a, ld_a, h, ld_h, w_ih, w_hh, b_ih, b_hh, n, m, hd,
-                                                         out, ld_out, num_tiles, col_tiles);
+                                                         out, ld_out, num_tiles, col_tiles, gates);
+  PTGNN_LAUNCH_CHECK();
+  return PTGNN_AMD_OK;
+}
+
+extern "C" int ptgnn_amd_gru_cell_f32(const float *a, int64_t ld_a, const float *h, int64_t ld_h,
+                                      const float *w_ih, const float *w_hh, const float *b_ih,
+                                      const float *b_hh, int64_t n, int32_t m, int32_t hd,
+                                      float *out, int64_t ld_out, void *stream_) {
+  return gru_launch(a, ld_a, h, ld_h, w_ih, w_hh, b_ih, b_hh, n, m, hd, out, ld_out, nullptr, stream_);
+}
+
+extern "C" int ptgnn_amd_gru_cell_train_f32(const float *a, int64_t ld_a, const float *h, int64_t ld_h,
+                                            const float *w_ih, const float *w_hh, const float *b_ih,
+                                            const float *b_hh, int64_t n, int32_t m, int32_t hd,
+                                            float *out, int64_t ld_out, float *gates, void *stream_) {
+  PTGNN_REQUIRE(gates != nullptr || n == 0, PTGNN_AMD_EINVAL, "gru_cell_train: gates is null");
+  return gru_launch(a, ld_a, h, ld_h, w_ih, w_hh, b_ih, b_hh, n, m, hd, out, ld_out, gates, stream_);
+}
+
+extern "C" int ptgnn_amd_gru_cell_backward_gates_f32(const float *grad_out, int64_t ld_grad_out,
+                                                     const float *gates, const float *h, int64_t ld_h,
+                                                     int64_t n, int32_t hd, float *d_gi, float *d_gh,
+                                                     float *d_h, void *stream_) {
+  PTGNN_REQUIRE(n >= 0 && hd > 0, PTGNN_AMD_EINVAL, "gru_cell_backward_gates: bad sizes");
+  if (n == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(grad_out && gates && h && d_gi && d_gh && d_h, PTGNN_AMD_EINVAL,
+                "gru_cell_backward_gates: null pointer");
+  PTGNN_REQUIRE(hd % 4 == 0 && ld_grad_out % 4 == 0 && ld_h % 4 == 0 && ld_grad_out >= hd && ld_h >= hd &&
+                    aligned16(grad_out) && aligned16(gates) && aligned16(h) && aligned16(d_gi) &&
+                    aligned16(d_gh) && aligned16(d_h),
+                PTGNN_AMD_EUNSUPPORTED, "gru_cell_backward_gates: needs hd %% 4 == 0 and 16-byte aligned rows");
+  const int64_t items = n * (hd / 4);
+  int64_t blocks = (items + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  k_gru_gates_backward<<<(unsigned)blocks, 256, 0, (hipStream_t)stream_>>>(grad_out, ld_grad_out, gates, h,
+                                                                          ld_h, n, hd, d_gi, d_gh, d_h);
   PTGNN_LAUNCH_CHECK();
   return PTGNN_AMD_OK;
 }

@@ -5,7 +5,9 @@ The reference's layers end in `nn.GRUCell` (gatedmessagepassing.py:25,69) or `nn
 gradients are ordinary [rows, k] x [k, n] products (fp32 MFMA, `ptgnn_amd_linear_f32`); the WEIGHT
 gradients reduce over all `rows` nodes into a tiny [n, k] matrix -- a shape the vendor BLAS runs at
 ~23 TFLOP/s on MI355X -- so they use the split-row MFMA kernel of edge_wgrad.hip
-(`ptgnn_amd_linear_weight_grad_f32`, deterministic two-stage reduction).
+(`ptgnn_amd_linear_weight_grad_f32`, deterministic two-stage reduction).  The GRU cell's forward is the
+same fused kernel inference uses (it additionally emits the gates), its gate-math backward one HBM-bound
+HIP kernel.
 """
 from typing import Optional
 
@@ -52,14 +54,36 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return _Linear.apply(x, weight, bias)
 
 
+class _GruCell(torch.autograd.Function):
+    """nn.GRUCell as one autograd node: forward = the fused HIP cell (gate GEMMs + gate math, also emitting
+    r, z, n, gh_n); backward = gate-math backward kernel, then the four GEMM halves (input gradients on the
+    MFMA GEMM, weight + bias gradients on the split-row kernel)."""
+
+    @staticmethod
+    def forward(ctx, a, h, w_ih, w_hh, b_ih, b_hh):
+        out, gates = ops.gru_cell_train(a, h, w_ih, w_hh, b_ih, b_hh)
+        ctx.save_for_backward(a, h, w_ih, w_hh, gates)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, h, w_ih, w_hh, gates = ctx.saved_tensors
+        d_gi, d_gh, d_h = ops.gru_gates_backward(g.contiguous(), gates, h)
+        need = ctx.needs_input_grad
+        d_a = ops.linear(d_gi, w_ih.detach().t().contiguous()) if need[0] else None
+        d_hx = d_h + ops.linear(d_gh, w_hh.detach().t().contiguous()) if need[1] else None
+        d_wih = d_bih = d_whh = d_bhh = None
+        if need[2] or need[4]:
+            d_wih, d_bih = ops.linear_weight_grad(a, d_gi, want_bias=True)
+        if need[3] or need[5]:
+            d_whh, d_bhh = ops.linear_weight_grad(h, d_gh, want_bias=True)
+        return d_a, d_hx, d_wih, d_whh, d_bih, d_bhh
+
+
 def gru_cell(cell: torch.nn.GRUCell, a: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
-    """Differentiable nn.GRUCell: the two gate GEMMs (forward, input and weight gradients) on the HIP
-    kernels, the gate non-linearities through torch's fused pointwise GRU op and its autograd."""
-    if not (_kernel_dims_ok(a, cell.weight_ih) and _kernel_dims_ok(h, cell.weight_hh) and cell.bias):
+    """Differentiable nn.GRUCell on the HIP kernels (see `_GruCell`); widths the kernels do not tile fall
+    back to torch's cell (still on the GPU)."""
+    if not (_kernel_dims_ok(a, cell.weight_ih) and _kernel_dims_ok(h, cell.weight_hh) and cell.bias
+            and h.shape[1] % 4 == 0):
         return cell(a, h)
-    # biases go into the gate GEMMs (fused epilogue forward, column sums of the weight-gradient pass
-    # backward): the gate math  r, z = sigmoid(gi + gh),  n = tanh(gi_n + r * gh_n)  is unchanged because
-    # b_hn sits inside the r * (.) product either way (torch.nn.GRUCell definition)
-    gi = _Linear.apply(a, cell.weight_ih, cell.bias_ih)
-    gh = _Linear.apply(h, cell.weight_hh, cell.bias_hh)
-    return torch.ops.aten._thnn_fused_gru_cell(gi, gh, h, None, None)[0]
+    return _GruCell.apply(a, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)

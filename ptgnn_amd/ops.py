@@ -633,6 +633,44 @@ def gru_cell(a: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh) -> torch.
     return out
 
 
+def gru_cell_train(a: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh):
+    """Fused GRU cell that also returns the gates the backward needs: (h', gates [n, 4*hd] = r|z|n|gh_n)."""
+    lib = _lib.load()
+    _require_cuda_f32("a", a)
+    _require_cuda_f32("h", h)
+    a, h = _rowmajor(a), _rowmajor(h)
+    n, m = a.shape
+    hd = h.shape[1]
+    out = torch.empty(n, hd, dtype=torch.float32, device=a.device)
+    gates = torch.empty(n, 4 * hd, dtype=torch.float32, device=a.device)
+    with _timed("gru_cell", flops=2.0 * n * 3 * hd * (m + hd),
+                bytes=4.0 * (n * (m + 2 * hd + 4 * hd) + 3 * hd * (m + hd))):
+        rc = lib.ptgnn_amd_gru_cell_train_f32(a.data_ptr(), _ld(a), h.data_ptr(), _ld(h),
+                                              w_ih.contiguous().data_ptr(), w_hh.contiguous().data_ptr(),
+                                              b_ih.contiguous().data_ptr(), b_hh.contiguous().data_ptr(),
+                                              n, m, hd, out.data_ptr(), hd, gates.data_ptr(), _stream(out))
+    _lib.check(rc, "ptgnn_amd_gru_cell_train_f32")
+    return out, gates
+
+
+def gru_gates_backward(grad_out: torch.Tensor, gates: torch.Tensor, h: torch.Tensor):
+    """Backward of the GRU gate math: (d_gi [n, 3hd], d_gh [n, 3hd], d_h_direct [n, hd])."""
+    lib = _lib.load()
+    _require_cuda_f32("grad_out", grad_out)
+    _require_cuda_f32("h", h)
+    grad_out, h = _rowmajor(grad_out), _rowmajor(h)
+    n, hd = h.shape
+    d_gi = torch.empty(n, 3 * hd, dtype=torch.float32, device=h.device)
+    d_gh = torch.empty(n, 3 * hd, dtype=torch.float32, device=h.device)
+    d_h = torch.empty(n, hd, dtype=torch.float32, device=h.device)
+    with _timed("gru_gates_backward", bytes=4.0 * n * hd * 13):
+        rc = lib.ptgnn_amd_gru_cell_backward_gates_f32(grad_out.data_ptr(), _ld(grad_out), gates.data_ptr(),
+                                                       h.data_ptr(), _ld(h), n, hd, d_gi.data_ptr(),
+                                                       d_gh.data_ptr(), d_h.data_ptr(), _stream(d_h))
+    _lib.check(rc, "ptgnn_amd_gru_cell_backward_gates_f32")
+    return d_gi, d_gh, d_h
+
+
 def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _require_cuda_f32("x", x)
