@@ -198,22 +198,46 @@ struct RowOp {
         fold(m[u], i + u * stride);
       }
     }
-    for (; i < end; i += stride) {
-      const int32_t pk = a.col[i];
-      const int64_t s = pk >> a.type_bits;
-      const int t = pk & tmask;
-      float m[CH][VEC];
-      load_row(a.ysrc + s * a.ld_y + (int64_t)t * M, m);
-      apply_mask(m, s, i);
-      if (HAS_DST) {
-        float d[CH][VEC];
-        load_row(dst_base + (int64_t)t * M, d);
+    if (i < end) {
+      // tail of 1 .. U-1 slots as ONE more group: indices clamped to the last slot (unconditional loads,
+      // all in flight together) instead of a serial col -> row -> fold chain per slot.  A duplicate of
+      // the last slot is idempotent for max/min (strict compare) and is zeroed for the sums.
+      const int last = i + ((end - 1 - i) / stride) * stride;
+      constexpr int TU = U - 1;   // the tail holds at most U - 1 slots
+      int32_t pk[TU];
+      int idx[TU];
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) m[c][v] += d[c][v];
+      for (int u = 0; u < TU; ++u) {
+        idx[u] = i + u * stride < end ? i + u * stride : last;
+        pk[u] = a.col[idx[u]];
       }
-      fold(m, i);
+      float m[TU][CH][VEC];
+      float d[TU][CH][VEC];
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        const int64_t s = pk[u] >> a.type_bits;
+        const int t = pk[u] & tmask;
+        load_row(a.ysrc + s * a.ld_y + (int64_t)t * M, m[u]);
+        apply_mask(m[u], s, idx[u]);
+        if (HAS_DST) load_row(dst_base + (int64_t)t * M, d[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        const bool valid = i + u * stride < end;
+        if (HAS_DST) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) m[u][c][v] += d[u][c][v];
+        }
+        if (REDUCE != PTGNN_AMD_MAX && REDUCE != PTGNN_AMD_MIN) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) m[u][c][v] = valid ? m[u][c][v] : 0.f;
+        }
+        fold(m[u], idx[u]);
+      }
     }
   }
 
