@@ -486,31 +486,39 @@ __global__ __launch_bounds__(256, 3) void k_gru(const float *__restrict__ a, int
     row = row < n ? row : n - 1;
     hprev[r] = h[row * ld_h + j];
   }
-  // torch.nn.GRUCell: gi = W_ih x + b_ih, gh = W_hh h + b_hh
+  // torch.nn.GRUCell: gi = W_ih x + b_ih, gh = W_hh h + b_hh.
+  // No mul+add contraction in the gate math: the 16 elements of a lane are 16 different ROWS, and the
+  // compiler otherwise fuses some element pairs (packed fp32 ops) and not others, which makes a row's
+  // result depend on where it sits in the tile (1 ulp) -- sharded and unsharded runs must agree bit for
+  // bit.  Every op below is individually rounded, like the reference's torch ops.
   float res[16];
-  if (gates) {
-    // training: keep r, z, n and gh_n = W_hn h + b_hn ([n, 4H], gate-major) for the backward
-    // (ptgnn_amd_gru_cell_backward_gates_f32); same arithmetic as the inference branch below
+  {
+#pragma clang fp contract(off)
+    if (gates) {
+      // training: keep r, z, n and gh_n = W_hn h + b_hn ([n, 4H], gate-major) for the backward
+      // (ptgnn_amd_gru_cell_backward_gates_f32); same arithmetic as the inference branch below
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const float rg_ = sigmoidf_((acc_r[r] + bir) + bhr);
-      const float zg = sigmoidf_((acc_z[r] + biz) + bhz);
-      const float hn = acc_hn[r] + bhn;
-      const float ng = tanhf((acc_in[r] + bin) + rg_ * hn);
-      res[r] = (1.0f - zg) * ng + zg * hprev[r];
-      if (row < n) {
-        float *gp = gates + row * (int64_t)(4 * H) + j;
-        gp[0] = rg_; gp[H] = zg; gp[2 * H] = ng; gp[3 * H] = hn;
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float rg_ = sigmoidf_((acc_r[r] + bir) + bhr);
+        const float zg = sigmoidf_((acc_z[r] + biz) + bhz);
+        const float hn = acc_hn[r] + bhn;
+        const float ng = tanhf((acc_in[r] + bin) + rg_ * hn);
+        res[r] = (1.0f - zg) * ng + zg * hprev[r];
+        if (row < n) {
+          float *gp = gates + row * (int64_t)(4 * H) + j;
+          gp[0] = rg_; gp[H] = zg; gp[2 * H] = ng; gp[3 * H] = hn;
+        }
       }
-    }
-  } else {
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float rg_ = sigmoidf_((acc_r[r] + bir) + bhr);
-      const float zg = sigmoidf_((acc_z[r] + biz) + bhz);
-      const float ng = tanhf((acc_in[r] + bin) + rg_ * (acc_hn[r] + bhn));
-      res[r] = (1.0f - zg) * ng + zg * hprev[r];
+      for (int r = 0; r < 16; ++r) {
+        const float rg_ = sigmoidf_((acc_r[r] + bir) + bhr);
+        const float zg = sigmoidf_((acc_z[r] + biz) + bhz);
+        const float hn = acc_hn[r] + bhn;
+        const float ng = tanhf((acc_in[r] + bin) + rg_ * hn);
+        res[r] = (1.0f - zg) * ng + zg * hprev[r];
+      }
     }
   }
   float *dst = out + (row0 + wave * 32 + 4 * hi) * ld_out + j;
