@@ -12,9 +12,9 @@ from typing import NamedTuple, Union
 import torch
 from torch import nn
 
-from ptgnn_amd import _lib, ops
+from ptgnn_amd import _lib, dense, ops
 from ptgnn_amd.layers import AbstractMessagePassingLayer, _check_device, _no_grad_needed
-from ptgnn_amd.scatter import segment_reduce
+from ptgnn_amd.scatter import gather_rows as gather_rows_autograd, segment_reduce
 
 
 class ElementsToSummaryRepresentationInput(NamedTuple):
@@ -79,10 +79,13 @@ class AbstractGlobalGraphExchange(AbstractMessagePassingLayer):
         num_graphs = int(node_to_graph_idx[-1]) + 1 if node_to_graph_idx.numel() else 0
         e = ElementsToSummaryRepresentationInput(node_states, node_to_graph_idx, num_graphs)
         graph_reps = self.__dropout(self.__global_graph_representation_module(e))
-        if graph_reps.dtype == torch.float32 and _no_grad_needed(graph_reps):
-            per_node = ops.gather_rows(graph_reps.contiguous(), node_to_graph_idx)
-        else:
+        if graph_reps.dtype != torch.float32:
             per_node = graph_reps[node_to_graph_idx]
+        elif _no_grad_needed(graph_reps):
+            per_node = ops.gather_rows(graph_reps.contiguous(), node_to_graph_idx)
+        else:   # training: HIP row gather whose backward is the HIP segment-sum over the graphs (deterministic)
+            plan = ops.plan_from_sorted_index(node_to_graph_idx, num_graphs)
+            per_node = gather_rows_autograd(graph_reps.contiguous(), node_to_graph_idx, plan)
         return self._update_node_states(node_states, per_node)
 
 
@@ -100,7 +103,7 @@ class GruGlobalStateUpdate(AbstractGlobalGraphExchange):
                 and _no_grad_needed(node_states, global_info_per_node, *gru.parameters())):
             return ops.gru_cell(global_info_per_node, node_states, gru.weight_ih, gru.weight_hh,
                                 gru.bias_ih, gru.bias_hh)
-        return gru(global_info_per_node, node_states)
+        return dense.gru_cell(gru, global_info_per_node, node_states)
 
     @property
     def input_state_dimension(self) -> int:

@@ -138,6 +138,12 @@ class _GatherRows(torch.autograd.Function):
         return ops.segment_reduce(g.contiguous(), ctx.plan, "sum"), None, None
 
 
+def gather_rows(x: torch.Tensor, index: torch.Tensor, plan: "ops.GraphPlan") -> torch.Tensor:
+    """Differentiable x[index] on the HIP kernels; `plan` must be the segment plan of `index`
+    (rows = x.shape[0]), e.g. `ops.plan_from_sorted_index(node_to_graph_idx, num_graphs)`."""
+    return _GatherRows.apply(x, index, plan)
+
+
 def scatter_log_softmax(src, index, dim: int = -1, eps: float = 1e-12,
                         dim_size: Optional[int] = None) -> torch.Tensor:
     """torch_scatter.composite.scatter_log_softmax (varsizedsummary.py:57,106,158; varmisuse.py:79;

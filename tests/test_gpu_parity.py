@@ -1128,3 +1128,40 @@ def test_forward_is_hip_graph_capturable():
             got = y_static.clone()
             want = fwd()
             assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("pool", ["weighted_sum", "max"])
+def test_global_exchange_training_gradients_match_oracle_autograd(pool):
+    """GruGlobalStateUpdate (globalgraphexchange.py:29-64) in training mode: pooling, broadcast-gather and GRU
+    cell all on the HIP autograd nodes; gradients w.r.t. the node states and the GRU weights vs the oracle."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import reduceops as R, workloads
+    sizes = [700, 1, 1300, 64]
+    n2g = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    N, H = int(n2g.shape[0]), 64
+    torch.manual_seed(8)
+    mod = R.GruGlobalStateUpdate(R.WeightedSumVarSizedElementReduce(H) if pool == "weighted_sum"
+                                 else R.SimpleVarSizedElementReduce(pool), H, H).train()
+    sd = mod.state_dict()
+    spec = {"pool": pool, "w_ih": sd["_GruGlobalStateUpdate__gru_cell.weight_ih"],
+            "w_hh": sd["_GruGlobalStateUpdate__gru_cell.weight_hh"],
+            "b_ih": sd["_GruGlobalStateUpdate__gru_cell.bias_ih"],
+            "b_hh": sd["_GruGlobalStateUpdate__gru_cell.bias_hh"]}
+    if pool == "weighted_sum":
+        spec["pool_w"] = [v for k, v in sd.items() if k.endswith("weights_layer.weight")][0]
+    spec = {k: (v.clone().requires_grad_(True) if isinstance(v, torch.Tensor) else v) for k, v in spec.items()}
+    x = workloads.node_states(N, H, seed=3)
+    gout = workloads.node_states(N, H, seed=4)
+    xo = x.clone().requires_grad_(True)
+    yo = O.global_gru_exchange(xo, n2g, spec)
+    yo.backward(gout)
+    mod = mod.cuda()
+    xg = x.cuda().requires_grad_(True)
+    yg = mod(xg, [], n2g.cuda(), {}, {}, [])
+    yg.backward(gout.cuda())
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=0, atol=TOL)
+    sc = max(1.0, float(xo.grad.abs().max()))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=0, atol=2e-5 * sc)
+    got_w = mod.state_dict(keep_vars=True)["_GruGlobalStateUpdate__gru_cell.weight_ih"].grad
+    sc = max(1.0, float(spec["w_ih"].grad.abs().max()))
+    np.testing.assert_allclose(got_w.cpu().numpy(), spec["w_ih"].grad.numpy(), rtol=0, atol=2e-5 * sc)
