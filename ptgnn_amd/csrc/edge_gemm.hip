@@ -18,6 +18,8 @@
 //     128 edges, read straight from ptgnn's adjacency tensors once per tile,
 //   * the B operand = that type's own nn.Linear weight (no stacked copy needed).
 // Bound: MFMA fp32 for the math; the gather reads E*H*4 bytes of L2/MALL-resident node states.
+#include <stdlib.h>
+
 #include "dense_common.h"
 
 namespace ptgnn_amd {
@@ -223,7 +225,11 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int32_t state_dim,
   PTGNN_REQUIRE(ld_x % 4 == 0 && ld_msg % 4 == 0 && ld_msg >= msg_dim && aligned16(x) && aligned16(msg),
                 PTGNN_AMD_EUNSUPPORTED, "edge_linear: x/msg rows must be 16-byte aligned");
   const int use_dst = dst_per_type != nullptr;
-  const int nj = msg_dim <= 64 ? 1 : 2;
+  int nj = msg_dim <= 64 ? 1 : 2;
+  if (const char *e = getenv("PTGNN_AMD_EDGE_NJ")) {   // developer A/B knob
+    const int v = atoi(e);
+    if (v == 1 || v == 2) nj = v;
+  }
   const int col_tiles = (msg_dim + 64 * nj - 1) / (64 * nj);
   // the mask is indexed by the column of the FORWARD input: the A operand in mode 1, the output in mode 2
   const DropoutParams drop = make_dropout(dropout_p, dropout_seed, dropout_mode == 2 ? msg_dim : state_dim);
