@@ -172,3 +172,37 @@ def test_minibatch_builder_refuses_cpu():
     b.extend([(np.zeros(2, np.int32), np.ones(2, np.int32))], 3, {})
     with pytest.raises(_lib.PtgnnAmdError):
         b.finalize("cpu")
+
+
+def test_forward_scope_shares_derived_tensors_only_inside_a_scope():
+    """Stacked tied weights are built once per forward scope (so autograd accumulates one stacked gradient
+    per use) and never cached outside one or with grad disabled."""
+    import torch
+    from ptgnn_amd import layers as L
+    calls = []
+
+    def make():
+        calls.append(1)
+        return torch.zeros(2, requires_grad=True)
+    a, b = L._scoped("k", make), L._scoped("k", make)
+    assert a is not b and len(calls) == 2                      # no scope: nothing is kept
+    with L.forward_scope():
+        c, d = L._scoped("k", make), L._scoped("k", make)
+        assert c is d and len(calls) == 3
+        with L.forward_scope():                                # nested scopes share the outer cache
+            assert L._scoped("k", make) is c
+        with torch.no_grad():
+            assert L._scoped("k", make) is not c               # inference never caches autograd tensors
+    assert L._FORWARD_SCOPE is None
+    with L.forward_scope():
+        assert L._scoped("k", make) is not c                   # a new forward builds its own
+
+
+def test_training_path_selection_rules():
+    import torch
+    from ptgnn_amd import dense, layers as L
+    assert L._edge_training_ok(128, 128) and not L._edge_training_ok(128, 48) and not L._edge_training_ok(100, 64)
+    assert L._prefer_edge_path(625_130, 115_772, 17, 128, 128)          # Graph2Class batch: edge form
+    assert not L._prefer_edge_path(1_100_000, 200_000, 1, 128, 128)     # config 2: per-node table
+    x, w = torch.zeros(4, 8), torch.zeros(12, 8)
+    assert not dense._kernel_dims_ok(x, w)                              # CPU tensors never take the HIP nodes
