@@ -178,21 +178,35 @@ def make_cfg3(dev, rank=0):
                     "(incl. reverse+self), Typilus GGNN arch: 8 GGNN layers H=128 (+concat residual), max"}
 
 
-def train_cfg3(dev, dropout, steps=6, warmup=2):
-    """Training step (forward + backward + Adam) of the same Graph2Class-style stack with a linear
-    classification head on the `supernodes` references -- the quantity README.md:15-17 quotes
-    (1.13 M edges/s on a V100).  dropout = 0.1 is the shipped Typilus setting (per-edge dropout =>
-    general per-edge path); dropout = 0 uses the table path with the HIP aggregation both ways."""
-    from ptgnn_amd import layers as L, ops, workloads
+def typilus_stack(arch, H, T, dropout):
+    """The two architectures of ptgnn/implementations/typilus/train.py: "ggnn" = create_ggnn_mp_layers
+    (:37-64, the shape BASELINE configs[2] names, at the hidden size given) and "mlp" = create_mlp_mp_layers
+    (:66-99), the DEFAULT the README's V100 numbers were measured on (hidden 64)."""
+    from ptgnn_amd import layers as L
+    if arch == "ggnn":
+        ggnn = L.GatedMessagePassingLayer(H, H, T, "max", dropout_rate=dropout)
+        r1 = L.ConcatResidualLayer(H)
+        last = L.GatedMessagePassingLayer(2 * H, H, T, "max", dropout_rate=dropout)
+        return [r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last]
+    mk = lambda: L.MlpMessagePassingLayer(H, H, H, T, "max", dropout_rate=dropout)          # noqa: E731
+    mk2 = lambda: L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, "max", dropout_rate=dropout)  # noqa: E731
+    r1, r2 = L.ConcatResidualLayer(H), L.ConcatResidualLayer(H)
+    return [r1.pass_through_dummy_layer(), mk(), mk(), mk(), r1, mk2(),
+            r2.pass_through_dummy_layer(), mk(), mk(), mk(), r2, mk2()]
+
+
+def train_cfg3(dev, dropout, steps=8, warmup=4, arch="ggnn", H=128, forward_too=False):
+    """Training step (forward + backward + Adam) of a Typilus stack on the Graph2Class-style batch with a
+    linear classification head on the `supernodes` references -- the quantity README.md:15-17 quotes
+    (1.13 M edges/s on a V100, for the default MLP-MP architecture at hidden 64).  `dropout` is the layers'
+    dropout rate (GGNN: per-edge input dropout; MLP-MP: on the node update)."""
+    from ptgnn_amd import ops, workloads
     from ptgnn_amd.gnn import GraphNeuralNetwork
-    H, T = 128, 17
+    T = 17
     mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234)
     torch.manual_seed(1234)
-    ggnn = L.GatedMessagePassingLayer(H, H, T, "max", dropout_rate=dropout)
-    r1 = L.ConcatResidualLayer(H)
-    last = L.GatedMessagePassingLayer(2 * H, H, T, "max", dropout_rate=dropout)
-    net = GraphNeuralNetwork([r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last], torch.nn.Identity(),
-                             True, True).to(dev).train()
+    mods = typilus_stack(arch, H, T, dropout)
+    net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).to(dev).train()
     N = mb["num_nodes"]
     E = 2 * sum(int(a[0].shape[0]) for a in mb["adjacency_lists"]) + N
     x = workloads.node_states(N, H, seed=5).to(dev)
@@ -200,30 +214,43 @@ def train_cfg3(dev, dropout, steps=6, warmup=2):
     n2g = mb["node_to_graph_idx"].to(dev)
     refs = {k: v.to(dev) for k, v in mb["reference_node_ids"].items()}
     refg = {k: v.to(dev) for k, v in mb["reference_node_graph_idx"].items()}
-    head = torch.nn.Linear(2 * H, 100).to(dev)
+    head = torch.nn.Linear(net.output_node_state_dim, 100).to(dev)
     opt = torch.optim.Adam(list(net.parameters()) + list(head.parameters()), lr=1e-4)
     target = torch.randint(0, 100, (refs["supernodes"].shape[0],), device=dev)
 
-    def step():
+    def forward():
         ops.clear_plan_cache()
+        return net(node_data={"input": x}, adjacency_lists=adj, edge_feature_data=[], node_to_graph_idx=n2g,
+                   reference_node_ids=refs, reference_node_graph_idx=refg, num_graphs=mb["num_graphs"])
+
+    def step():
         opt.zero_grad(set_to_none=True)
-        out = net(node_data={"input": x}, adjacency_lists=adj, edge_feature_data=[], node_to_graph_idx=n2g,
-                  reference_node_ids=refs, reference_node_graph_idx=refg, num_graphs=mb["num_graphs"])
+        out = forward()
         logits = head(out.output_node_representations[out.node_idx_references["supernodes"]])
         torch.nn.functional.cross_entropy(logits, target).backward()
         opt.step()
 
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {"dropout": dropout, "ms_per_train_step": round(dt * 1e3, 3),
-            "edges_per_sec_readme_convention": round(E / dt, 1), "graphs_per_sec": round(mb["num_graphs"] / dt, 1),
-            "vs_readme_v100_training_1129k": round(E / dt / 1.129e6, 2)}
+    def clock(fn, n, w):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    dt = clock(step, steps, warmup)
+    res = {"arch": arch, "hidden": H, "dropout": dropout, "ms_per_train_step": round(dt * 1e3, 3),
+           "edges_per_sec_readme_convention": round(E / dt, 1), "graphs_per_sec": round(mb["num_graphs"] / dt, 1),
+           "vs_readme_v100_training_1129k": round(E / dt / 1.129e6, 2)}
+    if forward_too:
+        net.eval()
+        with torch.no_grad():
+            df = clock(forward, 3 * steps, warmup)
+        res.update(ms_per_forward=round(df * 1e3, 3), inference_edges_per_sec_readme_convention=round(E / df, 1),
+                   vs_readme_v100_inference_2527k=round(E / df / 2.527e6, 2))
+    return res
 
 
 def step_cfg3(st):
@@ -441,6 +468,9 @@ def main():
                 del st3
             torch.cuda.empty_cache()
             result["graph2class_train"] = [train_cfg3(dev, 0.0), train_cfg3(dev, 0.1)]
+            torch.cuda.empty_cache()
+            # like for like with README.md:15-18: the README's own (default) architecture and settings
+            result["readme_default_arch"] = train_cfg3(dev, 0.1, arch="mlp", H=64, forward_too=True)
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_cfg2(st) if args.workload == "cfg2" else cpu_baseline_cfg3(st)
