@@ -107,6 +107,36 @@ def single_layers():
         save(name, x=x, y=y, **pack_adj(adj), **pack_specs([weights_from_reference_layer(layer)]))
 
 
+def training_gradients():
+    """Backward pins: the reference's OWN layers in train mode (dropout 0 => deterministic) under torch
+    autograd on CPU: output, d loss / d x and every parameter gradient for a fixed upstream gradient.
+    Widths are multiples of 32 so the HIP edge form (grouped GEMM + weight-gradient kernel) can replay them."""
+    gen = torch.Generator().manual_seed(777)
+    n, H, M, T = 300, 32, 64, 4
+    for name, make in (
+            ("train_ggnn_max", lambda: GatedMessagePassingLayer(H, M, T, "max")),
+            ("train_ggnn_sum", lambda: GatedMessagePassingLayer(H, M, T, "sum")),
+            ("train_mlp_sum_target", lambda: MlpMessagePassingLayer(H, H, M, T, "sum")),
+            ("train_mlp_max_notarget", lambda: MlpMessagePassingLayer(H, H, M, T, "max",
+                                                                      use_target_state_as_message_input=False))):
+        torch.manual_seed(len(name))
+        adj = rand_adj(gen, n, [500, 0, 37, 260])
+        x = torch.randn(n, H, generator=gen).requires_grad_(True)
+        layer = make().train()
+        with torch.no_grad():
+            for p_name, p_ in layer.named_parameters():
+                if "state_update" in p_name and p_.dim() == 1:
+                    p_.add_(0.1 * torch.randn(p_.shape, generator=gen))
+        y = layer(x, adj, None, {}, {}, empty_feats(adj))
+        gout = torch.randn(y.shape, generator=gen)
+        y.backward(gout)
+        grads = {"g.x": x.grad}
+        for p_name, p_ in layer.named_parameters():
+            grads["g." + p_name] = p_.grad
+        save(name, x=x.detach(), y=y.detach(), gout=gout, **pack_adj(adj),
+             **pack_specs([weights_from_reference_layer(layer)]), **grads)
+
+
 class _Identity(torch.nn.Module):
     def forward(self, x):
         return x
@@ -287,6 +317,7 @@ def batcher():
 if __name__ == "__main__":
     torch.set_num_threads(1)
     single_layers()
+    training_gradients()
     containers()
     varmisuse_ggnn()
     batcher()
