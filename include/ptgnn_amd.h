@@ -56,6 +56,18 @@ enum { PTGNN_AMD_ACT_NONE = 0, PTGNN_AMD_ACT_TANH = 1, PTGNN_AMD_ACT_RELU = 2 };
 int ptgnn_amd_version(void);
 const char *ptgnn_amd_last_error(void);
 
+/* Arithmetic / kernel family of the dense blocks (ptgnn_amd_linear_f32, ptgnn_amd_gru_cell*_f32,
+ * ptgnn_amd_edge_linear_f32) -- i.e. of what replaces nn.Linear / nn.GRUCell at
+ * gatedmessagepassing.py:57-69 and mlpmessagepassing.py:96-117.  Process-wide; initial value from the
+ * environment variable PTGNN_AMD_GEMM (default 1).
+ *   0  128 x 128 tile kernels, exact fp32 MFMA
+ *   1  streaming weight-stationary kernels, exact fp32 MFMA (v_mfma_f32_32x32x2_f32: an fmaf chain)
+ *   2  streaming kernels, "f32 via 3xbf16 split": operands split exactly into 3 bf16 pieces, the 6 largest
+ *      piece products on the bf16 MFMA with fp32 accumulation (error vs float64 = that of mode 1; results
+ *      are not bit-identical to mode 0/1).  Shapes a mode does not tile run on mode 0. */
+int ptgnn_amd_set_gemm_mode(int mode);
+int ptgnn_amd_get_gemm_mode(void);
+
 /* ------------------------------------------------------------------------------------------
  * Graph plan: merge the per-edge-type adjacency lists of one minibatch into ONE
  * destination-sorted CSR that all L message-passing layers of a forward reuse.
@@ -91,6 +103,12 @@ int ptgnn_amd_csr_build(const int64_t *const *src_per_type, /* host [num_types] 
                         int32_t hub_threshold /* 0 = no hub list */,
                         int32_t *hub_entries /* nullable: int32 [2 * ceil(E/1024)][2] (chunk,row) */,
                         int32_t *hub_count /* nullable device scalar: number of pairs */,
+                        int32_t *bad_index_count /* nullable device scalar, ACCUMULATED (never reset here):   *
+                                                  * ids outside [0, num_nodes) / [0, num_src_rows) -- the     *
+                                                  * reference device-asserts on those in F.embedding          *
+                                                  * (gatedmessagepassing.py:54-56); here they are clamped to *
+                                                  * row 0 so nothing is read or written out of bounds, and   *
+                                                  * counted so the host can raise                            */,
                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* The hub (chunk, row) list of an existing rowptr (plans that are not built by ptgnn_amd_csr_build,
@@ -204,7 +222,9 @@ int ptgnn_amd_batch_offsets_i64(const int32_t *in, int64_t n_in, const int64_t *
  *               [msg_dim, state_dim * (dst ? 2 : 1)], row-major contiguous.
  * Requires state_dim % 32 == 0, msg_dim % 4 == 0, 16-byte aligned rows (else EUNSUPPORTED).
  * ---------------------------------------------------------------------------------------- */
-int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int32_t state_dim,
+int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x,
+        int64_t num_rows /* rows of x: gathered node ids are clamped into [0, num_rows) */,
+        int32_t state_dim,
                               const int64_t *const *src_per_type,
                               const int64_t *const *dst_per_type /* nullable */,
                               const int64_t *edges_per_type, const float *const *w_per_type,
@@ -226,7 +246,9 @@ int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int32_t state_dim,
  *   dropout_mode 0 or dropout_p == 0: plain ptgnn_amd_edge_linear_f32.
  * The mask is Bernoulli(1 - p') per element with p' = round(p * 65536) / 65536.
  * ---------------------------------------------------------------------------------------- */
-int ptgnn_amd_edge_linear_dropout_f32(const float *x, int64_t ld_x, int32_t state_dim,
+int ptgnn_amd_edge_linear_dropout_f32(const float *x, int64_t ld_x,
+        int64_t num_rows /* rows of x: gathered node ids are clamped into [0, num_rows) */,
+        int32_t state_dim,
                                       const int64_t *const *src_per_type,
                                       const int64_t *edges_per_type, const float *const *w_per_type,
                                       int32_t num_types, int32_t msg_dim, float *msg, int64_t ld_msg,
@@ -245,7 +267,9 @@ int ptgnn_amd_edge_linear_dropout_f32(const float *x, int64_t ld_x, int32_t stat
  * ---------------------------------------------------------------------------------------- */
 size_t ptgnn_amd_edge_wgrad_workspace_bytes(int64_t num_edges, int32_t num_types, int32_t msg_dim,
                                             int32_t in_dim);
-int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int32_t state_dim,
+int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x,
+        int64_t num_rows /* rows of x: gathered node ids are clamped into [0, num_rows) */,
+        int32_t state_dim,
                                    const int64_t *const *src_per_type,
                                    const int64_t *const *dst_per_type /* nullable */,
                                    const int64_t *edges_per_type, const float *grad_msg,

@@ -18,10 +18,12 @@ _i64, _i32, _vp, _f32 = _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_float
 SIGNATURES = {
     "ptgnn_amd_version": (_c.c_int, []),
     "ptgnn_amd_last_error": (_c.c_char_p, []),
+    "ptgnn_amd_set_gemm_mode": (_c.c_int, [_c.c_int]),
+    "ptgnn_amd_get_gemm_mode": (_c.c_int, []),
     "ptgnn_amd_csr_workspace_bytes": (_c.c_size_t, [_i64, _i64]),
     "ptgnn_amd_type_bits": (_c.c_int, [_i32]),
     "ptgnn_amd_csr_build": (_c.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _c.c_int, _vp, _vp, _vp, _vp,
-                                       _i32, _vp, _vp, _vp, _c.c_size_t, _vp]),
+                                       _i32, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     "ptgnn_amd_hub_workspace_bytes": (_c.c_size_t, [_i64, _i32, _c.c_int]),
     "ptgnn_amd_hub_ticket_count": (_i64, [_i64, _i32]),
     "ptgnn_amd_hub_list": (_c.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
@@ -34,12 +36,12 @@ SIGNATURES = {
     "ptgnn_amd_linear_f32": (_c.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _c.c_int, _vp, _i64,
                                         _vp]),
     "ptgnn_amd_batch_offsets_i64": (_c.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _vp, _vp]),
-    "ptgnn_amd_edge_linear_f32": (_c.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _c.c_int, _vp,
+    "ptgnn_amd_edge_linear_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _c.c_int, _vp,
                                              _i64, _vp]),
-    "ptgnn_amd_edge_linear_dropout_f32": (_c.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i64,
+    "ptgnn_amd_edge_linear_dropout_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i64,
                                                      _c.c_int, _c.c_float, _c.c_uint64, _vp]),
     "ptgnn_amd_edge_wgrad_workspace_bytes": (_c.c_size_t, [_i64, _i32, _i32, _i32]),
-    "ptgnn_amd_edge_weight_grad_f32": (_c.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
+    "ptgnn_amd_edge_weight_grad_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                                   _c.c_float, _c.c_uint64, _vp, _vp, _c.c_size_t, _vp]),
     "ptgnn_amd_linear_weight_grad_f32": (_c.c_int, [_vp, _i64, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _vp,
                                                     _c.c_size_t, _vp]),

@@ -44,9 +44,26 @@ struct EdgeRec {
   int32_t packed;
 };
 
+// Range guard (the reference device-asserts in F.embedding on a bad node id; here a bad id must never
+// become an out-of-bounds rowptr write or gather): ids outside [0, limit) are clamped to 0 and counted in
+// `bad` (nullable, accumulated -- the host reads it back asynchronously and raises).
+struct RangeGuard {
+  int64_t num_rows;   // plan rows (key domain)
+  int64_t src_rows;   // rows of the table the payload indexes (mode 0 only; 0 = unchecked)
+  int32_t *bad;
+};
+
+__device__ __forceinline__ void guard_record(const RangeGuard &g, int64_t &key, int64_t &payload_id, bool count) {
+  const bool kbad = key < 0 || key >= g.num_rows;
+  const bool pbad = g.src_rows > 0 && (payload_id < 0 || payload_id >= g.src_rows);
+  if (kbad) key = 0;
+  if (pbad) payload_id = 0;
+  if ((kbad || pbad) && count && g.bad) atomicAdd(g.bad, 1);
+}
+
 // edge e of the type-major concatenation -> (plan row, col payload)
 __device__ __forceinline__ EdgeRec edge_record(const TypeTable &tab, int64_t e, int32_t type_bits, int mode,
-                                               int total_types) {
+                                               int total_types, const RangeGuard &guard, bool count) {
   int lo = 0, hi = tab.num_types;   // binary search for the type (<= 6 steps; table lives in SGPRs)
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -57,10 +74,15 @@ __device__ __forceinline__ EdgeRec edge_record(const TypeTable &tab, int64_t e, 
   const int64_t ty = tab.type_base + lo;
   EdgeRec r;
   if (mode == 2) {
-    r.key = (uint32_t)(s * total_types + ty);
+    int64_t key = s * total_types + ty;
+    if (s < 0) key = -1;
+    int64_t none = 0;
+    guard_record(guard, key, none, count);
+    r.key = (uint32_t)key;
     r.packed = (int32_t)d;
   } else {
     if (mode == 1) { const int64_t t = s; s = d; d = t; }
+    guard_record(guard, d, s, count);
     r.key = (uint32_t)d;
     r.packed = (int32_t)((s << type_bits) | ty);
   }
@@ -70,29 +92,15 @@ __device__ __forceinline__ EdgeRec edge_record(const TypeTable &tab, int64_t e, 
 __global__ __launch_bounds__(256) void k_pack(TypeTable tab, int32_t type_bits, int mode, int total_types,
                                               uint32_t *__restrict__ keys,
                                               int32_t *__restrict__ pos,
-                                              int32_t *__restrict__ packed, int64_t pos_base) {
+                                              int32_t *__restrict__ packed, int64_t pos_base, RangeGuard guard) {
   const int64_t total = tab.offset[tab.num_types];
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
-    // binary search for the type (<= 6 steps; table lives in SGPR/scalar cache)
-    int lo = 0, hi = tab.num_types;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (tab.offset[mid] <= e) lo = mid; else hi = mid;
-    }
-    const int64_t i = e - tab.offset[lo];
-    int64_t s = tab.src[lo][i], d = tab.dst[lo][i];
-    const int64_t ty = tab.type_base + lo;
+    const EdgeRec r = edge_record(tab, e, type_bits, mode, total_types, guard, true);
     const int64_t g = pos_base + e;
     pos[g] = (int32_t)g;
-    if (mode == 2) {
-      keys[g] = (uint32_t)(s * total_types + ty);
-      packed[g] = (int32_t)d;
-    } else {
-      if (mode == 1) { const int64_t t = s; s = d; d = t; }
-      keys[g] = (uint32_t)d;
-      packed[g] = (int32_t)((s << type_bits) | ty);
-    }
+    keys[g] = r.key;
+    packed[g] = r.packed;
   }
 }
 
@@ -211,13 +219,13 @@ __device__ __forceinline__ int block_scan_512(int v, int *tmp) {
 __global__ __launch_bounds__(kMsdBlock) void k_msd_hist(TypeTable tab, int32_t type_bits, int mode,
                                                         int total_types, int64_t n, int low_bits,
                                                         int bins, int32_t *__restrict__ hist,
-                                                        int64_t nblocks, int32_t *hub_count) {
+                                                        int64_t nblocks, int32_t *hub_count, RangeGuard guard) {
   __shared__ int lh[kMaxBins];
   for (int j = threadIdx.x; j < bins; j += kMsdBlock) lh[j] = 0;
   if (hub_count && blockIdx.x == 0 && threadIdx.x == 0) *hub_count = 0;
   __syncthreads();
   const int64_t e = blockIdx.x * (int64_t)kMsdBlock + threadIdx.x;
-  if (e < n) atomicAdd(&lh[edge_record(tab, e, type_bits, mode, total_types).key >> low_bits], 1);
+  if (e < n) atomicAdd(&lh[edge_record(tab, e, type_bits, mode, total_types, guard, true).key >> low_bits], 1);
   __syncthreads();
   for (int j = threadIdx.x; j < bins; j += kMsdBlock) hist[(int64_t)j * nblocks + blockIdx.x] = lh[j];
 }
@@ -288,7 +296,8 @@ __global__ __launch_bounds__(kMsdBlock) void k_msd_scatter(TypeTable tab, int32_
                                                            int high_bits, int bins,
                                                            const int32_t *__restrict__ hist_prefix,
                                                            const int32_t *__restrict__ totals,
-                                                           int64_t nblocks, int4 *__restrict__ recs) {
+                                                           int64_t nblocks, int4 *__restrict__ recs,
+                                                           RangeGuard guard) {
   __shared__ int wave_cnt[(kMsdBlock / 64) * kMaxBins];
   __shared__ int base[kMaxBins];
   __shared__ int tmp[8];
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(kMsdBlock) void k_msd_scatter(TypeTable tab, int32_
   const int64_t e = blockIdx.x * (int64_t)kMsdBlock + threadIdx.x;
   const bool valid = e < n;
   EdgeRec r{0u, 0};
-  if (valid) r = edge_record(tab, e, type_bits, mode, total_types);
+  if (valid) r = edge_record(tab, e, type_bits, mode, total_types, guard, false);
   const int digit = (int)(r.key >> low_bits);
   int run;
   const int local = block_stable_rank(valid, digit, high_bits, bins, wave_cnt, &run);   // syncs inside
@@ -513,6 +522,7 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
                                    int32_t *rowptr,
                                    int32_t *col, int32_t *perm, int32_t *max_degree,
                                    int32_t hub_threshold, int32_t *hub_entries, int32_t *hub_count,
+                                   int32_t *bad_index_count,
                                    void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PTGNN_REQUIRE(num_types >= 0 && num_nodes >= 0, PTGNN_AMD_EINVAL, "csr_build: negative size");
@@ -536,6 +546,7 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
                 "csr_build: num_edges=%lld / source rows=%lld x 2^%d exceed the int32 plan format",
                 (long long)num_edges, (long long)src_rows, type_bits);
   PTGNN_REQUIRE(num_edges == 0 || col != nullptr, PTGNN_AMD_EINVAL, "csr_build: col is null");
+  const RangeGuard guard{num_nodes, swap_src_dst == 0 ? src_rows : 0, bad_index_count};
   WsLayout L;
   PTGNN_REQUIRE(layout(num_edges, num_nodes, &L), PTGNN_AMD_EHIP, "csr_build: sort size query failed");
   PTGNN_REQUIRE(workspace_bytes >= L.total && (workspace || L.total == 0), PTGNN_AMD_EWORKSPACE,
@@ -570,13 +581,13 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
     const bool hubs = hub_entries && hub_count && hub_threshold > 0;
     k_msd_hist<<<(unsigned)nblocks, kMsdBlock, 0, stream>>>(tab, type_bits, swap_src_dst, num_types, num_edges,
                                                             low_bits, bins, hist, nblocks,
-                                                            hubs ? hub_count : nullptr);
+                                                            hubs ? hub_count : nullptr, guard);
     PTGNN_LAUNCH_CHECK();
     k_msd_scan<<<(unsigned)bins, 256, 0, stream>>>(hist, nblocks, totals);
     PTGNN_LAUNCH_CHECK();
     k_msd_scatter<<<(unsigned)nblocks, kMsdBlock, 0, stream>>>(tab, type_bits, swap_src_dst, num_types,
                                                                num_edges, low_bits, high_bits, bins, hist,
-                                                               totals, nblocks, recs);
+                                                               totals, nblocks, recs, guard);
     PTGNN_LAUNCH_CHECK();
     k_msd_buckets<<<(unsigned)bins, kMsdBlock, 0, stream>>>(recs, totals, bins, low_bits, num_nodes, num_edges,
                                                             rowptr, col, perm, hubs ? hub_threshold : 0, 1024,
@@ -606,7 +617,7 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
       if (chunk > 0) {
         const int64_t blocks = (chunk + 255) / 256;
         k_pack<<<(unsigned)(blocks < 4096 ? blocks : 4096), 256, 0, stream>>>(
-            tab, type_bits, swap_src_dst, num_types, keys_in, pos_in, packed, base);
+            tab, type_bits, swap_src_dst, num_types, keys_in, pos_in, packed, base, guard);
         PTGNN_LAUNCH_CHECK();
       }
       base += chunk;

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "dense_common.h"
+#include "stream_gemm.h"
 
 namespace ptgnn_amd {
 namespace {
@@ -649,6 +650,10 @@ extern "C" int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int
   PTGNN_REQUIRE(act >= 0 && act <= PTGNN_AMD_ACT_RELU, PTGNN_AMD_EINVAL, "linear: bad act");
   if (rows == 0) return PTGNN_AMD_OK;
   PTGNN_REQUIRE(x && w && y && ld_x >= k && ld_y >= n_out, PTGNN_AMD_EINVAL, "linear: null/ld");
+  if (stream_linear(x, rows, k, ld_x, w, n_out, bias, act, y, ld_y, (hipStream_t)stream_)) {
+    PTGNN_LAUNCH_CHECK();
+    return PTGNN_AMD_OK;
+  }
   int nj = linear_nj();
   if (nj == 0) nj = n_out <= 128 ? 1 : 2;  // narrow outputs: finer tiles, more workgroups per CU
   const int bn = 64 * nj;
@@ -703,6 +708,10 @@ static int gru_launch(const float *a, int64_t ld_a, const float *h, int64_t ld_h
   PTGNN_REQUIRE(a && h && w_ih && w_hh && b_ih && b_hh && out, PTGNN_AMD_EINVAL, "gru_cell: null");
   PTGNN_REQUIRE(ld_a >= m && ld_h >= hd && ld_out >= hd, PTGNN_AMD_EINVAL, "gru_cell: bad ld");
   PTGNN_REQUIRE(out != h, PTGNN_AMD_EINVAL, "gru_cell: in-place update is not supported");
+  if (stream_gru(a, ld_a, h, ld_h, w_ih, w_hh, b_ih, b_hh, n, m, hd, out, ld_out, gates, (hipStream_t)stream_)) {
+    PTGNN_LAUNCH_CHECK();
+    return PTGNN_AMD_OK;
+  }
   const int64_t row_tiles = (n + 127) / 128;
   const int col_tiles = (hd + 31) / 32;
   const int64_t num_tiles = row_tiles * col_tiles;

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "dense_common.h"
+#include "stream_gemm.h"
 
 namespace ptgnn_amd {
 namespace {
@@ -49,7 +50,7 @@ struct GatherRows {  // tile row r -> node id of edge (e0 + r); rows past the ty
 // of the forward input), see DropoutParams.
 template <int ACT, int NJ, int DROP>
 __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
-    EdgeTypeTable tab, const float *__restrict__ x, int64_t ld_x, int H, int use_dst, int n_out,
+    EdgeTypeTable tab, const float *__restrict__ x, int64_t ld_x, int64_t num_rows, int H, int use_dst, int n_out,
     float *__restrict__ msg, int64_t ld_msg, int64_t msg_row_base, int col_tiles, DropoutParams drop) {
   constexpr int BN = 64 * NJ;
   constexpr int B_FLOATS = BN * LDS_LD;
@@ -88,8 +89,12 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
   for (int r = 0; r < 4; ++r) {
     int64_t e = e0 + (threadIdx.x >> 3) + r * 32;
     e = e < n_edges ? e : n_edges - 1;
-    gs.idx[r] = tab.src[t][e];
-    gd.idx[r] = use_dst ? tab.dst[t][e] : 0;
+    // ids were range-checked by the plan build (ptgnn_amd_csr_build); clamp anyway so a bad id can never fault
+    int64_t si = tab.src[t][e], di = use_dst ? tab.dst[t][e] : 0;
+    si = si < 0 ? 0 : (si < num_rows ? si : num_rows - 1);
+    di = di < 0 ? 0 : (di < num_rows ? di : num_rows - 1);
+    gs.idx[r] = si;
+    gd.idx[r] = di;
   }
 
   f32x16 acc[2][NJ];
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
 
 using namespace ptgnn_amd;
 
-static int edge_linear_launch(const float *x, int64_t ld_x, int32_t state_dim,
+static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
                               const int64_t *const *src_per_type, const int64_t *const *dst_per_type,
                               const int64_t *edges_per_type, const float *const *w_per_type,
                               int32_t num_types, int32_t msg_dim, int act, float *msg, int64_t ld_msg,
@@ -220,6 +225,7 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int32_t state_dim,
   PTGNN_REQUIRE(dropout_mode == 0 || (act == PTGNN_AMD_ACT_NONE && dst_per_type == nullptr),
                 PTGNN_AMD_EUNSUPPORTED, "edge_linear: dropout needs act none and no target-state half");
   if (num_types == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(num_rows > 0, PTGNN_AMD_EINVAL, "edge_linear: num_rows must be positive");
   PTGNN_REQUIRE(x && src_per_type && edges_per_type && w_per_type && msg, PTGNN_AMD_EINVAL,
                 "edge_linear: null pointer");
   PTGNN_REQUIRE(ld_x % 4 == 0 && ld_msg % 4 == 0 && ld_msg >= msg_dim && aligned16(x) && aligned16(msg),
@@ -235,6 +241,36 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int32_t state_dim,
   const DropoutParams drop = make_dropout(dropout_p, dropout_seed, dropout_mode == 2 ? msg_dim : state_dim);
   hipStream_t st = (hipStream_t)stream_;
   int64_t row_base = 0;
+  // streaming core (stream_gemm.hip): inference / no-dropout shapes it tiles
+  const bool streaming = dropout_mode == 0 && stream_edge_supported(state_dim, msg_dim, use_dst) &&
+                         ld_x % 4 == 0 && aligned16(x);
+  for (int t0 = 0; streaming && t0 < num_types; t0 += kStreamMaxTypes) {
+    StreamEdgeTable tab;
+    tab.num_types = (num_types - t0 < kStreamMaxTypes) ? (num_types - t0) : kStreamMaxTypes;
+    tab.edge_off[0] = 0;
+    tab.unit_off[0] = 0;
+    for (int t = 0; t < tab.num_types; ++t) {
+      const int64_t n = edges_per_type[t0 + t];
+      PTGNN_REQUIRE(n >= 0, PTGNN_AMD_EINVAL, "edge_linear: negative edge count");
+      PTGNN_REQUIRE(n == 0 || (src_per_type[t0 + t] && w_per_type[t0 + t] &&
+                               (!use_dst || dst_per_type[t0 + t])),
+                    PTGNN_AMD_EINVAL, "edge_linear: null table entry for type %d", t0 + t);
+      PTGNN_REQUIRE(n == 0 || aligned16(w_per_type[t0 + t]), PTGNN_AMD_EUNSUPPORTED,
+                    "edge_linear: weight of type %d is not 16-byte aligned", t0 + t);
+      tab.src[t] = src_per_type[t0 + t];
+      tab.dst[t] = use_dst ? dst_per_type[t0 + t] : src_per_type[t0 + t];
+      tab.w[t] = w_per_type[t0 + t];
+      tab.edge_off[t + 1] = tab.edge_off[t] + n;
+      const int64_t units = tab.unit_off[t] + (n + 31) / 32;
+      PTGNN_REQUIRE(units < ((int64_t)1 << 30), PTGNN_AMD_EUNSUPPORTED, "edge_linear: too many units");
+      tab.unit_off[t + 1] = (int32_t)units;
+    }
+    PTGNN_REQUIRE(stream_edge(tab, x, ld_x, num_rows, state_dim, use_dst, msg_dim, act, msg, ld_msg, row_base, st) == 1,
+                  PTGNN_AMD_EHIP, "edge_linear: streaming launch failed");
+    PTGNN_LAUNCH_CHECK();
+    row_base += tab.edge_off[tab.num_types];
+  }
+  if (streaming) return PTGNN_AMD_OK;
   for (int t0 = 0; t0 < num_types; t0 += kMaxTypes) {
     EdgeTypeTable tab;
     tab.num_types = (num_types - t0 < kMaxTypes) ? (num_types - t0) : kMaxTypes;
@@ -260,7 +296,7 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int32_t state_dim,
     if (total_tiles > 0) {
       const unsigned grid = (unsigned)xcd_padded_blocks(total_tiles);
 #define PTGNN_EDGE_LAUNCH(ACT, NJ, DROP)                                                            \
-  k_edge_linear<ACT, NJ, DROP><<<grid, 256, 0, st>>>(tab, x, ld_x, state_dim, use_dst, msg_dim, msg, \
+  k_edge_linear<ACT, NJ, DROP><<<grid, 256, 0, st>>>(tab, x, ld_x, num_rows, state_dim, use_dst, msg_dim, msg, \
                                                      ld_msg, row_base, col_tiles, drop)
       if (dropout_mode == 1) {
         if (nj == 1) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 1, 1); else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 2, 1);
@@ -283,25 +319,26 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int32_t state_dim,
   return PTGNN_AMD_OK;
 }
 
-extern "C" int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int32_t state_dim,
+extern "C" int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
                                          const int64_t *const *src_per_type,
                                          const int64_t *const *dst_per_type,
                                          const int64_t *edges_per_type,
                                          const float *const *w_per_type, int32_t num_types,
                                          int32_t msg_dim, int act, float *msg, int64_t ld_msg,
                                          void *stream_) {
-  return edge_linear_launch(x, ld_x, state_dim, src_per_type, dst_per_type, edges_per_type, w_per_type,
+  return edge_linear_launch(x, ld_x, num_rows, state_dim, src_per_type, dst_per_type, edges_per_type, w_per_type,
                             num_types, msg_dim, act, msg, ld_msg, 0, 0.f, 0, stream_);
 }
 
-extern "C" int ptgnn_amd_edge_linear_dropout_f32(const float *x, int64_t ld_x, int32_t state_dim,
+extern "C" int ptgnn_amd_edge_linear_dropout_f32(const float *x, int64_t ld_x, int64_t num_rows,
+                                                 int32_t state_dim,
                                                  const int64_t *const *src_per_type,
                                                  const int64_t *edges_per_type,
                                                  const float *const *w_per_type, int32_t num_types,
                                                  int32_t msg_dim, float *msg, int64_t ld_msg,
                                                  int dropout_mode, float dropout_p,
                                                  uint64_t dropout_seed, void *stream_) {
-  return edge_linear_launch(x, ld_x, state_dim, src_per_type, nullptr, edges_per_type, w_per_type,
+  return edge_linear_launch(x, ld_x, num_rows, state_dim, src_per_type, nullptr, edges_per_type, w_per_type,
                             num_types, msg_dim, PTGNN_AMD_ACT_NONE, msg, ld_msg, dropout_mode, dropout_p,
                             dropout_seed, stream_);
 }

@@ -38,7 +38,7 @@ struct WgradTable {
 // A tiles already in LDS, for the k-tile-0 workgroups.
 template <bool DROP, bool COLSUM>
 __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
-    WgradTable tab, const float *__restrict__ x, int64_t ld_x, int H, int use_dst,
+    WgradTable tab, const float *__restrict__ x, int64_t ld_x, int64_t num_rows, int H, int use_dst,
     const float *__restrict__ gm, int64_t ld_gm, int M, int64_t gm_row_base, int chunk_edges,
     int mtiles, int ktiles, float *__restrict__ partial, int chunk_base, DropoutParams drop,
     float *__restrict__ colsum_partial) {
@@ -95,11 +95,13 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
 #define WG_EDGE(S, R) ([&]() -> int64_t {                                   \
     int64_t e_ = e_begin + (int64_t)(S) * STEP + erow + (R) * 8;            \
     return e_ < n_edges ? e_ : n_edges - 1; }())
+#define WG_CLAMP(V) ([&]() -> int64_t { int64_t v_ = (V); v_ = v_ < 0 ? 0 : v_;            \
+    return v_ < num_rows ? v_ : num_rows - 1; }())   /* ids were range-checked by the plan build */
 #define WG_LOAD_IDX(S)                                                       \
   do {                                                                       \
     if (idx) { /* uniform: a null index list means "row e of x" (dense weight gradient) */ \
-      nid0 = idx[WG_EDGE(S, 0)]; nid1 = idx[WG_EDGE(S, 1)];                  \
-      nid2 = idx[WG_EDGE(S, 2)]; nid3 = idx[WG_EDGE(S, 3)];                  \
+      nid0 = WG_CLAMP(idx[WG_EDGE(S, 0)]); nid1 = WG_CLAMP(idx[WG_EDGE(S, 1)]); \
+      nid2 = WG_CLAMP(idx[WG_EDGE(S, 2)]); nid3 = WG_CLAMP(idx[WG_EDGE(S, 3)]); \
     } else {                                                                 \
       nid0 = WG_EDGE(S, 0); nid1 = WG_EDGE(S, 1);                            \
       nid2 = WG_EDGE(S, 2); nid3 = WG_EDGE(S, 3);                            \
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
 
 #undef WG_EDGE
 #undef WG_LOAD_IDX
+#undef WG_CLAMP
 #undef WG_LOAD_ROW
 #undef WG_LOAD_ROWS
 #undef WG_STORE
@@ -264,7 +267,7 @@ extern "C" size_t ptgnn_amd_edge_wgrad_workspace_bytes(int64_t num_edges, int32_
   return (size_t)chunks * mtiles * (ktiles * kTile + 128) * sizeof(float);   // tiles + column-sum partials
 }
 
-static int weight_grad_launch(const float *x, int64_t ld_x, int32_t state_dim,
+static int weight_grad_launch(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
                               const int64_t *const *src_per_type, const int64_t *const *dst_per_type,
                               const int64_t *edges_per_type, const float *grad_msg, int64_t ld_grad_msg,
                               int32_t num_types, int32_t msg_dim, float dropout_p, uint64_t dropout_seed,
@@ -324,7 +327,7 @@ static int weight_grad_launch(const float *x, int64_t ld_x, int32_t state_dim,
       const unsigned grid = (unsigned)xcd_padded_blocks(total);
       float *const colsum_ws = (float *)workspace + total_chunk_bound * mtiles * ktiles * kTile;
 #define PTGNN_WGRAD_LAUNCH(DROP, COLSUM)                                                              \
-  k_edge_wgrad<DROP, COLSUM><<<grid, 256, 0, st>>>(tab, x, ld_x, state_dim, use_dst, grad_msg,         \
+  k_edge_wgrad<DROP, COLSUM><<<grid, 256, 0, st>>>(tab, x, ld_x, num_rows, state_dim, use_dst, grad_msg, \
                                                    ld_grad_msg, msg_dim, row_base, ch, mtiles, ktiles, \
                                                    (float *)workspace, (int)chunk_base, drop, colsum_ws)
       if (grad_b) PTGNN_WGRAD_LAUNCH(false, true);
@@ -350,14 +353,15 @@ static int weight_grad_launch(const float *x, int64_t ld_x, int32_t state_dim,
   return PTGNN_AMD_OK;
 }
 
-extern "C" int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int32_t state_dim,
+extern "C" int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
                                               const int64_t *const *src_per_type,
                                               const int64_t *const *dst_per_type,
                                               const int64_t *edges_per_type, const float *grad_msg,
                                               int64_t ld_grad_msg, int32_t num_types, int32_t msg_dim,
                                               float dropout_p, uint64_t dropout_seed, float *grad_w,
                                               void *workspace, size_t workspace_bytes, void *stream_) {
-  return weight_grad_launch(x, ld_x, state_dim, src_per_type, dst_per_type, edges_per_type, grad_msg,
+  PTGNN_REQUIRE(num_rows > 0 || num_types == 0, PTGNN_AMD_EINVAL, "edge_weight_grad: num_rows must be positive");
+  return weight_grad_launch(x, ld_x, num_rows, state_dim, src_per_type, dst_per_type, edges_per_type, grad_msg,
                             ld_grad_msg, num_types, msg_dim, dropout_p, dropout_seed, grad_w, workspace,
                             workspace_bytes, stream_, false, nullptr);
 }
@@ -371,6 +375,6 @@ extern "C" int ptgnn_amd_linear_weight_grad_f32(const float *x, int64_t ld_x, in
                                                 void *workspace, size_t workspace_bytes, void *stream_) {
   PTGNN_REQUIRE(rows >= 0, PTGNN_AMD_EINVAL, "linear_weight_grad: negative row count");
   const int64_t counts[1] = {rows};
-  return weight_grad_launch(x, ld_x, k, nullptr, nullptr, counts, grad_y, ld_grad_y, 1, n_out, 0.f, 0,
+  return weight_grad_launch(x, ld_x, rows, k, nullptr, nullptr, counts, grad_y, ld_grad_y, 1, n_out, 0.f, 0,
                             grad_w, workspace, workspace_bytes, stream_, true, grad_b);
 }

@@ -1,0 +1,840 @@
+// Streaming ("skinny") GEMM core of the message-passing layers: rows >> K, n_out.
+//
+//     C[rows, n_out] = A[rows, K] . W[n_out, K]^T          K in {64 .. ~400}, n_out small
+//
+// Every dense block of the hot path has this shape (per-edge message Linear: 625 k gathered rows x
+// K = 128; GRU gates: 116 k rows x K = 256; MLP update: 200 k rows x K = 128).  The round-1 kernels
+// tiled it like a square GEMM -- 128 x 128 output tile per workgroup, both operands staged through LDS
+// per 32-wide K chunk, two workgroup barriers per chunk -- and landed at 0.64 of the fp32-MFMA peak
+// with "time = t(MFMA) + t(memory)" (profiles/r01_notes.md): co-resident workgroups run in lockstep,
+// so the load/store phases of a tile never hide under another tile's MFMAs.
+//
+// This kernel turns the structure inside out (MI355X-first: 160 KB LDS per CU, 512 VGPRs per SIMD):
+//   * the WEIGHT SLAB is stationary: a persistent workgroup copies its [BN, K] slice of W into LDS
+//     once per run (BN = 128 columns, or the 3 x 32 gate rows of one GRU feature tile) -- 68 KB at
+//     K = 128, 100-150 KB for the GRU at K = 256-384;
+//   * A never touches LDS: a wave owns 32 rows ("unit") and loads its MFMA A fragments straight from
+//     global memory.  The K index of an MFMA step is a free permutation as long as A and B agree, so
+//     lane (row li, half hi) takes the 16-byte pieces k = 32c + 8g + 4hi + {0..3}: every global load is
+//     a dwordx4 and every LDS read of the matching B fragment is a conflict-free ds_read_b128;
+//   * there is NO workgroup barrier in steady state: the waves of a workgroup share only the read-only
+//     slab, run their units independently and drift out of phase, so one wave's loads, epilogue math
+//     and stores overlap the MFMAs of the other wave on its SIMD;
+//   * A is register-prefetched two K-chunks ahead ACROSS unit boundaries (the next unit's first chunks
+//     load under the current unit's last MFMAs and its epilogue);
+//   * work = static, balanced runs of units in group-major order (group = column slab or edge type);
+//     the dense kernels map runs so that the column slabs of one row range share an XCD (L2 reuse).
+// The accumulation order over K inside a row is fixed (a permutation of 0..K-1 that does not depend on
+// where the row sits), so results are independent of tiling / sharding, like the round-1 kernels'.
+//
+// Arithmetic modes (ptgnn_amd_set_gemm_mode / PTGNN_AMD_GEMM):
+//   1  exact fp32: v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain (default);
+//   2  "f32 via 3xbf16 split": every operand is split exactly into three bf16 pieces (8+8+8 significand
+//      bits) and the product formed from the six largest piece products on v_mfma_f32_32x32x16_bf16 with
+//      fp32 accumulation (dropped terms <= 2^-24 |a b|).  Same error against float64 as mode 1, not
+//      bit-identical to it; opt-in.
+//   0  the round-1 tile kernels (dense_f32.hip / edge_gemm.hip), also the fallback for shapes this file
+//      does not take (K % 64 != 0, unaligned rows, slabs that do not fit LDS).
+#include <stdlib.h>
+
+#include "dense_common.h"
+#include "stream_gemm.h"
+
+namespace ptgnn_amd {
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+constexpr int kLdsBudget = 160 * 1024;
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = 0.f;
+  return v;
+}
+
+// per-lane A row pointers (+ this lane's piece offset folded in) of the current and the next unit;
+// phase 1 = the second K range of two-source kernels (GRU: previous state, MLP edge form: target state)
+struct ARows {
+  const float *c0, *c1, *n0, *n1;
+};
+
+// float4 piece g of chunk cc of the lane's row; cc >= nch addresses the NEXT unit (cross-unit prefetch).
+// All conditions are wave-uniform: selects, no branches (a branch around a load costs a vmcnt(0) drain).
+template <bool SPLIT>
+__device__ __forceinline__ float4 load_piece(const ARows &r, int cc, int ch0, int nch, int g) {
+  const bool nx = cc >= nch;
+  const int c = nx ? cc - nch : cc;
+  const float *b0 = nx ? r.n0 : r.c0;
+  const float *b1 = nx ? r.n1 : r.c1;
+  const float *p = c < ch0 ? b0 + c * 32 : b1 + (c - ch0) * 32;
+  // fp32 MFMA (K = 2 per step): pieces 8g + 4hi;  bf16 MFMA (K = 16 per step): pieces 16 (g>>1) + 8hi + 4 (g&1)
+  const int off = SPLIT ? (g >> 1) * 16 + (g & 1) * 4 : g * 8;
+  return *reinterpret_cast<const float4 *>(p + off);
+}
+
+template <bool SPLIT>
+__device__ __forceinline__ int lane_piece_offset(int hi) { return SPLIT ? hi * 8 : hi * 4; }
+
+// ---- exact 3-way bf16 split ---------------------------------------------------------------------
+// two fp32 -> one dword of two bf16 (element 0 in the low half) per piece.  v_perm_b32 picks the upper
+// halves of both inputs in one op, so only the values that feed a subtraction need the explicit mask.
+__device__ __forceinline__ uint32_t pack_hi16(float x0, float x1) {
+  return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
+  const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
+  const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
+  const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
+  const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+  h = pack_hi16(x0, x1); m = pack_hi16(r0, r1); l = pack_hi16(q0, q1);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// ---- one K chunk (32 columns) of one unit ---------------------------------------------------------
+// NBLK column blocks of the slab per step; GRU maps block 2 to accumulator 3 in phase 1 (h_n).
+// After a piece is consumed its registers are refilled with the piece two chunks ahead.
+template <int NBLK, int NACC, int PH, bool GRU>
+__device__ __forceinline__ void chunk_f32(f32x16 (&acc)[NACC], float4 (&buf)[4], float4 (&bcur)[NBLK],
+                                          const float *bl, int cbs, int kofs, int kofs_next, const ARows &rows,
+                                          int cnext, int ch0, int nch) {
+  // bcur holds the B fragments of piece 0 on entry and those of the NEXT chunk's piece 0 on exit: the
+  // LDS reads run one piece ahead of the MFMAs.  The sched_barrier pins each refill load behind the 16
+  // MFMAs that consumed its registers (hipcc otherwise sinks all eight loads to the end of the loop body
+  // and drains them with vmcnt(0) at the top: no prefetch left).
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 bn[NBLK];
+    const int ko = g < 3 ? kofs + (g + 1) * 8 : kofs_next;
+#pragma unroll
+    for (int n = 0; n < NBLK; ++n) bn[n] = *reinterpret_cast<const float4 *>(bl + n * cbs + ko);
+    __builtin_amdgcn_sched_barrier(0);   // reads first: hipcc otherwise sinks them below the MFMAs
+    const float4 a = buf[g];
+#define PTGNN_STEP(C)                                                                     \
+    _Pragma("unroll") for (int n = 0; n < NBLK; ++n) {                                    \
+      const int t = (GRU && PH == 1 && n == 2) ? 3 : n;                                   \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.C, bcur[n].C, acc[t], 0, 0, 0);     \
+    }
+    PTGNN_STEP(x) PTGNN_STEP(y) PTGNN_STEP(z) PTGNN_STEP(w)
+#undef PTGNN_STEP
+    buf[g] = load_piece<false>(rows, cnext, ch0, nch, g);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NBLK; ++n) bcur[n] = bn[n];
+  }
+}
+
+// split mode: the slab holds three bf16 planes (hi | mid | lo), each [rows][ldb] bf16; `bl` is the lane's
+// base in plane 0 (uint16 units), `plane` the plane stride, cbs the column-block stride.
+template <int NBLK, int NACC, int PH, bool GRU>
+__device__ __forceinline__ void chunk_split(f32x16 (&acc)[NACC], float4 (&buf)[4], const uint16_t *bl, int cbs,
+                                            int plane, int kofs, const ARows &rows, int cnext, int ch0,
+                                            int nch) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {   // two bf16 MFMA K-steps of 16 per chunk
+    const float4 v0 = buf[2 * s], v1 = buf[2 * s + 1];
+    u32x4 ah, am, al;
+    {
+      uint32_t h, m, l;
+      split_pair(v0.x, v0.y, h, m, l); ah[0] = h; am[0] = m; al[0] = l;
+      split_pair(v0.z, v0.w, h, m, l); ah[1] = h; am[1] = m; al[1] = l;
+      split_pair(v1.x, v1.y, h, m, l); ah[2] = h; am[2] = m; al[2] = l;
+      split_pair(v1.z, v1.w, h, m, l); ah[3] = h; am[3] = m; al[3] = l;
+    }
+    buf[2 * s] = load_piece<true>(rows, cnext, ch0, nch, 2 * s);
+    __builtin_amdgcn_sched_barrier(0);   // keep the refill order = the prologue order (counted vmcnt)
+    buf[2 * s + 1] = load_piece<true>(rows, cnext, ch0, nch, 2 * s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8 a1 = as_bf16x8(ah), a2 = as_bf16x8(am), a3 = as_bf16x8(al);
+#pragma unroll
+    for (int n = 0; n < NBLK; ++n) {
+      const uint16_t *p = bl + n * cbs + kofs + s * 16;
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(p);
+      const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(p + plane);
+      const bf16x8 b3 = *reinterpret_cast<const bf16x8 *>(p + 2 * plane);
+      const int t = (GRU && PH == 1 && n == 2) ? 3 : n;
+      f32x16 c = acc[t];   // smallest terms first
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+      acc[t] = c;
+    }
+  }
+}
+
+// The slab in LDS.  fp32: [rows][K + 4] floats.  split: 3 planes of [rows][K + 8] bf16.
+template <bool SPLIT>
+struct Slab {
+  int ld;       // row stride (floats | bf16)
+  int plane;    // plane stride in bf16 (split only)
+  __device__ __forceinline__ Slab(int K, int rows) {
+    ld = SPLIT ? K + 8 : K + 4;
+    plane = rows * ld;
+  }
+  static size_t bytes(int K, int rows) { return SPLIT ? (size_t)3 * rows * (K + 8) * 2 : (size_t)rows * (K + 4) * 4; }
+
+  // store 4 consecutive K values of slab row r
+  __device__ __forceinline__ void put4(float *smem, int r, int k, float4 v) const {
+    if constexpr (!SPLIT) {
+      *reinterpret_cast<float4 *>(smem + r * ld + k) = v;
+    } else {
+      uint16_t *p = reinterpret_cast<uint16_t *>(smem) + r * ld + k;
+      uint32_t h0, m0, l0, h1, m1, l1;
+      split_pair(v.x, v.y, h0, m0, l0);
+      split_pair(v.z, v.w, h1, m1, l1);
+      *reinterpret_cast<uint2 *>(p) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2 *>(p + plane) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2 *>(p + 2 * plane) = make_uint2(l0, l1);
+    }
+  }
+};
+
+// K loop of one unit: chunks [0, ch0) are phase 0, [ch0, nch) phase 1; a0/a1 hold chunks 0/1 on entry
+// and the next unit's chunks 0/1 on exit.  ch0 and nch are even.
+template <int NBLK, int NACC, bool GRU, bool SPLIT>
+__device__ __forceinline__ void unit_kloop(f32x16 (&acc)[NACC], float4 (&a0)[4], float4 (&a1)[4],
+                                           const float *smem, const Slab<SPLIT> &sl, int li, int hi,
+                                           const ARows &rows, int ch0, int nch) {
+  if constexpr (!SPLIT) {
+    const float *bl = smem + li * sl.ld + hi * 4;
+    const int cbs = 32 * sl.ld;
+    const int e0 = GRU ? ch0 : nch;
+    float4 bcur[NBLK];
+#pragma unroll
+    for (int n = 0; n < NBLK; ++n) bcur[n] = *reinterpret_cast<const float4 *>(bl + n * cbs);
+    for (int c = 0; c < e0; c += 2) {
+      const int kn = c + 2 < nch ? c * 32 + 64 : 0;   // the chunk after next (0: first chunk of the next unit)
+      chunk_f32<NBLK, NACC, 0, GRU>(acc, a0, bcur, bl, cbs, c * 32, c * 32 + 32, rows, c + 2, ch0, nch);
+      chunk_f32<NBLK, NACC, 0, GRU>(acc, a1, bcur, bl, cbs, c * 32 + 32, kn, rows, c + 3, ch0, nch);
+    }
+    if constexpr (GRU) {
+      for (int c = ch0; c < nch; c += 2) {
+        const int kn = c + 2 < nch ? c * 32 + 64 : 0;
+        chunk_f32<NBLK, NACC, 1, GRU>(acc, a0, bcur, bl, cbs, c * 32, c * 32 + 32, rows, c + 2, ch0, nch);
+        chunk_f32<NBLK, NACC, 1, GRU>(acc, a1, bcur, bl, cbs, c * 32 + 32, kn, rows, c + 3, ch0, nch);
+      }
+    }
+  } else {
+    const uint16_t *bl = reinterpret_cast<const uint16_t *>(smem) + li * sl.ld + hi * 8;
+    const int cbs = 32 * sl.ld;
+    const int e0 = GRU ? ch0 : nch;
+    for (int c = 0; c < e0; c += 2) {
+      chunk_split<NBLK, NACC, 0, GRU>(acc, a0, bl, cbs, sl.plane, c * 32, rows, c + 2, ch0, nch);
+      chunk_split<NBLK, NACC, 0, GRU>(acc, a1, bl, cbs, sl.plane, c * 32 + 32, rows, c + 3, ch0, nch);
+    }
+    if constexpr (GRU) {
+      for (int c = ch0; c < nch; c += 2) {
+        chunk_split<NBLK, NACC, 1, GRU>(acc, a0, bl, cbs, sl.plane, c * 32, rows, c + 2, ch0, nch);
+        chunk_split<NBLK, NACC, 1, GRU>(acc, a1, bl, cbs, sl.plane, c * 32 + 32, rows, c + 3, ch0, nch);
+      }
+    }
+  }
+}
+
+// hipcc counts vmcnt per loop only when every path into the loop header issued the pending loads in the
+// SAME order as the loop body does (the header wait is the most conservative of its predecessors).  So:
+// the first unit's loads are pinned in steady-state order, and each unit starts from a drained queue
+// (`unit_fence`): the epilogue's stores share the counter with the prefetched loads, and a mixed
+// load/store queue makes the compiler fall back to vmcnt(0) on EVERY chunk instead of once per unit.
+template <bool SPLIT>
+__device__ __forceinline__ void prologue_loads(float4 (&a0)[4], float4 (&a1)[4], const ARows &rows, int ch0,
+                                               int nch) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    a0[g] = load_piece<SPLIT>(rows, 0, ch0, nch, g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    a1[g] = load_piece<SPLIT>(rows, 1, ch0, nch, g);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ void unit_fence() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Dynamic unit claiming: the waves of a workgroup pull units of the current run / segment from one LDS
+// counter (one returning LDS atomic per unit), so they finish within one unit of each other whatever
+// their relative speed.  `claim` returns an index >= `count` when the segment is exhausted.
+__device__ __forceinline__ int claim_unit(int *counter) {
+  int v = 0;
+  if ((threadIdx.x & 63) == 0) v = atomicAdd(counter, 1);
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+// De-phase the two waves that share a SIMD (waves w and w + 4 of an 8-wave workgroup).  Started together
+// they stay in lockstep for the whole run -- both in their K loops (sharing the matrix pipe), then both in
+// their epilogue + queue drain (pipe idle): measured 62 % MFMA-busy with 75 % of the wave cycles waiting to
+// issue.  An initial offset of about one solo K loop is self-preserving and puts one
+// wave's epilogue under the other's MFMAs.
+__device__ __forceinline__ void dephase(int wave, int ticks) {
+  if (wave >= 4)
+    for (int i = 0; i < ticks; ++i) __builtin_amdgcn_s_sleep(32);   // 32 * 64 = 2048 clocks per tick
+}
+
+// ---------------------------------------------------------------------------------------------------
+// linear: y = act(x W^T + b)
+// ---------------------------------------------------------------------------------------------------
+struct LinearArgs {
+  const float *x; int64_t rows; int K; int64_t ld_x;
+  const float *w; int n_out; const float *bias; int act;
+  float *y; int64_t ld_y;
+  int nrb, ncs, rps, run_len;
+  int lds_floats, dephase;   // slab size in floats (the unit counter sits behind it); de-phase ticks
+};
+
+template <int ACT>
+__device__ __forceinline__ void store_block(const f32x16 &c, float *yp, int64_t ld_y, float bv, int64_t row0,
+                                            int64_t rows, int hi) {
+  // C fragment: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 hi
+  if (row0 + 32 <= rows) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      yp[(int64_t)((r & 3) + 8 * (r >> 2)) * ld_y] = act_apply<ACT>(c[r] + bv);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2);
+      if (row0 + rr + 4 * hi < rows) yp[(int64_t)rr * ld_y] = act_apply<ACT>(c[r] + bv);
+    }
+  }
+}
+
+template <int NB, bool SPLIT>
+__global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 512, BN = 32 * NB;
+  const int b = blockIdx.x, G = gridDim.x;
+  int slab, part;
+  if (G % (kNumXcd * p.ncs) == 0) {   // the column slabs of one row range share an XCD (L2 reuse of A)
+    const int xcd = b % kNumXcd, j = b / kNumXcd;
+    slab = j % p.ncs;
+    part = xcd + kNumXcd * (j / p.ncs);
+  } else {
+    slab = b / p.rps;
+    part = b % p.rps;
+  }
+  const int rb0 = part * p.run_len;
+  const int rb1 = rb0 + p.run_len < p.nrb ? rb0 + p.run_len : p.nrb;
+  if (rb0 >= rb1) return;
+  const int count = rb1 - rb0;
+
+  const Slab<SPLIT> sl(p.K, BN);
+  int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
+  if (threadIdx.x == 0) *counter = 0;
+  const int col_base = slab * BN;
+  {
+    const int kq = p.K >> 2;
+    for (int i = threadIdx.x; i < BN * kq; i += NT) {
+      const int r = i / kq, k = (i - r * kq) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col_base + r < p.n_out) v = *reinterpret_cast<const float4 *>(p.w + (int64_t)(col_base + r) * p.K + k);
+      sl.put4(smem, r, k, v);
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int nch = p.K >> 5;
+  const int lofs = lane_piece_offset<SPLIT>(hi);
+  auto rowp = [&](int u) {   // u: unit index inside the run (clamped to the run)
+    int64_t row = (int64_t)(rb0 + (u < count ? u : count - 1)) * 32 + li;
+    row = row < p.rows ? row : p.rows - 1;
+    return p.x + row * p.ld_x + lofs;
+  };
+  int cur = claim_unit(counter);
+  if (cur >= count) return;
+  int nxt = claim_unit(counter);
+  dephase(wave, p.dephase);
+  ARows rows;
+  rows.c0 = rows.c1 = rowp(cur);
+  rows.n0 = rows.n1 = rowp(nxt);
+  float4 a0[4], a1[4];
+  prologue_loads<SPLIT>(a0, a1, rows, nch, nch);
+  f32x16 acc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) acc[n] = zero16();
+
+  while (cur < count) {
+    const int nn = claim_unit(counter);
+    unit_fence();
+    unit_kloop<NB, NB, false, SPLIT>(acc, a0, a1, smem, sl, li, hi, rows, nch, nch);
+    const int64_t row0 = (int64_t)(rb0 + cur) * 32;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int col = col_base + n * 32 + li;
+      if (col_base + n * 32 < p.n_out) {   // n_out % 32 == 0: whole column blocks
+        const float bv = p.bias ? p.bias[col] : 0.f;
+        float *yp = p.y + (row0 + 4 * hi) * p.ld_y + col;
+        if (p.act == PTGNN_AMD_ACT_TANH) store_block<PTGNN_AMD_ACT_TANH>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
+        else if (p.act == PTGNN_AMD_ACT_RELU) store_block<PTGNN_AMD_ACT_RELU>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
+        else store_block<PTGNN_AMD_ACT_NONE>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
+      }
+      acc[n] = zero16();
+    }
+    cur = nxt;
+    nxt = nn;
+    rows.c0 = rows.c1 = rows.n0;
+    rows.n0 = rows.n1 = rowp(nxt);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused GRU cell: unit = 32 rows x 32 state features; slab = the 3 x 32 gate rows of the feature tile,
+// each [W_ih row | W_hh row] (K = M + H); accumulators r, z, i_n, h_n share one C-fragment map.
+// ---------------------------------------------------------------------------------------------------
+struct GruArgs {
+  const float *a; int64_t ld_a; const float *h; int64_t ld_h;
+  const float *w_ih, *w_hh, *b_ih, *b_hh;
+  int64_t n; int M, H;
+  float *out; int64_t ld_out; float *gates;
+  int nrb, ncs, rps, run_len;
+  int lds_floats, dephase;
+};
+
+// sigmoid / tanh on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each): absolute error
+// ~1.5e-7, against ~1700 VALU instructions per unit for the libm forms -- which made the epilogue 40 % of
+// a unit's MFMA time
+__device__ __forceinline__ float fast_sigmoid(float v) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+__device__ __forceinline__ float fast_tanh(float v) {
+  return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * v)) - 1.0f;
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 512;
+  const int b = blockIdx.x, G = gridDim.x;
+  int slab, part;
+  if (G % (kNumXcd * p.ncs) == 0) {
+    const int xcd = b % kNumXcd, j = b / kNumXcd;
+    slab = j % p.ncs;
+    part = xcd + kNumXcd * (j / p.ncs);
+  } else {
+    slab = b / p.rps;
+    part = b % p.rps;
+  }
+  const int rb0 = part * p.run_len;
+  const int rb1 = rb0 + p.run_len < p.nrb ? rb0 + p.run_len : p.nrb;
+  if (rb0 >= rb1) return;
+  const int count = rb1 - rb0;
+
+  const int K = p.M + p.H;
+  const Slab<SPLIT> sl(K, 96);
+  int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
+  if (threadIdx.x == 0) *counter = 0;
+  const int j0 = slab * 32;
+  {
+    const int kq = K >> 2, mq = p.M >> 2;
+    for (int i = threadIdx.x; i < 96 * kq; i += NT) {
+      const int r = i / kq, q = i - r * kq;
+      const int gate = r >> 5, jj = j0 + (r & 31);   // H % 32 == 0: always a valid feature
+      const float *src = q < mq ? p.w_ih + ((int64_t)gate * p.H + jj) * p.M + q * 4
+                                : p.w_hh + ((int64_t)gate * p.H + jj) * p.H + (q - mq) * 4;
+      sl.put4(smem, r, q * 4, *reinterpret_cast<const float4 *>(src));
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int ch0 = p.M >> 5, nch = K >> 5;
+  const int lofs = lane_piece_offset<SPLIT>(hi);
+  auto clampr = [&](int u) {
+    const int64_t row = (int64_t)(rb0 + (u < count ? u : count - 1)) * 32 + li;
+    return row < p.n ? row : p.n - 1;
+  };
+  int cur = claim_unit(counter);
+  if (cur >= count) return;
+  int nxt = claim_unit(counter);
+  dephase(wave, p.dephase);
+  ARows rows;
+  {
+    const int64_t r0 = clampr(cur), r1 = clampr(nxt);
+    rows.c0 = p.a + r0 * p.ld_a + lofs; rows.c1 = p.h + r0 * p.ld_h + lofs;
+    rows.n0 = p.a + r1 * p.ld_a + lofs; rows.n1 = p.h + r1 * p.ld_h + lofs;
+  }
+  float4 a0[4], a1[4];
+  prologue_loads<SPLIT>(a0, a1, rows, ch0, nch);
+  f32x16 acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc[n] = zero16();
+
+  const int j = j0 + li;
+  const float bir = p.b_ih[j], biz = p.b_ih[p.H + j], bin = p.b_ih[2 * p.H + j];
+  const float bhr = p.b_hh[j], bhz = p.b_hh[p.H + j], bhn = p.b_hh[2 * p.H + j];
+
+  while (cur < count) {
+    const int nn = claim_unit(counter);
+    unit_fence();
+    unit_kloop<3, 4, true, SPLIT>(acc, a0, a1, smem, sl, li, hi, rows, ch0, nch);
+    const int64_t row0 = (int64_t)(rb0 + cur) * 32;
+    // previous state of this lane's 16 output elements: re-read (L2-hot, this unit just streamed the rows)
+    float hprev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      row = row < p.n ? row : p.n - 1;
+      hprev[r] = p.h[row * p.ld_h + j];
+    }
+    float res[16];
+    {
+      // no mul+add contraction: a row's result must not depend on which of the lane's 16 slots it occupies
+      // (sharded == unsharded bit for bit)
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float rg = fast_sigmoid((acc[0][r] + bir) + bhr);
+        const float zg = fast_sigmoid((acc[1][r] + biz) + bhz);
+        const float hn = acc[3][r] + bhn;
+        const float ng = fast_tanh((acc[2][r] + bin) + rg * hn);
+        res[r] = (1.0f - zg) * ng + zg * hprev[r];
+        if (p.gates) {   // training: r, z, n, gh_n for the backward ([n, 4H], gate-major)
+          const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (row < p.n) {
+            float *gp = p.gates + row * (int64_t)(4 * p.H) + j;
+            gp[0] = rg; gp[p.H] = zg; gp[2 * p.H] = ng; gp[3 * p.H] = hn;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = zero16();
+    float *dst = p.out + (row0 + 4 * hi) * p.ld_out + j;
+    if (row0 + 32 <= p.n) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * p.ld_out] = res[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2);
+        if (row0 + rr + 4 * hi < p.n) dst[(int64_t)rr * p.ld_out] = res[r];
+      }
+    }
+    cur = nxt;
+    nxt = nn;
+    rows.c0 = rows.n0; rows.c1 = rows.n1;
+    const int64_t r1 = clampr(nxt);
+    rows.n0 = p.a + r1 * p.ld_a + lofs; rows.n1 = p.h + r1 * p.ld_h + lofs;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// grouped per-edge GEMM: unit = 32 edges of one type; flat balanced runs over the type-major unit order;
+// a run reloads the slab (W_t) when it crosses into the next edge type.
+// ---------------------------------------------------------------------------------------------------
+struct EdgeArgs {
+  StreamEdgeTable tab;
+  const float *x; int64_t ld_x; int H; int use_dst; int M; int act;
+  float *msg; int64_t ld_msg; int64_t msg_row_base;
+  int64_t num_rows;          // rows of x (gathered ids are clamped into it)
+  int run_len, lds_floats, dephase;
+};
+
+template <int NB, bool SPLIT>
+__global__ __launch_bounds__(512, 2) void k_stream_edge(EdgeArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 512, BN = 32 * NB;
+  const int total = p.tab.unit_off[p.tab.num_types];
+  int u = blockIdx.x * p.run_len;
+  const int u_end = u + p.run_len < total ? u + p.run_len : total;
+  if (u >= u_end) return;
+  const int K = p.use_dst ? 2 * p.H : p.H;
+  const Slab<SPLIT> sl(K, BN);
+  int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int ch0 = p.H >> 5, nch = K >> 5;
+  const int lofs = lane_piece_offset<SPLIT>(hi);
+
+  while (u < u_end) {
+    int lo = 0, hi_t = p.tab.num_types;   // edge type of unit u (table lives in SGPRs)
+    while (hi_t - lo > 1) {
+      const int mid = (lo + hi_t) >> 1;
+      if (p.tab.unit_off[mid] <= u) lo = mid; else hi_t = mid;
+    }
+    const int t = lo;
+    const int seg_end = p.tab.unit_off[t + 1] < u_end ? p.tab.unit_off[t + 1] : u_end;
+    const int ub = u - p.tab.unit_off[t];             // first unit of the segment inside the type
+    const int count = seg_end - u;
+    const int64_t n_edges = p.tab.edge_off[t + 1] - p.tab.edge_off[t];
+    const int64_t *__restrict__ src = p.tab.src[t];
+    const int64_t *__restrict__ dst = p.tab.dst[t];
+    __syncthreads();   // every wave is done with the previous slab and its counter
+    if (threadIdx.x == 0) *counter = 0;
+    {
+      const float *w = p.tab.w[t];
+      const int kq = K >> 2;
+      for (int i = threadIdx.x; i < BN * kq; i += NT) {
+        const int r = i / kq, k = (i - r * kq) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < p.M) v = *reinterpret_cast<const float4 *>(w + (int64_t)r * K + k);
+        sl.put4(smem, r, k, v);
+      }
+    }
+    __syncthreads();
+
+    int cur = claim_unit(counter);
+    if (cur < count) {
+      int nxt = claim_unit(counter);
+      int nn = claim_unit(counter);   // the node ids of a unit are fetched two units ahead of its rows
+      dephase(wave, p.dephase);
+      auto edge_of = [&](int unit) {
+        const int64_t e = (int64_t)(ub + (unit < count ? unit : count - 1)) * 32 + li;
+        return e < n_edges ? e : n_edges - 1;
+      };
+      auto node_row = [&](int64_t id) {   // ids were range-checked by the plan build; clamp anyway
+        id = id < 0 ? 0 : id;
+        return p.x + (id < p.num_rows ? id : p.num_rows - 1) * p.ld_x + lofs;
+      };
+      ARows rows;
+      {
+        const int64_t e0 = edge_of(cur), e1 = edge_of(nxt);
+        rows.c0 = node_row(src[e0]); rows.c1 = node_row(dst[e0]);
+        rows.n0 = node_row(src[e1]); rows.n1 = node_row(dst[e1]);
+      }
+      float4 a0[4], a1[4];
+      prologue_loads<SPLIT>(a0, a1, rows, ch0, nch);
+      f32x16 acc[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[n] = zero16();
+      while (cur < count) {
+        const int n3 = claim_unit(counter);
+        const int64_t e_nn = edge_of(nn);
+        unit_fence();
+        const int64_t s_nn = src[e_nn], d_nn = dst[e_nn];   // lands under this unit's MFMAs
+        unit_kloop<NB, NB, false, SPLIT>(acc, a0, a1, smem, sl, li, hi, rows, ch0, nch);
+        const int64_t e_row0 = (int64_t)(ub + cur) * 32;
+        const int64_t out_row0 = p.msg_row_base + p.tab.edge_off[t] + e_row0;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          if (n * 32 < p.M) {
+            float *yp = p.msg + (out_row0 + 4 * hi) * p.ld_msg + n * 32 + li;
+            if (p.act == PTGNN_AMD_ACT_TANH) store_block<PTGNN_AMD_ACT_TANH>(acc[n], yp, p.ld_msg, 0.f, e_row0, n_edges, hi);
+            else if (p.act == PTGNN_AMD_ACT_RELU) store_block<PTGNN_AMD_ACT_RELU>(acc[n], yp, p.ld_msg, 0.f, e_row0, n_edges, hi);
+            else store_block<PTGNN_AMD_ACT_NONE>(acc[n], yp, p.ld_msg, 0.f, e_row0, n_edges, hi);
+          }
+          acc[n] = zero16();
+        }
+        cur = nxt; nxt = nn; nn = n3;
+        rows.c0 = rows.n0; rows.c1 = rows.n1;
+        rows.n0 = node_row(s_nn); rows.n1 = node_row(d_nn);
+      }
+    }
+    u = seg_end;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+int g_mode = -1;
+
+bool debug_on() {
+  static int v = -1;
+  if (v < 0) v = getenv("PTGNN_AMD_DEBUG") ? 1 : 0;
+  return v == 1;
+}
+
+template <typename Kern>
+bool set_lds(Kern kern, size_t bytes) {
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (debug_on()) fprintf(stderr, "[ptgnn_amd] stream kernel: %zu B of LDS refused (%s) -> tile kernel\n", bytes, hipGetErrorString(e));
+  }
+  return e == hipSuccess;
+}
+
+// de-phase offset ~ one solo K loop of a unit, in ticks of 2048 clocks
+int dephase_ticks(int nch, int nblk, bool split) {
+  const int64_t clk = split ? (int64_t)nch * nblk * 2 * 6 * 32 : (int64_t)nch * nblk * 16 * 64;
+  int t = (int)((clk + 1024) / 2048);
+  if (const char *e = getenv("PTGNN_AMD_DEPHASE")) t = atoi(e);   // developer A/B knob (0 = off)
+  return t < 0 ? 0 : (t > 64 ? 64 : t);
+}
+
+// runs per slab for the dense kernels: one 8-wave workgroup per CU
+void dense_runs(int nrb, int ncs, int &rps, int &run_len) {
+  const int max_wg = num_compute_units();
+  rps = max_wg / ncs;
+  if (rps < 1) rps = 1;
+  if (rps >= kNumXcd && (rps / kNumXcd * kNumXcd) * ncs * 10 >= max_wg * 9) rps = rps / kNumXcd * kNumXcd;
+  if (rps > nrb) rps = nrb;
+  run_len = (nrb + rps - 1) / rps;
+  rps = (nrb + run_len - 1) / run_len;   // drop runs that would be empty
+}
+
+}  // namespace
+
+int stream_gemm_mode() {
+  if (g_mode < 0) {
+    const char *e = getenv("PTGNN_AMD_GEMM");
+    int m = e ? atoi(e) : 1;
+    g_mode = (m >= 0 && m <= 2) ? m : 1;
+  }
+  return g_mode;
+}
+
+void stream_gemm_set_mode(int mode) { g_mode = mode; }
+
+#define PTGNN_STREAM_DISPATCH_NB(NBV, KERN, ...)     \
+  switch (NBV) {                                      \
+    case 1: KERN(1, __VA_ARGS__); break;              \
+    case 2: KERN(2, __VA_ARGS__); break;              \
+    case 3: KERN(3, __VA_ARGS__); break;              \
+    default: KERN(4, __VA_ARGS__); break;             \
+  }
+
+int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const float *w, int32_t n_out,
+                  const float *bias, int act, float *y, int64_t ld_y, hipStream_t st) {
+  const int mode = stream_gemm_mode();
+  if (mode == 0) return 0;
+  if (k % 64 != 0 || n_out % 32 != 0 || ld_x % 4 != 0 || !aligned16(x) || !aligned16(w)) return 0;
+  if (rows >= ((int64_t)1 << 31) * 32) return 0;
+  const int bn = n_out >= 128 ? 128 : n_out;
+  const int nb = bn / 32;
+  bool split = mode == 2;
+  size_t slab = split ? Slab<true>::bytes(k, bn) : Slab<false>::bytes(k, bn);
+  if (split && slab + 16 > (size_t)kLdsBudget) {   // three bf16 planes do not fit: this shape stays exact fp32
+    split = false;
+    slab = Slab<false>::bytes(k, bn);
+  }
+  const size_t lds = slab + 16;
+  if (lds > (size_t)kLdsBudget) return 0;
+  LinearArgs p;
+  p.x = x; p.rows = rows; p.K = k; p.ld_x = ld_x; p.w = w; p.n_out = n_out; p.bias = bias; p.act = act;
+  p.y = y; p.ld_y = ld_y;
+  p.nrb = (int)((rows + 31) / 32);
+  p.ncs = (n_out + bn - 1) / bn;
+  dense_runs(p.nrb, p.ncs, p.rps, p.run_len);
+  p.lds_floats = (int)(slab / 4);
+  p.dephase = dephase_ticks(k / 32, nb, split);
+  const unsigned grid = (unsigned)(p.ncs * p.rps);
+#define PTGNN_K(NBV, SP)                                                            \
+  do {                                                                              \
+    auto kern = k_stream_linear<NBV, SP>;                                           \
+    if (!set_lds(kern, lds)) return 0;                                              \
+    kern<<<grid, 512, lds, st>>>(p);                                                \
+  } while (0)
+  if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
+#undef PTGNN_K
+  return 1;
+}
+
+int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const float *w_ih,
+               const float *w_hh, const float *b_ih, const float *b_hh, int64_t n, int32_t m, int32_t hd,
+               float *out, int64_t ld_out, float *gates, hipStream_t st) {
+  const int mode = stream_gemm_mode();
+  if (mode == 0) return 0;
+  if (m % 64 != 0 || hd % 64 != 0 || ld_a % 4 != 0 || ld_h % 4 != 0 || !aligned16(a) || !aligned16(h) ||
+      !aligned16(w_ih) || !aligned16(w_hh))
+    return 0;
+  if (n >= ((int64_t)1 << 31) * 32) return 0;
+  bool split = mode == 2;
+  const int K = m + hd;
+  size_t slab = split ? Slab<true>::bytes(K, 96) : Slab<false>::bytes(K, 96);
+  if (split && slab + 16 > (size_t)kLdsBudget) {
+    split = false;
+    slab = Slab<false>::bytes(K, 96);
+  }
+  const size_t lds = slab + 16;
+  if (lds > (size_t)kLdsBudget) return 0;
+  GruArgs p;
+  p.a = a; p.ld_a = ld_a; p.h = h; p.ld_h = ld_h; p.w_ih = w_ih; p.w_hh = w_hh; p.b_ih = b_ih; p.b_hh = b_hh;
+  p.n = n; p.M = m; p.H = hd; p.out = out; p.ld_out = ld_out; p.gates = gates;
+  p.nrb = (int)((n + 31) / 32);
+  p.ncs = hd / 32;
+  dense_runs(p.nrb, p.ncs, p.rps, p.run_len);
+  p.lds_floats = (int)(slab / 4);
+  p.dephase = dephase_ticks(K / 32, 3, split);
+  const unsigned grid = (unsigned)(p.ncs * p.rps);
+#define PTGNN_K(SP)                                      \
+  do {                                                   \
+    auto kern = k_stream_gru<SP>;                        \
+    if (!set_lds(kern, lds)) return 0;                   \
+    kern<<<grid, 512, lds, st>>>(p);                     \
+  } while (0)
+  if (split) PTGNN_K(true); else PTGNN_K(false);
+#undef PTGNN_K
+  return 1;
+}
+
+// 0 = not taken, 1 = exact fp32 streaming, 2 = split streaming
+static int edge_plan(int32_t state_dim, int32_t msg_dim, int use_dst, size_t *slab_bytes) {
+  const int mode = stream_gemm_mode();
+  if (mode == 0) return 0;
+  const int K = use_dst ? 2 * state_dim : state_dim;
+  if (K % 64 != 0 || state_dim % 32 != 0 || msg_dim % 32 != 0 || msg_dim > 128) return 0;
+  if (mode == 2 && Slab<true>::bytes(K, msg_dim) + 16 <= (size_t)kLdsBudget) {
+    *slab_bytes = Slab<true>::bytes(K, msg_dim);
+    return 2;
+  }
+  if (Slab<false>::bytes(K, msg_dim) + 16 <= (size_t)kLdsBudget) {
+    *slab_bytes = Slab<false>::bytes(K, msg_dim);
+    return 1;
+  }
+  return 0;
+}
+
+int stream_edge_supported(int32_t state_dim, int32_t msg_dim, int use_dst) {
+  size_t b;
+  return edge_plan(state_dim, msg_dim, use_dst, &b) != 0;
+}
+
+int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
+                int use_dst, int32_t msg_dim, int act, float *msg, int64_t ld_msg, int64_t msg_row_base,
+                hipStream_t st) {
+  size_t slab = 0;
+  const int kind = edge_plan(state_dim, msg_dim, use_dst, &slab);
+  if (kind == 0) return 0;
+  const bool split = kind == 2;
+  const int K = use_dst ? 2 * state_dim : state_dim;
+  const int nb = msg_dim / 32;
+  const size_t lds = slab + 16;
+  const int total = tab.unit_off[tab.num_types];
+  if (total == 0) return 1;
+  EdgeArgs p;
+  p.tab = tab; p.x = x; p.ld_x = ld_x; p.H = state_dim; p.use_dst = use_dst; p.M = msg_dim; p.act = act;
+  p.msg = msg; p.ld_msg = ld_msg; p.msg_row_base = msg_row_base; p.num_rows = num_rows;
+  const int max_wg = num_compute_units();
+  p.run_len = (total + max_wg - 1) / max_wg;
+  if (p.run_len < 8) p.run_len = 8;   // at least one unit per wave
+  p.lds_floats = (int)(slab / 4);
+  p.dephase = dephase_ticks(K / 32, nb, split);
+  const unsigned grid = (unsigned)((total + p.run_len - 1) / p.run_len);
+#define PTGNN_K(NBV, SP)                                      \
+  do {                                                        \
+    auto kern = k_stream_edge<NBV, SP>;                       \
+    if (!set_lds(kern, lds)) return 0;                        \
+    kern<<<grid, 512, lds, st>>>(p);                          \
+  } while (0)
+  if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
+#undef PTGNN_K
+  return 1;
+}
+
+}  // namespace ptgnn_amd
+
+extern "C" int ptgnn_amd_set_gemm_mode(int mode) {
+  if (mode < 0 || mode > 2) {
+    ptgnn_amd::set_error("set_gemm_mode: mode must be 0 (tile kernels), 1 (streaming fp32) or 2 (streaming 3xbf16 split)");
+    return PTGNN_AMD_EINVAL;
+  }
+  ptgnn_amd::stream_gemm_set_mode(mode);
+  return PTGNN_AMD_OK;
+}
+
+extern "C" int ptgnn_amd_get_gemm_mode(void) { return ptgnn_amd::stream_gemm_mode(); }

@@ -30,6 +30,7 @@ general per-edge path: torch dense ops on the GPU plus the HIP segment-reduce se
 rule.  No path runs on the CPU.
 """
 import contextlib
+import threading
 from typing import Dict, List, Optional, Tuple, Union
 
 import torch
@@ -79,32 +80,31 @@ Adj = List[Tuple[torch.Tensor, torch.Tensor]]
 # `forward_scope()` -- ptgnn_amd.gnn.GraphNeuralNetwork opens one around its layer loop -- they are built
 # once, so autograd accumulates one stacked gradient per use instead of T small ones.  Outside a scope
 # nothing is cached (the autograd graph of a cached tensor must not outlive its forward).
-_FORWARD_SCOPE: Optional[dict] = None
+_SCOPE = threading.local()
 
 
 @contextlib.contextmanager
 def forward_scope():
-    global _FORWARD_SCOPE
-    outer = _FORWARD_SCOPE
+    outer = getattr(_SCOPE, "cache", None)
     if outer is None:
-        _FORWARD_SCOPE = {}
+        _SCOPE.cache = {}
     try:
         yield
     finally:
-        _FORWARD_SCOPE = outer
+        _SCOPE.cache = outer
 
 
-def _scoped(key, make):
-    if _FORWARD_SCOPE is None or not torch.is_grad_enabled():
+def _scoped(owner, name, make):
+    """Per-thread cache keyed on the module OBJECT (kept alive by the key, so an id() can never be reused
+    by another module while the entry exists)."""
+    cache = getattr(_SCOPE, "cache", None)
+    if cache is None or not torch.is_grad_enabled():
         return make()
-    val = _FORWARD_SCOPE.get(key)
+    key = (owner, name)
+    val = cache.get(key)
     if val is None:
-        val = _FORWARD_SCOPE[key] = make()
+        val = cache[key] = make()
     return val
-
-
-def _versions(params) -> Tuple:
-    return tuple((p.data_ptr(), p._version) for p in params)
 
 
 def _no_grad_needed(*tensors) -> bool:
@@ -208,16 +208,13 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
         self.__dropout = nn.Dropout(p=dropout_rate)
         self._message_dimension = message_dimension
         self._edge_feature_dimension = edge_feature_dimension
-        self._stacked = None  # (versions, [T*M, H] weight)
 
     # -- fused path -------------------------------------------------------------------------
     def _stacked_edge_weights(self) -> torch.Tensor:
-        ws = [lin.weight for lin in self.__edge_message_transformation_layers]
-        key = _versions(ws)
-        if self._stacked is None or self._stacked[0] != key:
-            with torch.no_grad():
-                self._stacked = (key, torch.cat([w.detach() for w in ws], dim=0).contiguous())
-        return self._stacked[1]
+        """[T*M, H] = [W_0; ...; W_{T-1}], rebuilt per call: a cache keyed on parameter versions would go
+        stale under `p.data` updates (EMA, weight clipping), and the copy is tiny next to the GEMM."""
+        ws = [lin.weight.detach() for lin in self.__edge_message_transformation_layers]
+        return ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
 
     def _table_ok(self, node_states, edge_features) -> bool:
         """Message == row of the per-node table X [W_0; ...]^T: no edge features, no per-edge dropout."""
@@ -261,7 +258,7 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                 and (p > 0 or _prefer_edge_path(plan.num_edges, num_nodes, T, self.__state_dimension, M))):
             # training, edge form: grouped per-edge GEMM with the reference's per-edge input dropout
             # folded in (forward + both gradients on HIP), HIP segment reduce, torch GRU cell
-            w_stack = _scoped((id(self), "edge_w"), lambda: torch.stack(
+            w_stack = _scoped(self, "edge_w", lambda: torch.stack(
                 [l.weight for l in self.__edge_message_transformation_layers]))
             msgs = edge_linear_autograd(node_states, plan, w_stack, False, p, _dropout_seed() if p > 0 else 0)
             agg = segment_reduce(msgs, plan, self.__aggregation_fn)
@@ -384,20 +381,17 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             object.__setattr__(self, name, mod)
         self._message_dimension = message_dimension
         self._features_dimension = features_dimension
-        self._stacked = None
 
     # -- fused path -------------------------------------------------------------------------
     def _stacked_edge_weights(self) -> torch.Tensor:
-        ws = [m.linears[0].weight for m in self.__edge_message_transformation_layers]
-        key = _versions(ws)
-        if self._stacked is None or self._stacked[0] != key:
-            H = self.__input_state_dim
-            with torch.no_grad():
-                parts = [w.detach()[:, :H] for w in ws]
-                if self.__use_target_state_as_message_input:
-                    parts += [w.detach()[:, H:2 * H] for w in ws]
-                self._stacked = (key, torch.cat(parts, dim=0).contiguous())   # [(1|2)*T*M, H]
-        return self._stacked[1]
+        """[(1|2)*T*M, H]: source halves of every type, then (with target state) the target halves; rebuilt
+        per call (see GatedMessagePassingLayer._stacked_edge_weights)."""
+        ws = [m.linears[0].weight.detach() for m in self.__edge_message_transformation_layers]
+        H = self.__input_state_dim
+        parts = [w[:, :H] for w in ws]
+        if self.__use_target_state_as_message_input:
+            parts += [w[:, H:2 * H] for w in ws]
+        return torch.cat(parts, dim=0).contiguous()
 
     def _table_ok(self, node_states, edge_features) -> bool:
         if not isinstance(self.__aggregation_fn, str):
@@ -513,7 +507,7 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             if _edge_training_ok(H, M) and _prefer_edge_path(plan.num_edges, num_nodes, T, H, M):
                 # training, many sparse edge types: grouped per-edge GEMM forward + backward on HIP
                 # (the edge MLPs of this layer carry no dropout: mlpmessagepassing.py:39-47)
-                w_stack = _scoped((id(self), "edge_w"), lambda: torch.stack(ws))
+                w_stack = _scoped(self, "edge_w", lambda: torch.stack(ws))
                 msgs = edge_linear_autograd(node_states, plan, w_stack, self.__use_target_state_as_message_input)
                 return self._update(segment_reduce(msgs, plan, self.__aggregation_fn), False)
             # training: dense blocks through torch autograd, aggregation fwd + bwd on the HIP kernel

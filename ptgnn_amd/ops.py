@@ -5,6 +5,7 @@ allocator and stream semantics are preserved) and supplies the current HIP strea
 happens in libptgnn_amd.so; there is no eager fallback.
 """
 import ctypes
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -15,6 +16,24 @@ from ptgnn_amd import _lib
 REDUCE_IDS = {"sum": 0, "add": 0, "mean": 1, "max": 2, "min": 3}
 EPI_NONE, EPI_GELU, EPI_LAYERNORM, EPI_GELU_LAYERNORM = 0, 1, 2, 3
 ACT_IDS = {None: 0, "none": 0, "tanh": 1, "relu": 2}
+
+
+GEMM_MODES = {"tile": 0, "stream": 1, "split": 2}
+
+
+def set_gemm_mode(mode) -> int:
+    """Kernel family / arithmetic of the dense blocks (ptgnn_amd_set_gemm_mode): "tile" = round-1 128x128
+    tile kernels, "stream" = weight-stationary streaming kernels, both exact fp32 MFMA; "split" = streaming
+    kernels with f32 emulated by an exact 3 x bf16 operand split on the bf16 MFMA (opt-in).  Returns the
+    previous mode id."""
+    lib = _lib.load()
+    prev = lib.ptgnn_amd_get_gemm_mode()
+    _lib.check(lib.ptgnn_amd_set_gemm_mode(GEMM_MODES.get(mode, mode)), "ptgnn_amd_set_gemm_mode")
+    return prev
+
+
+def get_gemm_mode() -> int:
+    return _lib.load().ptgnn_amd_get_gemm_mode()
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -211,6 +230,65 @@ class GraphPlan:
         return self._inv_perm
 
 
+# ------------------------------------------------------------------------------------------------
+# index range guard
+# ------------------------------------------------------------------------------------------------
+# The reference device-asserts on an out-of-range node id (F.embedding, gatedmessagepassing.py:54-56).
+# Here the plan build clamps such ids to row 0 (nothing is ever read or written out of bounds) and counts
+# them in a per-device accumulator; the count travels back through a pinned host word WITHOUT a sync and
+# is looked at on later plan builds (or on demand: `check_indices(sync=True)`).  A non-zero count raises
+# PtgnnAmdError: the results of the offending minibatch are garbage, like the reference's would be.
+_BAD = {}    # device index -> {"dev": int32[1] accumulator, "host": pinned int32[1], "event": Event | None}
+VALIDATE_INDICES = os.environ.get("PTGNN_AMD_VALIDATE", "async")   # "async" | "sync" | "off"
+
+
+def _bad_state(device):
+    key = torch.device(device).index or 0
+    st = _BAD.get(key)
+    if st is None:
+        st = {"dev": torch.zeros(1, dtype=torch.int32, device=device),
+              "host": torch.zeros(1, dtype=torch.int32).pin_memory(), "event": None}
+        _BAD[key] = st
+    return st
+
+
+def _raise_bad(st, count: int):
+    st["dev"].zero_()
+    st["host"].zero_()
+    st["event"] = None
+    raise _lib.PtgnnAmdError(
+        f"{count} node id(s) outside [0, num_nodes) reached the graph plan build (adjacency lists / scatter "
+        "index / dim_size too small). They were clamped to row 0 so no memory was touched out of bounds, but "
+        "the outputs of that minibatch are wrong.")
+
+
+def check_indices(device=None, sync: bool = False) -> None:
+    """Raise if a plan build on `device` saw an out-of-range node id.  sync=False only looks at read-backs
+    that have already completed (no host-device synchronisation)."""
+    for key, st in list(_BAD.items()):
+        if device is not None and (torch.device(device).index or 0) != key:
+            continue
+        if sync:
+            n = int(st["dev"].item())
+            if n:
+                _raise_bad(st, n)
+            continue
+        ev = st["event"]
+        if ev is not None and ev.query():
+            st["event"] = None
+            n = int(st["host"][0])
+            if n:
+                _raise_bad(st, n)
+
+
+def _post_plan_readback(st) -> None:
+    if st["event"] is None:   # one read-back in flight at a time
+        st["host"].copy_(st["dev"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["event"] = ev
+
+
 def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num_nodes: int,
                transposed: bool = False, want_perm: bool = True,
                num_src_rows: Optional[int] = None, mode: Optional[int] = None) -> GraphPlan:
@@ -253,6 +331,10 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
     src_ptrs = PtrArr(*[s.data_ptr() if s.numel() else None for s in srcs])
     dst_ptrs = PtrArr(*[d.data_ptr() if d.numel() else None for d in dsts])
     cnts = CntArr(*counts)
+    bad = None
+    if VALIDATE_INDICES != "off":
+        bad = _bad_state(dev)
+        check_indices(dev)          # surfaces an earlier minibatch's bad ids (never blocks)
     # algorithmic bytes: read 16 B/edge (int64 src+dst), write 4 B/edge col (+4 perm) + rowptr
     with _timed("csr_build", bytes=E * (16 + 4 + (4 if want_perm else 0)) + 4.0 * (num_nodes + 1)):
         rc = lib.ptgnn_amd_csr_build(ctypes.cast(src_ptrs, ctypes.c_void_p),
@@ -264,8 +346,14 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
                                      HUB_THRESHOLD if hub_entries is not None else 0,
                                      hub_entries.data_ptr() if hub_entries is not None else None,
                                      hub_count.data_ptr() if hub_count is not None else None,
+                                     bad["dev"].data_ptr() if bad is not None else None,
                                      ws.data_ptr(), ws_bytes, _stream(rowptr))
     _lib.check(rc, "ptgnn_amd_csr_build")
+    if bad is not None:
+        if VALIDATE_INDICES == "sync":
+            check_indices(dev, sync=True)
+        elif not torch.cuda.is_current_stream_capturing():
+            _post_plan_readback(bad)
     # `ws`, `srcs`, `dsts` are stream-ordered: torch's caching allocator only hands their memory to
     # later work on the same stream, so dropping the references here is safe.
     # col/perm keep >= 1 element so their base pointer is never null (E == 0 batches are legal)
@@ -519,13 +607,14 @@ def edge_linear(x: torch.Tensor, adjacency_lists, weights: Sequence[torch.Tensor
             raise _lib.PtgnnAmdError("edge_linear: dropout supports the GGNN form only (no target half, no act)")
         with _timed("edge_linear", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
             rc = lib.ptgnn_amd_edge_linear_dropout_f32(
-                x.data_ptr(), _ld(x), H, ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(cn, ctypes.c_void_p),
+                x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),
+                ctypes.cast(cn, ctypes.c_void_p),
                 ctypes.cast(wp, ctypes.c_void_p), T, M, msg.data_ptr(), M, int(dropout[0]),
                 float(dropout[1]), int(dropout[2]) & 0xFFFFFFFFFFFFFFFF, _stream(msg))
         _lib.check(rc, "ptgnn_amd_edge_linear_dropout_f32")
         return msg[:E] if E > 0 else msg[:0]
     with _timed("edge_linear", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
-        rc = lib.ptgnn_amd_edge_linear_f32(x.data_ptr(), _ld(x), H, ctypes.cast(sp, ctypes.c_void_p),
+        rc = lib.ptgnn_amd_edge_linear_f32(x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),
                                            ctypes.cast(dp, ctypes.c_void_p) if use_dst else None,
                                            ctypes.cast(cn, ctypes.c_void_p),
                                            ctypes.cast(wp, ctypes.c_void_p), T, M, ACT_IDS[act],
@@ -559,7 +648,7 @@ def edge_weight_grad(x: torch.Tensor, adjacency_lists, grad_msg: torch.Tensor, u
     gm_ptr = grad_msg.data_ptr() if E > 0 else x.data_ptr()
     with _timed("edge_weight_grad", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
         rc = lib.ptgnn_amd_edge_weight_grad_f32(
-            x.data_ptr(), _ld(x), H, ctypes.cast(sp, ctypes.c_void_p),
+            x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),
             ctypes.cast(dp, ctypes.c_void_p) if use_dst else None, ctypes.cast(cn, ctypes.c_void_p),
             gm_ptr, _ld(grad_msg) if E > 0 else M, T, M, float(dropout_p),
             int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, grad_w.data_ptr(), ws.data_ptr(), ws_bytes, _stream(grad_w))

@@ -7,6 +7,7 @@ The pooling is the same segment reduce as message aggregation with `node_to_grap
 A disjoint-union batch lists the nodes of graph 0, then graph 1, ... (graphneuralnetwork.py:418-423),
 so the index is SORTED and the plan needs no sort at all: rowptr = searchsorted, col = identity.
 """
+import weakref
 from typing import NamedTuple, Union
 
 import torch
@@ -29,10 +30,40 @@ class AbstractVarSizedElementReduce(nn.Module):
         raise NotImplementedError
 
 
+# (weakref(index), version, is_sorted, upper) of the most recent index tensors: the sortedness test costs
+# one host read-back, so it is made once per index tensor (= once per minibatch), not once per layer.
+_INDEX_INFO = []
+
+
+def _index_info(index: torch.Tensor):
+    """(is_sorted, max + 1) of an element -> sample map.  The reference's reducers are plain
+    torch_scatter calls (varsizedsummary.py:35-41,76-81) and accept ANY map; only a non-decreasing one
+    (`node_to_graph_idx` of a disjoint-union batch, graphneuralnetwork.py:418-423,440-443) may take the
+    sort-free plan."""
+    for ref, ver, srt, upper in _INDEX_INFO:
+        if ref() is index and ver == index._version:
+            return srt, upper
+    if index.numel() == 0:
+        srt, upper = True, 0
+    else:
+        unsorted, last = torch.stack([(index[1:] < index[:-1]).any().to(torch.int64), index[-1]]).tolist()
+        srt = not unsorted
+        upper = int(last) + 1 if srt else int(index.max()) + 1
+    _INDEX_INFO.insert(0, (weakref.ref(index), index._version, srt, upper))
+    del _INDEX_INFO[4:]
+    return srt, upper
+
+
+def _index_plan(index: torch.Tensor, num_samples: int) -> "ops.GraphPlan":
+    if _index_info(index)[0]:
+        return ops.plan_from_sorted_index(index, int(num_samples))
+    return ops.build_plan([(index, index)], int(num_samples))      # arbitrary map: one stable sort
+
+
 def _pool(values: torch.Tensor, index: torch.Tensor, num_samples, reduce: str) -> torch.Tensor:
     if not values.is_cuda:
         raise _lib.PtgnnAmdError("ptgnn_amd reduce ops run on the MI355X only")
-    plan = ops.plan_from_sorted_index(index, int(num_samples))
+    plan = _index_plan(index, int(num_samples))
     dt = values.dtype
     return segment_reduce(values.to(torch.float32).contiguous(), plan, reduce).to(dt)
 
@@ -74,9 +105,9 @@ class AbstractGlobalGraphExchange(AbstractMessagePassingLayer):
     def forward(self, node_states, adjacency_lists, node_to_graph_idx, reference_node_ids,
                 reference_node_graph_idx, edge_features) -> torch.Tensor:
         _check_device(node_states)
-        # the batch is a disjoint union in graph order => the last node belongs to the last graph
-        # (the reference's `node_to_graph_idx.max() + 1` is the same host read-back)
-        num_graphs = int(node_to_graph_idx[-1]) + 1 if node_to_graph_idx.numel() else 0
+        # the reference's `node_to_graph_idx.max() + 1` (globalgraphexchange.py:40) is a host read-back;
+        # the same read-back here also tells whether the map is sorted (disjoint-union batches are)
+        num_graphs = _index_info(node_to_graph_idx)[1]
         e = ElementsToSummaryRepresentationInput(node_states, node_to_graph_idx, num_graphs)
         graph_reps = self.__dropout(self.__global_graph_representation_module(e))
         if graph_reps.dtype != torch.float32:
@@ -84,7 +115,7 @@ class AbstractGlobalGraphExchange(AbstractMessagePassingLayer):
         elif _no_grad_needed(graph_reps):
             per_node = ops.gather_rows(graph_reps.contiguous(), node_to_graph_idx)
         else:   # training: HIP row gather whose backward is the HIP segment-sum over the graphs (deterministic)
-            plan = ops.plan_from_sorted_index(node_to_graph_idx, num_graphs)
+            plan = _index_plan(node_to_graph_idx, num_graphs)
             per_node = gather_rows_autograd(graph_reps.contiguous(), node_to_graph_idx, plan)
         return self._update_node_states(node_states, per_node)
 

@@ -200,7 +200,7 @@ class _HaloExchange(torch.autograd.Function):
         sh = ctx.shard
         g = g.contiguous()
         d_own = g[: sh.n_local]
-        if sh.n_halo == 0 and sum(sh.send_splits) == 0:
+        if sh.no_cut:   # agreed on by every rank at build time: nobody enters the collective
             return d_own, None
         back = torch.empty(sum(sh.send_splits), g.shape[1], dtype=g.dtype, device=g.device)
         dist.all_to_all_single(back, g[sh.n_local:].contiguous(), sh.send_splits, sh.recv_splits,

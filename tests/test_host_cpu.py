@@ -184,18 +184,48 @@ def test_forward_scope_shares_derived_tensors_only_inside_a_scope():
     def make():
         calls.append(1)
         return torch.zeros(2, requires_grad=True)
-    a, b = L._scoped("k", make), L._scoped("k", make)
+    owner = object()
+    a, b = L._scoped(owner, "k", make), L._scoped(owner, "k", make)
     assert a is not b and len(calls) == 2                      # no scope: nothing is kept
     with L.forward_scope():
-        c, d = L._scoped("k", make), L._scoped("k", make)
+        c, d = L._scoped(owner, "k", make), L._scoped(owner, "k", make)
         assert c is d and len(calls) == 3
+        assert L._scoped(object(), "k", make) is not c         # keyed on the owning module object
         with L.forward_scope():                                # nested scopes share the outer cache
-            assert L._scoped("k", make) is c
+            assert L._scoped(owner, "k", make) is c
         with torch.no_grad():
-            assert L._scoped("k", make) is not c               # inference never caches autograd tensors
-    assert L._FORWARD_SCOPE is None
+            assert L._scoped(owner, "k", make) is not c        # inference never caches autograd tensors
+    assert getattr(L._SCOPE, "cache", None) is None
     with L.forward_scope():
-        assert L._scoped("k", make) is not c                   # a new forward builds its own
+        assert L._scoped(owner, "k", make) is not c            # a new forward builds its own
+
+
+def test_forward_scope_is_per_thread():
+    """Two threads (e.g. nn.DataParallel replicas) interleaving their forward scopes never see each other's
+    cache and never leave one behind."""
+    import threading
+    import torch
+    from ptgnn_amd import layers as L
+    owner, seen = object(), {}
+    enter_a, enter_b, exit_a = threading.Event(), threading.Event(), threading.Event()
+
+    def worker_a():
+        with L.forward_scope():
+            seen["a"] = L._scoped(owner, "k", lambda: torch.zeros(1, requires_grad=True))
+            enter_a.set(); enter_b.wait(5)
+        exit_a.set()
+
+    def worker_b():
+        enter_a.wait(5)
+        with L.forward_scope():
+            enter_b.set(); exit_a.wait(5)
+            seen["b"] = L._scoped(owner, "k", lambda: torch.ones(1, requires_grad=True))
+        seen["b_after"] = getattr(L._SCOPE, "cache", None)
+
+    ta, tb = threading.Thread(target=worker_a), threading.Thread(target=worker_b)
+    ta.start(); tb.start(); ta.join(10); tb.join(10)
+    assert seen["a"] is not seen["b"] and float(seen["b"]) == 1.0 and seen["b_after"] is None
+    assert getattr(L._SCOPE, "cache", None) is None
 
 
 def test_training_path_selection_rules():
