@@ -12,8 +12,11 @@ Primary workload: the batch BASELINE.json quotes its metric on -- the Graph2Clas
 configs[2] (48 graphs, ~116k nodes, 8 raw -> 17 edge types, Typilus GGNN stack: 8 GGNN layers,
 hidden 128, max aggregation, fp32, forward).  `value` = E / t_layer (edges per second per message-passing
 layer, E counted after reverse + self augmentation).  At N=1 the same run also reports configs[1]
-(synthetic 200k-node / 1.1M-edge graph, one MLP-MP layer) under "config2", the training step of the
-Graph2Class stack under "graph2class_train", and the CPU restatement under "cpu_baseline".
+(synthetic 200k-node / 1.1M-edge graph, one MLP-MP layer) under "config2", the per-GPU shard of configs[4]
+(power-law, 1.25M nodes / 12.5M edges, H=256) under "config5_shard", the same primary workload in the opt-in
+"f32 via 3xbf16 split" GEMM mode under "split_bf16", the training step of the Graph2Class stack under
+"graph2class_train", and the CPU restatement under "cpu_baseline".  The GPU output of the primary workload and
+of config 2 is compared with the CPU oracle's at FULL size ("parity"); a miss fails the run (exit code 3).
 
 N>1: the path partitions over whole graphs (a minibatch is a disjoint union; the reference's own
 multi-GPU mode hands whole graphs to ranks), so every rank runs the single-GPU step on ITS OWN
@@ -45,6 +48,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--gemm", default=None, choices=["tile", "stream", "split"],
+                   help="kernel family / arithmetic of the dense blocks for the PRIMARY line (default: stream = exact fp32)")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--force-sharded", action="store_true",
                    help="run the dst-range-sharded code path (process group, halo all-to-all) even at N=1")
@@ -313,69 +318,174 @@ def kernel_table(summary):
     return table
 
 
-PMC_KERNEL = {"linear": "k_linear_tlp", "gather_reduce": "k_gather_reduce", "gru_cell": "k_gru",
-              "edge_linear": "k_edge_linear"}
+# bench kernel bracket -> device kernel names it may resolve to (streaming core first, round-1 tile kernels second)
+PMC_KERNEL = {"linear": ("k_stream_linear", "k_linear_tlp"), "gather_reduce": ("k_gather_reduce",),
+              "gru_cell": ("k_stream_gru", "k_gru"), "edge_linear": ("k_stream_edge", "k_edge_linear")}
 
 
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r01_<workload>_traffic.json, written by scripts/gpu_profile.sh + summarize_prof.py:
-    FETCH_SIZE x2 wide-read correction + WRITE_SIZE, separate --pmc runs).  PMC counters cannot be read
-    from inside a plain bench run, so the figure is the profiled one and names its source; null when the
-    profile is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_{workload}_traffic.json")
-    try:
-        with open(path) as f:
-            prof = json.load(f)
-        row = prof["kernels"][PMC_KERNEL[kernel]]
-    except (OSError, KeyError, ValueError):
-        return {"traffic": None}
-    return {"traffic": row["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
-            "traffic_source": f"profiles/r01_{workload}_traffic.json ({prof['source']})"}
+    (profiles/r0N_<workload>_traffic.json, written by scripts/gpu_profile.sh + summarize_prof.py:
+    FETCH_SIZE x2 wide-read correction + WRITE_SIZE, separate --pmc runs; newest round first).  PMC counters
+    cannot be read from inside a plain bench run, so the figure is the profiled one and names its source; null
+    when no profile holds the kernel."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for rnd in ("r02", "r01"):
+        path = os.path.join(root, f"{rnd}_{workload}_traffic.json")
+        try:
+            with open(path) as f:
+                prof = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for name in PMC_KERNEL.get(kernel, ()):
+            row = prof.get("kernels", {}).get(name)
+            if row:
+                return {"traffic": row["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch", "traffic_kernel": name,
+                        "traffic_source": f"profiles/{rnd}_{workload}_traffic.json ({prof['source']})"}
+    return {"traffic": None}
 
 
-def cpu_baseline_cfg2(st):
-    """The CPU restatement of the reference path (oracle = 'port') on this box's host cores, on the
-    SAME config-2 inputs: 1 warm-up + 3 timed forwards of the MLP-MP layer."""
+PARITY_TOL = 1e-5   # BASELINE.json north_star: fp32 node states within 1e-5 of the reference CPU path
+
+
+def _timed_forwards(fn, n_timed=3):
+    """1 warm-up + n timed forwards, median (SURVEY.md 8d / BASELINE.md 3)."""
+    fn()
+    ts = []
+    for _ in range(n_timed):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], out
+
+
+def _thread_counts():
+    allc = os.cpu_count() or 1
+    return sorted({c for c in (1, 8, 32, allc) if c <= allc})
+
+
+def cpu_baseline_cfg2(st, gpu_out):
+    """The CPU restatement of the reference path (kind "port": the reference's own modules live in
+    /root/reference, which does not exist on the GPU box) on this box's host cores, on the SAME config-2 inputs:
+    thread sweep {1, 8, 32, all}, 1 warm-up + 3 timed forwards each, median; parity of the GPU output against
+    the oracle output at full size."""
     from oracle import mp_oracle as O
     spec = st["layer"].export_weights()
     x, adj = st["cpu_x"], st["cpu_adj"]
     feats = [torch.empty(st["E"], 0)]
+    sweep, want = {}, None
     with torch.no_grad():
-        O.mlp_mp_layer(x, adj, feats, spec)
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            O.mlp_mp_layer(x, adj, feats, spec)
-            ts.append(time.perf_counter() - t0)
-    ts.sort()
-    med = ts[1]
-    return {"value": round(st["E"] / med, 1), "unit": "edges/s", "cores": torch.get_num_threads(),
-            "kind": "port", "host_cpus": os.cpu_count(),
-            "sample": f"cfg2 full size (N=200k, E=1.1M), 1 MLP-MP layer forward, median of 3 = {med:.3f}s, "
-                      "torch-CPU fp32 restatement of the reference layer (oracle/mp_oracle.py)"}
+        for c in _thread_counts():
+            torch.set_num_threads(c)
+            med, want = _timed_forwards(lambda: O.mlp_mp_layer(x, adj, feats, spec))
+            sweep[str(c)] = round(med, 4)
+    best = min(sweep, key=lambda k: sweep[k])
+    parity = {"max_abs": float((gpu_out.cpu() - want).abs().max()), "tol": PARITY_TOL, "n": st["N"],
+              "against": "oracle/mp_oracle.py at full size (N=200k, E=1.1M)"}
+    return {"value": round(st["E"] / sweep[best], 1), "unit": "edges/s", "cores": int(best), "kind": "port",
+            "host_cpus": os.cpu_count(), "seconds_by_threads": sweep,
+            "value_1_thread": round(st["E"] / sweep["1"], 1),
+            "sample": "cfg2 full size (N=200k, E=1.1M), 1 MLP-MP layer forward; per thread count 1 warm-up + 3 timed, "
+                      "median; best thread count reported in `cores`. torch-CPU fp32 restatement of the reference "
+                      "layer (oracle/mp_oracle.py): the reference's own modules cannot be imported on the GPU box "
+                      "(no /root/reference there); their timing in the authoring container is in BASELINE.md"}, parity
 
 
-def cpu_baseline_cfg3(st):
-    """The CPU restatement of the reference path (oracle = 'port') on this box's host cores over the SAME
-    Graph2Class batch and weights: one untimed + up to two timed 8-layer forwards (bounded to ~30 s)."""
+def cpu_baseline_cfg3(st, gpu_out):
+    """CPU restatement (kind "port") of the 8-layer GGNN stack on this box's host cores.
+    Thread sweep on a BOUNDED sample (the first 8 of the 48 graphs, same weights: 1 warm-up + 3 timed forwards per
+    thread count, median), then ONE forward of the full batch at the best thread count -- timed, and kept as the
+    full-size parity reference for the GPU output."""
     from oracle import mp_oracle as O
-    ts = []
+    from ptgnn_amd import workloads
+    small = workloads.batched_graphs(8, 2500, 8, 2.2, seed=1234)
+    xs = workloads.node_states(small["num_nodes"], st["H"], seed=5)
+    e_small = 2 * sum(int(a[0].shape[0]) for a in small["adjacency_lists"]) + small["num_nodes"]
+    sweep = {}
     with torch.no_grad():
+        for c in _thread_counts():
+            torch.set_num_threads(c)
+            med, _ = _timed_forwards(lambda: O.gnn_forward(xs, small["adjacency_lists"], st["specs"], True, True))
+            sweep[str(c)] = round(med, 4)
+        best = min(sweep, key=lambda k: sweep[k])
+        torch.set_num_threads(int(best))
         t0 = time.perf_counter()
-        O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True)
-        first = time.perf_counter() - t0
-        for _ in range(2 if first < 10.0 else 1):
-            t0 = time.perf_counter()
-            O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True)
-            ts.append(time.perf_counter() - t0)
-    best = min(ts)
+        want, n_edges = O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True)
+        full = time.perf_counter() - t0
     layers = st["layers_per_step"]
-    return {"value": round(st["E"] / (best / layers), 1), "unit": "edges/s", "cores": torch.get_num_threads(),
-            "kind": "port", "host_cpus": os.cpu_count(),
-            "sample": f"the full Graph2Class batch (N={st['N']}, E={st['E']}), {layers}-layer GGNN stack forward, "
-                      f"1 untimed + {len(ts)} timed, best = {best:.3f}s; torch-CPU fp32 restatement of the "
-                      "reference layers (oracle/mp_oracle.py)"}
+    parity = {"max_abs": float((gpu_out.cpu() - want).abs().max()), "tol": PARITY_TOL, "n": st["N"],
+              "edges_counted_match": bool(n_edges == st["E"]),
+              "against": f"oracle/mp_oracle.py at full size (N={st['N']}, E={st['E']}, 8 GGNN layers)"}
+    return {"value": round(e_small / (sweep[best] / layers), 1), "unit": "edges/s", "cores": int(best),
+            "kind": "port", "host_cpus": os.cpu_count(), "seconds_by_threads": sweep,
+            "value_1_thread": round(e_small / (sweep["1"] / layers), 1),
+            "full_batch_seconds": round(full, 3), "full_batch_value": round(st["E"] / (full / layers), 1),
+            "sample": f"thread sweep on the first 8 of the 48 graphs (N={small['num_nodes']}, E={e_small}), {layers}-layer "
+                      "GGNN stack forward, per thread count 1 warm-up + 3 timed, median; `value` = E / t_layer at the "
+                      "best thread count (`cores`); plus one forward of the FULL batch at that thread count "
+                      "(`full_batch_*`, also the parity reference). torch-CPU fp32 restatement of the reference layers "
+                      "(oracle/mp_oracle.py): the reference's own modules cannot be imported on the GPU box (no "
+                      "/root/reference there); their timing in the authoring container is in BASELINE.md"}, parity
+
+
+def repeat_stats(step_fn, steps, blocks=5):
+    """min / median ms per step over repeated K-step blocks (robust to DVFS and first-touch effects); the
+    contract's `ms_per_step` stays the single timed region."""
+    per = []
+    for _ in range(blocks):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t0) / steps * 1e3)
+    per.sort()
+    return {"blocks": blocks, "steps_per_block": steps, "ms_per_step_min": round(per[0], 4),
+            "ms_per_step_median": round(per[len(per) // 2], 4), "ms_per_step_max": round(per[-1], 4)}
+
+
+def config5_shard(dev):
+    """configs[4] at its per-GPU size (an 8-way dst-range shard of N=10M / E=100M: 1.25M rows, 12.5M in-edges with
+    Zipf-0.8 destinations, H=256): the only BASELINE shape whose node table (1.28 GB) exceeds the 256 MiB
+    Infinity Cache.  One GGNN layer (sum) through the layer API + the aggregation kernel on its own."""
+    from ptgnn_amd import layers as L, ops, workloads
+    N, E, H = 1_250_000, 12_500_000, 256
+    adj = workloads.power_law_graph(N, E, alpha=0.8, seed=1234)
+    cadj = [(adj[0][0].to(dev), adj[0][1].to(dev))]
+    x = workloads.node_states(N, H, seed=2).to(dev)
+    torch.manual_seed(5)
+    layer = L.GatedMessagePassingLayer(H, H, 1, "sum").to(dev).eval()
+
+    def step():
+        ops.clear_plan_cache()
+        with torch.no_grad():
+            return layer(x, cadj, None, {}, {}, [None])
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = 5
+    for _ in range(k):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    plan = ops.plan_for(cadj, N)
+    y = torch.randn(N, H, device=dev)
+    evs = []
+    for _ in range(7):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record(); ops.gather_reduce(y, plan, H, "sum"); e_.record()
+        evs.append((s_, e_))
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
+    nbytes = E * (4.0 * H + 4) + N * (4.0 * H + 4)
+    return {"workload": "cfg5 per-GPU shard: power-law (Zipf 0.8 destinations) N=1.25M E=12.5M, 1 GGNN layer H=M=256, sum",
+            "ms_per_layer_step": round(dt * 1e3, 3), "edges_per_sec_per_layer": round(E / dt, 1),
+            "nodes_per_sec_per_layer": round(N / dt, 1),
+            "gather_reduce": {"avg_ms": round(ms, 4), "algorithmic_bytes_per_launch": round(nbytes),
+                              "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "bound": "hbm"}}
 
 
 def main():
@@ -383,8 +493,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     rank, world, dev = dist_setup(args)
-    from ptgnn_amd import _lib
+    from ptgnn_amd import _lib, ops
     _lib.load()
+    ops.set_gemm_mode(args.gemm or "stream")
+    gemm_names = {0: "f32 (exact fp32 MFMA, 128x128 tile kernels)", 1: "f32 (exact fp32 MFMA, streaming kernels)",
+                  2: "f32 via 3xbf16 split (bf16 MFMA, fp32 accumulate)"}
 
     if args.workload == "cfg2":
         st = make_cfg2(dev, rank, world, args.force_sharded or args.global_ids, args.cut_edges)
@@ -412,7 +525,8 @@ def main():
         "metric": "edges/sec per MP layer", "value": round(value, 1), "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if ops.get_gemm_mode() != 2 else "f32 via 3xbf16 split",
+        "data": "synthetic", "gemm_mode": gemm_names[ops.get_gemm_mode()],
         "config": {"workload": st["desc"], "nodes_per_gpu": st["N"], "edges_per_gpu": st["E"],
                    "hidden": st["H"], "mp_layers_per_step": layers, "mode": "forward (inference), fp32",
                    "plan_build_in_step": True,
@@ -425,6 +539,7 @@ def main():
         "edges_per_sec_readme_convention": round(edges_all_ranks / (seconds / args.steps), 1),
         "roofline": roof, "kernels": ktab,
     }
+    exit_code = 0
     if args.workload == "cfg3":
         result["vs_readme_v100_inference_2527k"] = round(result["edges_per_sec_readme_convention"] / world / 2.527e6, 2)
 
@@ -443,6 +558,7 @@ def main():
                 result[key] = {"error": f"{type(exc).__name__}: {exc}"}
                 break              # ranks may have diverged: do not enter another collective section
     if rank == 0 and world == 1 and not args.force_sharded:
+        result["repeats"] = repeat_stats(step, args.steps)
         if not args.no_secondary:
             if args.workload == "cfg3":    # configs[1]: the synthetic 200k / 1.1M graph, one MLP-MP layer
                 st2 = make_cfg2(dev, 0, 1)
@@ -453,7 +569,23 @@ def main():
                     "workload": st2["desc"], "ms_per_step": round(sec2 / k2 * 1e3, 4),
                     "edges_per_sec_per_layer": round(st2["E"] / (sec2 / k2), 1),
                     "nodes_per_sec_per_layer": round(st2["N"] / (sec2 / k2), 1), "kernels": kt2}
+                if not args.no_cpu_baseline:   # full-size parity of config 2 (~2 s of oracle per forward)
+                    from oracle import mp_oracle as O
+                    with torch.no_grad():
+                        want2 = O.mlp_mp_layer(st2["cpu_x"], st2["cpu_adj"], [torch.empty(st2["E"], 0)],
+                                               st2["layer"].export_weights())
+                    err2 = float((step_cfg2(st2, 1).cpu() - want2).abs().max())
+                    result["config2"]["parity"] = {"max_abs": err2, "tol": PARITY_TOL, "n": st2["N"],
+                                                   "against": "oracle/mp_oracle.py at full size"}
+                    if not err2 <= PARITY_TOL:
+                        exit_code = 3
+                    del want2
                 del st2
+                try:
+                    result["config5_shard"] = config5_shard(dev)
+                except Exception as exc:  # noqa: BLE001  (secondary numbers must never cost the primary line)
+                    result["config5_shard"] = {"error": f"{type(exc).__name__}: {exc}"}
+                torch.cuda.empty_cache()
             else:
                 st3 = make_cfg3(dev)
                 k3 = max(10, args.steps // 2)
@@ -473,7 +605,35 @@ def main():
             result["readme_default_arch"] = train_cfg3(dev, 0.1, arch="mlp", H=64, forward_too=True)
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_cfg2(st) if args.workload == "cfg2" else cpu_baseline_cfg3(st)
+            with torch.no_grad():
+                gpu_out = step()
+            gpu_out = gpu_out.output_node_representations if args.workload == "cfg3" else gpu_out
+            base, parity = (cpu_baseline_cfg2 if args.workload == "cfg2" else cpu_baseline_cfg3)(st, gpu_out)
+            result["cpu_baseline"], result["parity"] = base, parity
+            if not parity["max_abs"] <= PARITY_TOL:
+                exit_code = 3
+            if args.workload == "cfg3" and not args.no_secondary and ops.get_gemm_mode() != 2:
+                # the same primary workload in the opt-in split-precision GEMM mode, with its own parity
+                from oracle import mp_oracle as O
+                prev = ops.set_gemm_mode("split")
+                try:
+                    sec_s, sum_s = timed_region(step, args.steps, args.warmup, 1, dev)
+                    kt_s = kernel_table(sum_s)
+                    with torch.no_grad():
+                        out_s = step().output_node_representations.cpu()
+                        want = O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True)[0]
+                    err_s = float((out_s - want).abs().max())
+                    result["split_bf16"] = {
+                        "dtype": "f32 via 3xbf16 split", "gemm_mode": gemm_names[2],
+                        "ms_per_step": round(sec_s / args.steps * 1e3, 4),
+                        "value": round(st["E"] / (sec_s / args.steps / layers), 1), "unit": "edges/s",
+                        "speedup_vs_primary": round(ms_per_step / (sec_s / args.steps * 1e3), 3),
+                        "parity": {"max_abs": err_s, "tol": PARITY_TOL, "n": st["N"]},
+                        "kernels": {k: {kk: v[kk] for kk in ("calls", "avg_ms", "achieved", "unit")} for k, v in kt_s.items()}}
+                except Exception as exc:  # noqa: BLE001
+                    result["split_bf16"] = {"error": f"{type(exc).__name__}: {exc}"}
+                finally:
+                    ops.set_gemm_mode(prev)
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
         dist.barrier()
@@ -488,6 +648,9 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
+    if exit_code:
+        sys.stderr.write("bench.py: GPU output is outside the parity tolerance of the CPU oracle (see \"parity\")\n")
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

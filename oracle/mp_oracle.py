@@ -164,7 +164,7 @@ def augment_adjacency(adjacency_lists: Adj, num_nodes: int, introduce_backwards_
 
 
 def run_layer_stack(node_states, adjacency_lists: Adj, layers: Sequence[Dict], edge_features=None,
-                    node_to_graph_idx=None):
+                    node_to_graph_idx=None, trace: Optional[List] = None):
     """GraphNeuralNetwork.gnn, graphneuralnetwork.py:121-131 (+ residual layers,
     residuallayers.py:8-96).  `layers` is a list of specs {"kind": ..., ...}; a tied layer is
     the same dict repeated."""
@@ -175,6 +175,7 @@ def run_layer_stack(node_states, adjacency_lists: Adj, layers: Sequence[Dict], e
     x = node_states
     for spec in layers:
         kind = spec["kind"]
+        x_in = x
         if kind == "ggnn":
             x = ggnn_layer(x, adjacency_lists, edge_features, spec)
         elif kind == "mlp":
@@ -191,17 +192,28 @@ def run_layer_stack(node_states, adjacency_lists: Adj, layers: Sequence[Dict], e
             x = linear(torch.cat((stash.pop(spec["name"]), x), dim=-1), spec["w"])
         else:
             raise ValueError(kind)
+        if trace is not None:     # (layer input, layer output) per module: per-layer parity checks and
+            trace.append((x_in, x))   # `return_all_states` (graphneuralnetwork.py:132-133)
     return x
 
 
 def gnn_forward(initial_node_representations, adjacency_lists: Adj, layers: Sequence[Dict],
-                introduce_backwards_edges: bool, add_self_edges: bool, node_to_graph_idx=None):
+                introduce_backwards_edges: bool, add_self_edges: bool, node_to_graph_idx=None,
+                trace: Optional[List] = None, edge_features=None):
     """GraphNeuralNetwork.forward minus the embedder, graphneuralnetwork.py:160-209.
     Returns (output_node_representations, num_edges_counted) where the edge count follows
     :198 (edges after augmentation)."""
     n = initial_node_representations.shape[0]
     adj = augment_adjacency(adjacency_lists, n, introduce_backwards_edges, add_self_edges)
-    out = run_layer_stack(initial_node_representations, adj, layers, node_to_graph_idx=node_to_graph_idx)
+    if edge_features is not None:   # graphneuralnetwork.py:174,183: reverse edges reuse the forward
+        feats = list(edge_features)  # features, self edges get zeros of the same width
+        if introduce_backwards_edges:
+            feats = feats + [f for f in feats]
+        if add_self_edges:
+            feats.append(torch.zeros(n, feats[-1].shape[-1], dtype=feats[-1].dtype))
+        edge_features = feats
+    out = run_layer_stack(initial_node_representations, adj, layers, edge_features=edge_features,
+                          node_to_graph_idx=node_to_graph_idx, trace=trace)
     return out, sum(int(a[0].shape[0]) for a in adj)
 
 

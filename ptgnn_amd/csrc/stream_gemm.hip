@@ -37,6 +37,9 @@
 //      does not take (K % 64 != 0, unaligned rows, slabs that do not fit LDS).
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "dense_common.h"
 #include "stream_gemm.h"
 
@@ -270,16 +273,6 @@ __device__ __forceinline__ int claim_unit(int *counter) {
   return __builtin_amdgcn_readfirstlane(v);
 }
 
-// De-phase the two waves that share a SIMD (waves w and w + 4 of an 8-wave workgroup).  Started together
-// they stay in lockstep for the whole run -- both in their K loops (sharing the matrix pipe), then both in
-// their epilogue + queue drain (pipe idle): measured 62 % MFMA-busy with 75 % of the wave cycles waiting to
-// issue.  An initial offset of about one solo K loop is self-preserving and puts one
-// wave's epilogue under the other's MFMAs.
-__device__ __forceinline__ void dephase(int wave, int ticks) {
-  if (wave >= 4)
-    for (int i = 0; i < ticks; ++i) __builtin_amdgcn_s_sleep(32);   // 32 * 64 = 2048 clocks per tick
-}
-
 // ---------------------------------------------------------------------------------------------------
 // linear: y = act(x W^T + b)
 // ---------------------------------------------------------------------------------------------------
@@ -288,7 +281,7 @@ struct LinearArgs {
   const float *w; int n_out; const float *bias; int act;
   float *y; int64_t ld_y;
   int nrb, ncs, rps, run_len;
-  int lds_floats, dephase;   // slab size in floats (the unit counter sits behind it); de-phase ticks
+  int lds_floats;            // slab size in floats (the unit counter sits behind it)
 };
 
 template <int ACT>
@@ -342,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int nch = p.K >> 5;
   const int lofs = lane_piece_offset<SPLIT>(hi);
@@ -354,7 +347,6 @@ __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
   int cur = claim_unit(counter);
   if (cur >= count) return;
   int nxt = claim_unit(counter);
-  dephase(wave, p.dephase);
   ARows rows;
   rows.c0 = rows.c1 = rowp(cur);
   rows.n0 = rows.n1 = rowp(nxt);
@@ -398,7 +390,7 @@ struct GruArgs {
   int64_t n; int M, H;
   float *out; int64_t ld_out; float *gates;
   int nrb, ncs, rps, run_len;
-  int lds_floats, dephase;
+  int lds_floats;
 };
 
 // sigmoid / tanh on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each): absolute error
@@ -447,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int ch0 = p.M >> 5, nch = K >> 5;
   const int lofs = lane_piece_offset<SPLIT>(hi);
@@ -458,7 +450,6 @@ __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
   int cur = claim_unit(counter);
   if (cur >= count) return;
   int nxt = claim_unit(counter);
-  dephase(wave, p.dephase);
   ARows rows;
   {
     const int64_t r0 = clampr(cur), r1 = clampr(nxt);
@@ -539,7 +530,7 @@ struct EdgeArgs {
   const float *x; int64_t ld_x; int H; int use_dst; int M; int act;
   float *msg; int64_t ld_msg; int64_t msg_row_base;
   int64_t num_rows;          // rows of x (gathered ids are clamped into it)
-  int run_len, lds_floats, dephase;
+  int run_len, lds_floats;
 };
 
 template <int NB, bool SPLIT>
@@ -553,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge(EdgeArgs p) {
   const int K = p.use_dst ? 2 * p.H : p.H;
   const Slab<SPLIT> sl(K, BN);
   int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int ch0 = p.H >> 5, nch = K >> 5;
   const int lofs = lane_piece_offset<SPLIT>(hi);
@@ -589,8 +580,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge(EdgeArgs p) {
     if (cur < count) {
       int nxt = claim_unit(counter);
       int nn = claim_unit(counter);   // the node ids of a unit are fetched two units ahead of its rows
-      dephase(wave, p.dephase);
-      auto edge_of = [&](int unit) {
+          auto edge_of = [&](int unit) {
         const int64_t e = (int64_t)(ub + (unit < count ? unit : count - 1)) * 32 + li;
         return e < n_edges ? e : n_edges - 1;
       };
@@ -647,23 +637,24 @@ bool debug_on() {
   return v == 1;
 }
 
+// Raise a kernel's dynamic-LDS limit once per (kernel, size): the attribute call is not legal while a
+// stream is being captured into a hipGraph, and the warm-up launch outside the capture has made it.
 template <typename Kern>
 bool set_lds(Kern kern, size_t bytes) {
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  static std::mutex mu;
+  static std::unordered_map<const void *, size_t> done;
+  const void *key = reinterpret_cast<const void *>(kern);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find(key);
+  if (it != done.end() && it->second >= bytes) return true;
+  const hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     if (debug_on()) fprintf(stderr, "[ptgnn_amd] stream kernel: %zu B of LDS refused (%s) -> tile kernel\n", bytes, hipGetErrorString(e));
+    return false;
   }
-  return e == hipSuccess;
-}
-
-// de-phase offset ~ one solo K loop of a unit, in ticks of 2048 clocks
-int dephase_ticks(int nch, int nblk, bool split) {
-  const int64_t clk = split ? (int64_t)nch * nblk * 2 * 6 * 32 : (int64_t)nch * nblk * 16 * 64;
-  int t = (int)((clk + 1024) / 2048);
-  if (const char *e = getenv("PTGNN_AMD_DEPHASE")) t = atoi(e);   // developer A/B knob (0 = off)
-  return t < 0 ? 0 : (t > 64 ? 64 : t);
+  done[key] = bytes;
+  return true;
 }
 
 // runs per slab for the dense kernels: one 8-wave workgroup per CU
@@ -707,6 +698,13 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   const int bn = n_out >= 128 ? 128 : n_out;
   const int nb = bn / 32;
   bool split = mode == 2;
+  {
+    // measured (profiles/r02_notes.md): the persistent kernel pays one slab copy per workgroup and re-reads
+    // A once per column slab, so in exact fp32 it only beats the tile kernel with >= 3 units per wave and
+    // few slabs; the split mode has no tile counterpart and always streams
+    const int64_t units = (rows + 31) / 32 * ((n_out + bn - 1) / bn);
+    if (!split && (units < (int64_t)num_compute_units() * 8 * 3 || (n_out + bn - 1) / bn > 4)) return 0;
+  }
   size_t slab = split ? Slab<true>::bytes(k, bn) : Slab<false>::bytes(k, bn);
   if (split && slab + 16 > (size_t)kLdsBudget) {   // three bf16 planes do not fit: this shape stays exact fp32
     split = false;
@@ -721,7 +719,6 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   p.ncs = (n_out + bn - 1) / bn;
   dense_runs(p.nrb, p.ncs, p.rps, p.run_len);
   p.lds_floats = (int)(slab / 4);
-  p.dephase = dephase_ticks(k / 32, nb, split);
   const unsigned grid = (unsigned)(p.ncs * p.rps);
 #define PTGNN_K(NBV, SP)                                                            \
   do {                                                                              \
@@ -759,7 +756,6 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
   p.ncs = hd / 32;
   dense_runs(p.nrb, p.ncs, p.rps, p.run_len);
   p.lds_floats = (int)(slab / 4);
-  p.dephase = dephase_ticks(K / 32, 3, split);
   const unsigned grid = (unsigned)(p.ncs * p.rps);
 #define PTGNN_K(SP)                                      \
   do {                                                   \
@@ -782,7 +778,9 @@ static int edge_plan(int32_t state_dim, int32_t msg_dim, int use_dst, size_t *sl
     *slab_bytes = Slab<true>::bytes(K, msg_dim);
     return 2;
   }
-  if (Slab<false>::bytes(K, msg_dim) + 16 <= (size_t)kLdsBudget) {
+  // exact fp32: measured equal to the tile kernel at K = 128 and 3 % behind it at K = 256 (one 8-wave
+  // workgroup per CU re-loading a 133 KB slab per edge-type segment)
+  if (K <= 128 && Slab<false>::bytes(K, msg_dim) + 16 <= (size_t)kLdsBudget) {
     *slab_bytes = Slab<false>::bytes(K, msg_dim);
     return 1;
   }
@@ -801,7 +799,6 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   const int kind = edge_plan(state_dim, msg_dim, use_dst, &slab);
   if (kind == 0) return 0;
   const bool split = kind == 2;
-  const int K = use_dst ? 2 * state_dim : state_dim;
   const int nb = msg_dim / 32;
   const size_t lds = slab + 16;
   const int total = tab.unit_off[tab.num_types];
@@ -813,7 +810,6 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   p.run_len = (total + max_wg - 1) / max_wg;
   if (p.run_len < 8) p.run_len = 8;   // at least one unit per wave
   p.lds_floats = (int)(slab / 4);
-  p.dephase = dephase_ticks(K / 32, nb, split);
   const unsigned grid = (unsigned)((total + p.run_len - 1) / p.run_len);
 #define PTGNN_K(NBV, SP)                                      \
   do {                                                        \

@@ -332,9 +332,11 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
     dst_ptrs = PtrArr(*[d.data_ptr() if d.numel() else None for d in dsts])
     cnts = CntArr(*counts)
     bad = None
+    capturing = torch.cuda.is_current_stream_capturing()
     if VALIDATE_INDICES != "off":
         bad = _bad_state(dev)
-        check_indices(dev)          # surfaces an earlier minibatch's bad ids (never blocks)
+        if not capturing:
+            check_indices(dev)      # surfaces an earlier minibatch's bad ids (never blocks)
     # algorithmic bytes: read 16 B/edge (int64 src+dst), write 4 B/edge col (+4 perm) + rowptr
     with _timed("csr_build", bytes=E * (16 + 4 + (4 if want_perm else 0)) + 4.0 * (num_nodes + 1)):
         rc = lib.ptgnn_amd_csr_build(ctypes.cast(src_ptrs, ctypes.c_void_p),
@@ -350,9 +352,11 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
                                      ws.data_ptr(), ws_bytes, _stream(rowptr))
     _lib.check(rc, "ptgnn_amd_csr_build")
     if bad is not None:
-        if VALIDATE_INDICES == "sync":
+        if capturing:
+            pass                    # a captured plan build keeps counting; read-backs resume outside the graph
+        elif VALIDATE_INDICES == "sync":
             check_indices(dev, sync=True)
-        elif not torch.cuda.is_current_stream_capturing():
+        else:
             _post_plan_readback(bad)
     # `ws`, `srcs`, `dsts` are stream-ordered: torch's caching allocator only hands their memory to
     # later work on the same stream, so dropping the references here is safe.

@@ -1204,3 +1204,294 @@ def test_training_gradients_match_reference_golden(name, path, monkeypatch):
                                        err_msg=key)
             checked += 1
     assert checked >= 8
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: the benchmarked configs at the size they are benchmarked, per-layer bars, container branches
+# ------------------------------------------------------------------------------------------------
+def _typilus_ggnn_stack(H, T, seed):
+    from ptgnn_amd import layers as L
+    torch.manual_seed(seed)
+    ggnn = L.GatedMessagePassingLayer(H, H, T, "max")
+    r1 = L.ConcatResidualLayer(H)
+    last = L.GatedMessagePassingLayer(2 * H, H, T, "max")
+    mods = [r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last]
+    specs = ([{"kind": "residual_origin", "name": "r1"}] + [ggnn.export_weights()] * 7
+             + [{"kind": "residual_concat", "name": "r1"}, last.export_weights()])
+    return mods, specs
+
+
+def _run_container(net, x, mb, **kw):
+    return net(node_data={"input": x.cuda()}, adjacency_lists=to_cuda_adj(mb["adjacency_lists"]),
+               edge_feature_data=kw.pop("edge_feature_data", []), node_to_graph_idx=mb["node_to_graph_idx"].cuda(),
+               reference_node_ids={k: v.cuda() for k, v in mb["reference_node_ids"].items()},
+               reference_node_graph_idx={k: v.cuda() for k, v in mb["reference_node_graph_idx"].items()},
+               num_graphs=mb["num_graphs"], **kw)
+
+
+@pytest.mark.parametrize("gemm_mode", ["stream", "split", "tile"])
+def test_config3_full_size_vs_oracle(gemm_mode):
+    """BASELINE config 3 at the size bench.py measures it: 48 graphs / 115 772 nodes / T = 17 / 625 130 edges,
+    the Typilus GGNN stack (8 GGNN layers, hidden 128, max) -- end to end against the CPU oracle, 1e-5, in
+    every GEMM mode (the oracle forward takes ~15 s on the host cores)."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import ops, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    H = 128
+    mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234)
+    N = mb["num_nodes"]
+    mods, specs = _typilus_ggnn_stack(H, 17, 1234)
+    x = workloads.node_states(N, H, seed=5)
+    key = "cfg3_full_oracle"
+    if key not in _CACHE:
+        _CACHE[key] = O.gnn_forward(x, mb["adjacency_lists"], specs, True, True)
+    want, n_edges = _CACHE[key]
+    net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).cuda().eval()
+    prev = ops.set_gemm_mode(gemm_mode)
+    try:
+        with torch.no_grad():
+            out = _run_container(net, x, mb)
+    finally:
+        ops.set_gemm_mode(prev)
+    assert N > 110_000 and net.report_metrics()["num_edges"] == n_edges
+    err = float((out.output_node_representations.cpu() - want).abs().max())
+    print(f"cfg3 full size [{gemm_mode}]: max|delta| vs oracle = {err:.2e}")
+    assert err <= TOL, f"[{gemm_mode}] max |delta| after 8 GGNN layers at N={N}: {err:.3e}"
+    np.testing.assert_array_equal(out.node_idx_references["supernodes"].cpu().numpy(),
+                                  mb["reference_node_ids"]["supernodes"].numpy())
+
+
+_CACHE = {}
+
+
+def _varmisuse_mlp_stack(H, T, seed):
+    """varmisuse/train.py:42-74 -- [origin r1, MLP x3, r1 (concat), MLP(2H -> H, M = 2H), origin r2, MLP x2,
+    r2 (mean), origin r3, MLP, r3 (concat), MLP(2H -> H)]: 8 MLP-MP layers, max, dropout 0.1 (eval)."""
+    from ptgnn_amd import layers as L
+    torch.manual_seed(seed)
+    mk = lambda: L.MlpMessagePassingLayer(H, H, H, T, "max", dropout_rate=0.1)          # noqa: E731
+    mk2 = lambda: L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, "max", dropout_rate=0.1)  # noqa: E731
+    r1, r2 = L.ConcatResidualLayer(H), L.MeanResidualLayer(H)
+    r3 = L.ConcatResidualLayer(H)
+    mods, specs = [], []
+
+    def add(m, spec=None):
+        mods.append(m)
+        specs.append(spec if spec is not None else m.export_weights())
+    add(r1.pass_through_dummy_layer(), {"kind": "residual_origin", "name": "r1"})
+    for _ in range(3):
+        add(mk())
+    add(r1, {"kind": "residual_concat", "name": "r1"})
+    add(mk2())
+    add(r2.pass_through_dummy_layer(), {"kind": "residual_origin", "name": "r2"})
+    for _ in range(2):
+        add(mk())
+    add(r2, {"kind": "residual_mean", "name": "r2"})
+    add(r3.pass_through_dummy_layer(), {"kind": "residual_origin", "name": "r3"})
+    add(mk())
+    add(r3, {"kind": "residual_concat", "name": "r3"})
+    add(mk2())
+    assert sum(1 for sp in specs if sp["kind"] == "mlp") == 8
+    return mods, specs
+
+
+@pytest.mark.parametrize("gemm_mode", ["stream", "split"])
+def test_config4_varmisuse_full_size_per_layer_and_end_to_end(gemm_mode):
+    """BASELINE config 4 at the reference's batch cap (varmisuse/train.py:119: 80 000 nodes): 40 graphs x ~2000
+    nodes, T0 = 10 -> T = 21, the 8-layer VarMisuse MLP-MP stack at hidden 64.
+      (a) PER LAYER at the stated bar: every MLP-MP layer, fed the ORACLE's input of that layer, is within
+          1e-5 of the oracle's output of that layer;
+      (b) end to end: 8 stacked LayerNorms amplify fp32 rounding, so the whole-stack delta is attributed
+          against a float64 evaluation -- the HIP path may sit no further from exact arithmetic than the
+          reference's own fp32 arithmetic does (x2), and the number is printed for DESIGN.md section 6."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import ops, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    H, T = 64, 21
+    mb = workloads.batched_graphs(40, 2000, 10, 2.4, seed=21)
+    N = mb["num_nodes"]
+    assert 70_000 < N <= 90_000
+    mods, specs = _varmisuse_mlp_stack(H, T, 4)
+    x = workloads.node_states(N, H, seed=6)
+    key = "cfg4_full_oracle"
+    if key not in _CACHE:
+        trace = []
+        want, n_edges = O.gnn_forward(x, mb["adjacency_lists"], specs, True, True, trace=trace)
+        exact, _ = O.gnn_forward(x.double(), mb["adjacency_lists"],
+                                 [O.cast_spec(sp, torch.float64) for sp in specs], True, True)
+        _CACHE[key] = (want, n_edges, trace, exact)
+    want, n_edges, trace, exact = _CACHE[key]
+    adj = O.augment_adjacency(mb["adjacency_lists"], N, True, True)
+    cadj = to_cuda_adj(adj)
+    feats = empty_feats(cadj, "cuda")
+    prev = ops.set_gemm_mode(gemm_mode)
+    try:
+        worst = 0.0
+        with torch.no_grad():
+            for mod, spec, (x_in, x_out) in zip(mods, specs, trace):
+                if spec["kind"] != "mlp":
+                    continue
+                ops.clear_plan_cache()
+                got = mod.cuda().eval()(x_in.cuda(), cadj, None, {}, {}, feats).cpu()
+                err = float((got - x_out).abs().max())
+                worst = max(worst, err)
+                assert err <= TOL, f"[{gemm_mode}] per-layer |delta| = {err:.3e} (layer fed the oracle's input)"
+            net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).cuda().eval()
+            out = _run_container(net, x, mb)
+    finally:
+        ops.set_gemm_mode(prev)
+    assert net.report_metrics()["num_edges"] == n_edges
+    got = out.output_node_representations.cpu()
+    err_ref = float((want.double() - exact).abs().max())
+    err_ours = float((got.double() - exact).abs().max())
+    err = float((got - want).abs().max())
+    print(f"cfg4 N={N} [{gemm_mode}]: per-layer worst {worst:.2e}; end-to-end ours-vs-oracle {err:.2e}, "
+          f"ours-vs-fp64 {err_ours:.2e}, oracle-vs-fp64 {err_ref:.2e}")
+    assert err_ours <= max(TOL, 2.0 * err_ref), f"vs fp64: ours {err_ours:.3e}, fp32 oracle {err_ref:.3e}"
+    assert err <= err_ref + err_ours + 1e-7
+
+
+def test_container_edge_dropout_branch_matches_oracle_on_the_kept_edges():
+    """graphneuralnetwork.py:105-119: in training mode the container drops edges (and their features) with a
+    Bernoulli mask per edge type before the layer loop.  The mask is torch's CUDA generator; replaying it with
+    the same seed gives the kept edge lists, on which the oracle must agree."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    H, rate = 64, 0.3
+    mb = workloads.batched_graphs(5, 400, 3, 2.5, seed=11)
+    N = mb["num_nodes"]
+    torch.manual_seed(9)
+    l1 = L.GatedMessagePassingLayer(H, H, 7, "sum")
+    l2 = L.MlpMessagePassingLayer(H, H, H, 7, "max")
+    x = workloads.node_states(N, H, seed=3)
+    net = GraphNeuralNetwork([l1, l2], torch.nn.Identity(), True, True, edge_dropout_rate=rate).cuda().train()
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        out = _run_container(net, x, mb)
+    # replay: same generator state, same call order (one rand_like per augmented edge type)
+    torch.manual_seed(4321)
+    adj = to_cuda_adj(O.augment_adjacency(mb["adjacency_lists"], N, True, True))
+    kept = []
+    for s, d in adj:
+        mask = torch.rand_like(s, dtype=torch.float32) > rate
+        kept.append((s.masked_select(mask).cpu(), d.masked_select(mask).cpu()))
+    assert sum(int(k[0].shape[0]) for k in kept) < sum(int(a[0].shape[0]) for a in adj)
+    want = O.run_layer_stack(x, kept, [l1.export_weights(), l2.export_weights()])
+    err = float((out.output_node_representations.cpu() - want).abs().max())
+    assert err <= TOL, f"edge-dropout branch: max |delta| = {err:.3e}"
+    net.eval()
+    with torch.no_grad():
+        full = _run_container(net, x, mb)
+    want_full, _ = O.gnn_forward(x, mb["adjacency_lists"], [l1.export_weights(), l2.export_weights()], True, True)
+    assert float((full.output_node_representations.cpu() - want_full).abs().max()) <= TOL   # eval: no dropout
+
+
+def test_container_return_all_states_and_linear_residual_match_oracle():
+    """graphneuralnetwork.py:132-133 (`return_all_states`: concatenation of the input and every module's
+    output) and residuallayers.py:99-142 (LinearResidualLayer) through the container."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    H = 64
+    mb = workloads.batched_graphs(4, 500, 2, 2.5, seed=12)
+    N = mb["num_nodes"]
+    torch.manual_seed(10)
+    g1 = L.GatedMessagePassingLayer(H, H, 5, "mean")
+    m1 = L.MlpMessagePassingLayer(H, 2 * H, H, 5, "sum")
+    lin = L.LinearResidualLayer(H, 2 * H, H)
+    mods = [lin.pass_through_dummy_layer(), g1, m1, lin]
+    w = lin.state_dict()["_LinearResidualLayer__linear_combination.weight"].detach().cpu()
+    specs = [{"kind": "residual_origin", "name": "r"}, g1.export_weights(), m1.export_weights(),
+             {"kind": "residual_linear", "name": "r", "w": w}]
+    x = workloads.node_states(N, H, seed=4)
+    trace = []
+    want, _ = O.gnn_forward(x, mb["adjacency_lists"], specs, True, True, trace=trace)
+    net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).cuda().eval()
+    assert net.output_node_state_dim == H
+    with torch.no_grad():
+        out = _run_container(net, x, mb)
+        all_states = _run_container(net, x, mb, return_all_states=True)
+    assert float((out.output_node_representations.cpu() - want).abs().max()) <= TOL
+    want_all = torch.cat([x] + [o for _, o in trace], dim=-1)
+    got_all = all_states.output_node_representations.cpu()
+    assert got_all.shape == want_all.shape == (N, H + H + H + 2 * H + H)
+    assert float((got_all - want_all).abs().max()) <= TOL
+
+
+def test_container_edge_feature_embedder_branch_matches_oracle():
+    """graphneuralnetwork.py:162-186: embedded edge features ride along (reverse edges reuse the forward
+    features, self edges get zeros) into GGNN layers built with `edge_feature_dimension` (K = H + F,
+    gatedmessagepassing.py:57-61) -- the general per-edge path."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    H, F = 32, 8
+    mb = workloads.batched_graphs(3, 300, 2, 2.0, seed=13)
+    N = mb["num_nodes"]
+
+    class Embed(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(5, F, bias=False)
+
+        def forward(self, features):
+            return self.lin(features)
+
+    torch.manual_seed(14)
+    emb = Embed()
+    layer = L.GatedMessagePassingLayer(H, H, 5, "sum", edge_feature_dimension=F)
+    gen = torch.Generator().manual_seed(15)
+    raw = [torch.randn(int(s.shape[0]), 5, generator=gen) for s, _ in mb["adjacency_lists"]]
+    x = workloads.node_states(N, H, seed=5)
+    feats = [emb.lin(r).detach() for r in raw]
+    want, _ = O.gnn_forward(x, mb["adjacency_lists"], [layer.export_weights()], True, True, edge_features=feats)
+    net = GraphNeuralNetwork([layer], torch.nn.Identity(), True, True, edge_feature_embedder=emb).cuda().eval()
+    with torch.no_grad():
+        out = _run_container(net, x, mb, edge_feature_data=[{"features": r.cuda()} for r in raw])
+    err = float((out.output_node_representations.cpu() - want).abs().max())
+    assert err <= TOL, f"edge-feature branch: max |delta| = {err:.3e}"
+
+
+def test_plan_build_flags_out_of_range_ids_without_touching_memory():
+    """The reference device-asserts on a bad node id (F.embedding).  Here the plan build clamps it (no
+    out-of-bounds access anywhere downstream) and the count surfaces as a PtgnnAmdError."""
+    from ptgnn_amd import _lib, ops
+    N = 1000
+    g = torch.Generator().manual_seed(3)
+    src = torch.randint(0, N, (5000,), generator=g)
+    dst = torch.randint(0, N, (5000,), generator=g)
+    dst[17] = N + 5
+    src[99] = -3
+    ops.clear_plan_cache()
+    ops.check_indices(sync=True)            # clean slate
+    plan = ops.build_plan([(src.cuda(), dst.cuda())], N)
+    y = torch.randn(N, 64, device="cuda")
+    out = ops.gather_reduce(y, plan, 64, "sum")            # runs on the clamped plan: no fault
+    msgs = ops.edge_linear(y, [(src.cuda(), dst.cuda())], [torch.randn(64, 64, device="cuda")], False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(msgs).all()
+    with pytest.raises(_lib.PtgnnAmdError, match="outside"):
+        ops.check_indices(sync=True)
+    ops.check_indices(sync=True)            # the counter was reset by the raise
+    good = ops.build_plan([(src.clamp(0, N - 1).cuda(), dst.clamp(0, N - 1).cuda())], N)
+    ops.check_indices(sync=True)
+    assert int(good.rowptr[-1]) == 5000
+
+
+def test_pooling_accepts_an_unsorted_element_to_sample_map():
+    """varsizedsummary.py:28-41 is a plain scatter: any element -> sample map must work, sorted or not."""
+    from oracle.scatter_ref import scatter
+    from ptgnn_amd import reduceops as R
+    g = torch.Generator().manual_seed(8)
+    idx = torch.randint(0, 7, (500,), generator=g)
+    assert bool((idx[1:] < idx[:-1]).any())
+    x = torch.randn(500, 32, generator=g)
+    for kind in ("sum", "max", "mean"):
+        red = R.SimpleVarSizedElementReduce(kind)
+        got = red(R.ElementsToSummaryRepresentationInput(x.cuda(), idx.cuda(), 7)).cpu()
+        want = scatter(x, idx, dim=0, dim_size=7, reduce=kind)
+        assert float((got - want).abs().max()) <= 1e-5, kind
+    sidx, _ = torch.sort(idx)
+    got = R.SimpleVarSizedElementReduce("sum")(R.ElementsToSummaryRepresentationInput(x.cuda(), sidx.cuda(), 7)).cpu()
+    assert float((got - scatter(x, sidx, dim=0, dim_size=7, reduce="sum")).abs().max()) <= 1e-5
