@@ -37,6 +37,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+_T0 = time.perf_counter()
+
+
+def _log(msg):
+    """Progress on stderr (stdout carries exactly one JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}\n")
+        sys.stderr.flush()
+
+
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 
@@ -62,6 +72,9 @@ def parse():
     p.add_argument("--global-ids", action="store_true",
                    help="N>1: the per-rank graphs as ONE disjoint-union batch with global node ids, split by "
                         "ptgnn_amd.sharded (no-cut detection = one all-reduce per minibatch)")
+    p.add_argument("--no-sharded-variants", action="store_true",
+                   help="N>1: skip the dst-range-sharded cut-edge workloads (cfg5 shard, cfg4 stack) that run after "
+                        "the primary measurement by default")
     a = p.parse_args()
     a.force_sharded = a.force_sharded or a.global_ids or a.cut_edges   # all three need the process group
     return a
@@ -71,7 +84,7 @@ def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.force_sharded:
+    if world > 1 or args.force_sharded or args.sharded_variants:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -488,6 +501,104 @@ def config5_shard(dev):
                               "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "bound": "hbm"}}
 
 
+# ------------------------------------------------------------------------------------------------
+# dst-range-sharded cut-edge workloads (north star: "destination-node sharding ... RCCL all-to-all of cut-edge
+# messages over xGMI"): every layer exchanges halo rows over RCCL.  Secondary entries at N > 1.
+# ------------------------------------------------------------------------------------------------
+def _clock_collective(fn, k, w, world, dev):
+    for _ in range(w):
+        fn()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(k):
+        fn()
+    barrier_sync(world)
+    return max_over_ranks(time.perf_counter() - t0, world, dev) / k
+
+
+def sharded_cfg5(dev, rank, world, k=5):
+    """configs[4] as a weak-scaling dst-range shard: rank p owns 1.25M nodes of ONE power-law graph of
+    world x 1.25M nodes and the 12.5M in-edges of its nodes (Zipf-0.8 destinations inside the range, sources
+    uniform over ALL ranks' nodes => (world-1)/world of the edges are cut); one GGNN layer, H = M = 256, sum.
+    Per step: halo bookkeeping + plan build + halo all-to-all (RCCL) + edge-free table form."""
+    from ptgnn_amd import layers as L, sharded, workloads
+    N, E, H = 1_250_000, 12_500_000, 256
+    lo = rank * N
+    adj = workloads.power_law_graph(N, E, alpha=0.8, seed=1234 + rank)
+    g = torch.Generator().manual_seed(99 + rank)
+    src = torch.randint(0, world * N, (E,), generator=g, dtype=torch.int64)
+    state = {"adj_global": [(src.to(dev), (adj[0][1] + lo).to(dev))], "range": (lo, lo + N),
+             "x": workloads.node_states(N, H, seed=7 + rank).to(dev),
+             "all_ranges": [(p * N, (p + 1) * N) for p in range(world)]}
+    torch.manual_seed(5)
+    layer = L.GatedMessagePassingLayer(H, H, 1, "sum").to(dev).eval()
+
+    def step():
+        from ptgnn_amd import ops
+        ops.clear_plan_cache()
+        with torch.no_grad():
+            return sharded.layer_forward(layer, state)
+    dt = _clock_collective(step, k, 2, world, dev)
+    shard = sharded.ShardedGraph.build(state["adj_global"], state["range"], all_ranges=state["all_ranges"])
+    y = torch.empty(N, H, device=dev)
+    t_x = 0.0 if shard.no_cut else _clock_collective(lambda: shard.exchange(y), k, 2, world, dev)
+    halo = sum_over_ranks(shard.n_halo, world, dev)
+    return {"workload": f"cfg5 shard x{world}: one power-law graph of {world} x 1.25M nodes, 12.5M in-edges per GPU, "
+                        f"sources uniform over all GPUs ({world - 1}/{world} of the edges cut), 1 GGNN layer H=M=256, sum",
+            "ms_per_step": round(dt * 1e3, 3), "edges_per_sec_per_layer": round(E * world / dt, 1),
+            "halo_rows_all_ranks": int(halo), "halo_bytes_per_layer_all_ranks": int(halo) * H * 4,
+            "all_to_all_ms": round(t_x * 1e3, 3), "no_cut": bool(shard.no_cut)}
+
+
+def sharded_cfg4(dev, rank, world, k=5):
+    """configs[3]: the VarMisuse batch (40 graphs x ~2000 nodes, T0 = 10 -> T = 21) through the 8-layer MLP-MP
+    stack of varmisuse/train.py:42-74 (hidden 64, max), destination ranges balanced by in-edge mass over `world`
+    GPUs (the cuts go through graphs), every layer through `forward_sharded` (edge form over the [own | halo]
+    table) with one RCCL all-to-all of halo rows per layer."""
+    from ptgnn_amd import layers as L, ops, sharded, workloads
+    H, T = 64, 21
+    mb = workloads.batched_graphs(40, 2000, 10, 2.4, seed=21)
+    n, n2g = mb["num_nodes"], mb["node_to_graph_idx"]
+    adj = list(mb["adjacency_lists"])
+    adj = adj + [(d_, s_) for s_, d_ in adj]
+    ar = torch.arange(n, dtype=torch.int64)
+    adj.append((ar, ar))
+    indeg = torch.zeros(n, dtype=torch.int64)
+    for _, d_ in adj:
+        indeg += torch.bincount(d_, minlength=n)
+    ranges = sharded.balanced_node_ranges(indeg, world)
+    lo, hi = ranges[rank]
+    mine = [(s_[(d_ >= lo) & (d_ < hi)].to(dev), d_[(d_ >= lo) & (d_ < hi)].to(dev)) for s_, d_ in adj]
+    e_mine = sum(int(a[0].shape[0]) for a in mine)
+    torch.manual_seed(4)
+    mk = lambda: L.MlpMessagePassingLayer(H, H, H, T, "max", dropout_rate=0.1)          # noqa: E731
+    mk2 = lambda: L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, "max", dropout_rate=0.1)  # noqa: E731
+    r1, r2, r3 = L.ConcatResidualLayer(H), L.MeanResidualLayer(H), L.ConcatResidualLayer(H)
+    mods = [r1.pass_through_dummy_layer(), mk(), mk(), mk(), r1, mk2(), r2.pass_through_dummy_layer(), mk(), mk(), r2,
+            r3.pass_through_dummy_layer(), mk(), r3, mk2()]
+    mods = [m.to(dev).eval() for m in mods]
+    x = workloads.node_states(n, H, seed=6)[lo:hi].contiguous().to(dev)
+    n2g_local = n2g[lo:hi].contiguous().to(dev)
+    holder = {}
+
+    def step():
+        ops.clear_plan_cache()
+        with torch.no_grad():
+            shard = sharded.ShardedGraph.build(mine, (lo, hi), all_ranges=ranges)
+            shard.attach_graph_index(n2g_local, mb["num_graphs"])
+            holder["shard"] = shard
+            return sharded.run_stack(mods, x, shard)
+    dt = _clock_collective(step, k, 2, world, dev)
+    shard = holder["shard"]
+    halo = sum_over_ranks(shard.n_halo, world, dev)
+    edges = sum_over_ranks(e_mine, world, dev)
+    return {"workload": f"cfg4 sharded x{world}: VarMisuse batch N={n}, T=21, E={int(edges)}, 8 MLP-MP layers hidden 64 "
+                        "(+ residuals), dst ranges balanced by in-edge mass, forward_sharded per layer",
+            "ms_per_forward": round(dt * 1e3, 3), "edges_per_sec_per_layer": round(edges / (dt / 8), 1),
+            "edges_per_sec_readme_convention": round(edges / dt, 1), "halo_rows_all_ranks": int(halo),
+            "halo_bytes_per_layer_all_ranks": int(halo) * H * 4, "no_cut": bool(shard.no_cut)}
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
@@ -508,8 +619,10 @@ def main():
         st = make_cfg3(dev, rank)
         step = lambda: step_cfg3(st)  # noqa: E731
 
+    _log(f"workload {args.workload} built; timing the primary region")
     seconds, summary = timed_region(step, args.steps, args.warmup, world, dev)
     ms_per_step = seconds / args.steps * 1e3
+    _log(f"primary: {ms_per_step:.3f} ms/step")
     layers = st["layers_per_step"]
     edges_all_ranks = sum_over_ranks(st["E"], world, dev)      # per-rank batches differ in size
     nodes_all_ranks = sum_over_ranks(st["N"], world, dev)
@@ -557,10 +670,23 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 result[key] = {"error": f"{type(exc).__name__}: {exc}"}
                 break              # ranks may have diverged: do not enter another collective section
+    if (world > 1 and not args.no_sharded_variants) or args.sharded_variants:
+        # the north-star split: every rank enters these together; a failure cannot cost the primary line
+        variants = {}
+        for key, fn in (("cfg5_shard", sharded_cfg5), ("cfg4_stack", sharded_cfg4)):
+            try:
+                _log(f"sharded cut-edge variant {key}")
+                variants[key] = fn(dev, rank, world)
+                torch.cuda.empty_cache()
+            except Exception as exc:  # noqa: BLE001
+                variants[key] = {"error": f"{type(exc).__name__}: {exc}"}
+                break              # ranks may have diverged: do not enter another collective section
+        result["cut_edges_variant"] = variants
     if rank == 0 and world == 1 and not args.force_sharded:
         result["repeats"] = repeat_stats(step, args.steps)
         if not args.no_secondary:
             if args.workload == "cfg3":    # configs[1]: the synthetic 200k / 1.1M graph, one MLP-MP layer
+                _log("secondary: config 2")
                 st2 = make_cfg2(dev, 0, 1)
                 k2 = max(10, args.steps)
                 sec2, sum2 = timed_region(lambda: step_cfg2(st2, 1), k2, 3, 1, dev)
@@ -582,6 +708,7 @@ def main():
                     del want2
                 del st2
                 try:
+                    _log("secondary: config 5 per-GPU shard")
                     result["config5_shard"] = config5_shard(dev)
                 except Exception as exc:  # noqa: BLE001  (secondary numbers must never cost the primary line)
                     result["config5_shard"] = {"error": f"{type(exc).__name__}: {exc}"}
@@ -599,12 +726,15 @@ def main():
                     "kernels": kernel_table(sum3)}
                 del st3
             torch.cuda.empty_cache()
+            _log("secondary: Graph2Class training steps")
             result["graph2class_train"] = [train_cfg3(dev, 0.0), train_cfg3(dev, 0.1)]
             torch.cuda.empty_cache()
             # like for like with README.md:15-18: the README's own (default) architecture and settings
+            _log("secondary: README default architecture")
             result["readme_default_arch"] = train_cfg3(dev, 0.1, arch="mlp", H=64, forward_too=True)
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
+            _log("cpu baseline (thread sweep) + full-size parity")
             with torch.no_grad():
                 gpu_out = step()
             gpu_out = gpu_out.output_node_representations if args.workload == "cfg3" else gpu_out
@@ -616,6 +746,7 @@ def main():
                 # the same primary workload in the opt-in split-precision GEMM mode, with its own parity
                 from oracle import mp_oracle as O
                 prev = ops.set_gemm_mode("split")
+                _log("split-precision GEMM mode line")
                 try:
                     sec_s, sum_s = timed_region(step, args.steps, args.warmup, 1, dev)
                     kt_s = kernel_table(sum_s)
@@ -634,7 +765,7 @@ def main():
                     result["split_bf16"] = {"error": f"{type(exc).__name__}: {exc}"}
                 finally:
                     ops.set_gemm_mode(prev)
-    if world > 1 or args.force_sharded:
+    if world > 1 or args.force_sharded or args.sharded_variants:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
@@ -645,6 +776,7 @@ def main():
         ctypes.CDLL(None).fflush(None)
     except Exception:  # noqa: BLE001
         pass
+    _log("done")
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(result), flush=True)

@@ -144,7 +144,5 @@ inline DropoutParams make_dropout(float p, uint64_t seed, int width) {
 // it out as float4 rows -- 256 contiguous bytes per row.
 constexpr int TILE_FLOATS = 128 * LDS_LD;
 
-// Static tile schedule of a persistent grid: block b walks tiles first(b), first(b)+G, ... where
-// first() keeps consecutive tiles on one XCD (b % 8 is the XCD the dispatcher is observed to use).
 }  // namespace
 }  // namespace ptgnn_amd

@@ -1,23 +1,19 @@
 // Dense blocks of the message-passing layers on the matrix cores, exact fp32
-// (v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fmaf chain, 64 FLOP/clk/SIMD).
+// (v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fmaf chain, 64 FLOP/clk/SIMD): the C-ABI entry points
 //   ptgnn_amd_linear_f32   : y = act(x W^T + b)            (pre-transform, MLP update, residual mix)
 //   ptgnn_amd_gru_cell_f32 : h' = GRUCell(a, h), gate GEMMs + gate math in one kernel
-// Contracts + reference lines: include/ptgnn_amd.h.
+// and their 128 x 128 TILE kernels.  Contracts + reference lines: include/ptgnn_amd.h.
 //
-// Both kernels are PERSISTENT: one 256-thread workgroup (4 waves = one per SIMD) per CU walks a
-// static, XCD-aware sequence of output tiles.  The K-chunks of consecutive tiles form ONE flat
-// software pipeline (global loads two chunks ahead in registers, LDS double-buffered one chunk
-// ahead, one barrier per chunk), so tile boundaries have no load bubble and a tile's epilogue
-// stores drain under the next tile's MFMAs.  Why: the r01a ablation (profiles/r01_notes.md)
-// showed a one-tile-per-block kernel serialises load / MFMA / store phases -- co-resident blocks
-// run in lockstep -- and reaches only ~75 TFLOP/s at K = 128.
-//   linear: 128 x 128 output tile, K chunks of 32 (LDS row stride 33 floats -> conflict-free
-//           ds_read_b32 for both MFMA operands); each wave owns 64 x 64 = 2 x 2 MFMA tiles.
-//   gru   : 128 rows x 32 state features; each wave owns 32 rows and FOUR 32x32 accumulators
-//           (r, z, i_n, h_n) whose C-fragment maps coincide, so the gate math is per-lane
-//           register arithmetic in the epilogue and the [n, 3H] gate matrices never exist; the
-//           previous state h needed by the epilogue is picked out of the LDS operand tile.
-// fp32 MFMA is 1/16 of the bf16 rate, so LDS/global traffic is far from limiting: MFMA-bound.
+// Each entry point first offers the call to the streaming weight-stationary core (stream_gemm.hip: GEMM modes
+// 1 and 2); the tile kernels below run GEMM mode 0 and every shape the streaming core does not take (K % 64 != 0,
+// unaligned rows, slabs beyond LDS, few rows per wave).  One output tile per 256-thread workgroup (4 waves = one
+// per SIMD), 3-4 workgroups per CU, XCD-swizzled tile order:
+//   linear: 128 x 128 (or 128 x 64 for narrow outputs) tile, K chunks of 32 through LDS (row stride 33 floats ->
+//           conflict-free ds_read_b32 for both MFMA operands), next chunk prefetched into registers under the
+//           MFMAs; each wave owns 64 x 64 (64 x 32) = 2 x 2 (2 x 1) MFMA tiles; epilogue through an LDS slab.
+//   gru   : 128 rows x 32 state features; each wave owns 32 rows and FOUR 32x32 accumulators (r, z, i_n, h_n)
+//           whose C-fragment maps coincide, so the gate math is per-lane register arithmetic in the epilogue and
+//           the [n, 3H] gate matrices never exist; the previous state is re-read (L2-hot) in the epilogue.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -28,223 +24,16 @@
 namespace ptgnn_amd {
 namespace {
 
-__constant__ int num_compute_units_dev = 256;
-
-struct TileWalk {
-  uint32_t first, stride, num_tiles;
-  __device__ __forceinline__ TileWalk(uint32_t ntiles) {
-    const uint32_t G = gridDim.x, b = blockIdx.x;
-    first = (G % kNumXcd == 0) ? (b % kNumXcd) * (G / kNumXcd) + b / kNumXcd : b;
-    stride = G;
-    num_tiles = ntiles;
-  }
-  __device__ __forceinline__ uint32_t count() const {
-    return first < num_tiles ? (num_tiles - first + stride - 1) / stride : 0;
-  }
-};
-
-// (row tile, col tile) of the i-th tile of this block, recomputed only when a cursor crosses a tile
-// boundary (one 32-bit division per tile instead of 64-bit divisions per K-chunk).
-struct TileCursor {
-  uint32_t tile, row_tile, col_tile;
-  int chunk;
-  __device__ __forceinline__ void set(uint32_t t, uint32_t col_tiles) {
-    tile = t;
-    row_tile = t / col_tiles;
-    col_tile = t - row_tile * col_tiles;
-  }
-  __device__ __forceinline__ void init(const TileWalk &w, uint32_t col_tiles) { set(w.first, col_tiles); chunk = 0; }
-  __device__ __forceinline__ bool advance(const TileWalk &w, uint32_t col_tiles, int nchunks) {
-    if (++chunk < nchunks) return false;
-    chunk = 0;
-    set(tile + w.stride, col_tiles);
-    return true;  // crossed into the next tile
-  }
-};
-
 // ---------------------------------------------------------------------------------------------
-// linear
-// ---------------------------------------------------------------------------------------------
-// Persistent variant: `BPC` workgroups per CU walk a static tile sequence; single LDS operand
-// buffer (two LDS-only barriers per K-chunk), the NEXT chunk -- also across tile boundaries -- is
-// prefetched into registers under the MFMAs, and epilogue stores are never drained (no vmcnt(0)
-// anywhere in the loop), so a finished tile's stores retire under the next tile's MFMAs.
-// NJ = MFMA tiles per wave along N: the workgroup tile is 128 x (64 * NJ).
-template <bool ALIGNED, int ACT, int NJ>
-__global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear(
-    const float *__restrict__ x, int64_t rows, int K, int64_t ld_x, const float *__restrict__ w,
-    int n_out, const float *__restrict__ bias, float *__restrict__ y, int64_t ld_y,
-    int64_t num_tiles, int col_tiles, int vec_store, int stagger_sleeps) {
-  constexpr int BN = 64 * NJ;
-  constexpr int B_FLOATS = BN * LDS_LD;
-  constexpr int SLAB_LD = 32 * NJ + 4;
-  constexpr int SLAB_FLOATS = 32 * SLAB_LD;
-  constexpr int OPER = TILE_FLOATS + B_FLOATS;
-  constexpr int kLds = OPER > 4 * SLAB_FLOATS ? OPER : 4 * SLAB_FLOATS;
-  __shared__ __attribute__((aligned(16))) float smem[kLds];
-  float *const As = smem, *const Bs = smem + TILE_FLOATS;
-  float *const slab = smem + (threadIdx.x >> 6) * SLAB_FLOATS;  // aliases the operand buffer
-
-  // De-phase the workgroups that share a CU.  Identical tiles keep a persistent grid in global
-  // lockstep (every CU loads, then multiplies, then stores at the same time), which serialises the
-  // HBM time behind the MFMA time; a one-off start offset of 1/BPC of a tile period per co-resident
-  // slot spreads the store bursts under other workgroups' MFMAs.
-  {
-    const int slot = blockIdx.x / num_compute_units_dev;
-    for (int i = 0; i < slot * stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-
-  const TileWalk walk((uint32_t)num_tiles);
-  const int nchunks = (K + BK - 1) / BK;
-  const int64_t total = (int64_t)walk.count() * nchunks;
-  if (total == 0) return;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, hi = lane >> 5;
-
-  f32x16 acc[2][NJ];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  Stager<128, ALIGNED, RowClamp> sa;
-  Stager<BN, ALIGNED, RowClamp> sb;
-  TileCursor ld, cp;  // load cursor runs one chunk ahead of the compute cursor
-  ld.init(walk, col_tiles);
-  cp.init(walk, col_tiles);
-  int64_t ld_left = total;
-  auto issue_load = [&]() {  // past the end the cursor parks on the last chunk (harmless re-load)
-    sa.load(x, ld_x, ld.chunk * BK, K, RowClamp{(int64_t)ld.row_tile * 128, rows});
-    sb.load(w, K, ld.chunk * BK, K, RowClamp{(int64_t)ld.col_tile * BN, n_out});
-    if (--ld_left > 0) ld.advance(walk, col_tiles, nchunks);
-  };
-
-  issue_load();
-  for (int64_t g = 0; g < total; ++g) {
-    lds_barrier();  // everyone is done with the previous chunk's operands / its own epilogue slab
-    sa.store(As);
-    sb.store(Bs);
-    lds_barrier();
-    issue_load();   // chunk g+1 (possibly the first chunk of the next tile) lands under the MFMAs
-
-    const float *ap = As + (wm * 64 + li) * LDS_LD + hi;
-    const float *bp = Bs + (wn * 32 * NJ + li) * LDS_LD + hi;
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      float a[2], b[NJ];
-      a[0] = ap[ks * 2];
-      a[1] = ap[32 * LDS_LD + ks * 2];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + ks * 2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-
-    const int64_t row0 = (int64_t)cp.row_tile * 128;
-    const int col0 = (int)cp.col_tile * BN;
-    if (!cp.advance(walk, col_tiles, nchunks)) continue;
-
-    // ---- tile finished: C fragments -> LDS slab -> float4 rows (bias + act on the way) ----
-    lds_barrier();  // the slab aliases the operand buffer other waves may still be reading
-    constexpr int LPRW = 8 * NJ;             // lanes per output row (float4 each)
-    constexpr int RPI = 64 / LPRW;           // rows per wave-instruction
-    constexpr int NIT = 32 / RPI;
-    const int c4 = (lane % LPRW) * 4;
-    const int rsub = lane / LPRW;
-    const int gcol = col0 + wn * 32 * NJ + c4;
-    if ((vec_store & 1) && row0 + 128 <= rows && col0 + BN <= n_out && (bias == nullptr || (vec_store & 2))) {
-      float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias) bv4 = *reinterpret_cast<const float4 *>(bias + gcol);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
-            acc[i][j][r] = 0.f;
-          }
-        __builtin_amdgcn_wave_barrier();
-        float4 v[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          v[it] = *reinterpret_cast<const float4 *>(slab + (it * RPI + rsub) * SLAB_LD + c4);
-        __builtin_amdgcn_wave_barrier();
-        float *dst = y + (row0 + wm * 64 + i * 32 + rsub) * ld_y + gcol;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          float4 o;
-          o.x = act_apply<ACT>(v[it].x + bv4.x);
-          o.y = act_apply<ACT>(v[it].y + bv4.y);
-          o.z = act_apply<ACT>(v[it].z + bv4.z);
-          o.w = act_apply<ACT>(v[it].w + bv4.w);
-          *reinterpret_cast<float4 *>(dst + (int64_t)it * RPI * ld_y) = o;
-        }
-      }
-      continue;
-    }
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) {
-      if (gcol + 0 < n_out) bv.x = bias[gcol + 0];
-      if (gcol + 1 < n_out) bv.y = bias[gcol + 1];
-      if (gcol + 2 < n_out) bv.z = bias[gcol + 2];
-      if (gcol + 3 < n_out) bv.w = bias[gcol + 3];
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      // C fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          slab[((r & 3) + 8 * (r >> 2) + 4 * hi) * SLAB_LD + j * 32 + li] = acc[i][j][r];
-          acc[i][j][r] = 0.f;
-        }
-      __builtin_amdgcn_wave_barrier();  // slab is wave-private; DS ops of a wave execute in order
-      const int64_t rbase = row0 + wm * 64 + i * 32;
-#pragma unroll
-      for (int it = 0; it < 32 / RPI; ++it) {
-        const int rl = it * RPI + rsub;
-        const int64_t grow = rbase + rl;
-        float4 v = *reinterpret_cast<const float4 *>(slab + rl * SLAB_LD + c4);
-        v.x = act_apply<ACT>(v.x + bv.x);
-        v.y = act_apply<ACT>(v.y + bv.y);
-        v.z = act_apply<ACT>(v.z + bv.z);
-        v.w = act_apply<ACT>(v.w + bv.w);
-        if (grow < rows) {
-          float *dst = y + grow * ld_y + gcol;
-          if ((vec_store & 1) && gcol + 3 < n_out) {
-            *reinterpret_cast<float4 *>(dst) = v;
-          } else {
-            if (gcol + 0 < n_out) dst[0] = v.x;
-            if (gcol + 1 < n_out) dst[1] = v.y;
-            if (gcol + 2 < n_out) dst[2] = v.z;
-            if (gcol + 3 < n_out) dst[3] = v.w;
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// linear, one tile per workgroup (occupancy-driven variant): single LDS buffer, two barriers per
-// K-chunk, next chunk prefetched into registers under the MFMAs; latency is hidden by 3-5
-// co-resident workgroups per CU and the hardware dispatcher balances the tail.
+// linear, one tile per workgroup: single LDS buffer, two barriers per K-chunk, next chunk prefetched into
+// registers under the MFMAs; latency is hidden by 3-5 co-resident workgroups per CU and the hardware
+// dispatcher balances the tail.
 // ---------------------------------------------------------------------------------------------
 template <bool ALIGNED, int ACT, int NJ>
 __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
     const float *__restrict__ x, int64_t rows, int K, int64_t ld_x, const float *__restrict__ w,
     int n_out, const float *__restrict__ bias, float *__restrict__ y, int64_t ld_y,
-    int64_t num_tiles, int col_tiles, int vec_store, int ablate) {
+    int64_t num_tiles, int col_tiles, int vec_store) {
   constexpr int BN = 64 * NJ;
   constexpr int B_FLOATS = BN * LDS_LD;
   constexpr int SLAB_LD = 32 * NJ + 4;
@@ -273,8 +62,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
 
   Stager<128, ALIGNED, RowClamp> sa;
   Stager<BN, ALIGNED, RowClamp> sb;
-  // ablation 16: fold the A rows onto a 2 MB (L2-resident) window => no HBM reads
-  const RowClamp ra{(ablate & 16) ? (row0 & 4095) : row0, rows}, rb{col0, n_out};
+  const RowClamp ra{row0, rows}, rb{col0, n_out};
   const int nchunks = (K + BK - 1) / BK;
   sa.load(x, ld_x, 0, K, ra);
   sb.load(w, K, 0, K, rb);
@@ -304,7 +92,6 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
     }
   }
 
-  if ((ablate & 1) && acc[0][0][0] != 123.456f) return;
   __syncthreads();  // operand buffers are reused as the epilogue slabs
   float *const slab = smem + wave * SLAB_FLOATS;
   constexpr int LPRW = 8 * NJ;             // lanes per output row (float4 each)
@@ -366,8 +153,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
 #pragma unroll 1
     for (int it = 0; it < NIT; ++it) {
       const int rl = it * RPI + rsub;
-      int64_t grow = rbase + rl;
-      if (ablate & 8) grow &= 1023;  // ablation 8: fold the output onto 1 MB => no HBM writes
+      const int64_t grow = rbase + rl;
       float4 v = *reinterpret_cast<const float4 *>(slab + rl * SLAB_LD + c4);
       v.x = act_apply<ACT>(v.x + bv.x);
       v.y = act_apply<ACT>(v.y + bv.y);
@@ -597,11 +383,7 @@ int num_compute_units() {
   return cus;
 }
 
-// tuning knobs (developer experiments; defaults are what profiles/ measured best):
-//   PTGNN_AMD_LINEAR_NJ=1|2   tile 128x64 | 128x128          (default: by n_out)
-//   PTGNN_AMD_LINEAR_MODE=0|1  one-shot shared tile (default) | persistent tile walk
-//   (two further variants -- wave-private operand staging and an epilogue software-pipelined under the
-//    next tile's K loop -- were measured slower and removed; numbers in profiles/r01_notes.md)
+// PTGNN_AMD_LINEAR_NJ=1|2 forces the 128x64 | 128x128 tile (default: by n_out)
 static int linear_nj() {  // 0 = heuristic
   static int nj = -1;
   if (nj < 0) {
@@ -610,33 +392,6 @@ static int linear_nj() {  // 0 = heuristic
     if (nj < 0 || nj > 2) nj = 0;
   }
   return nj;
-}
-
-static int linear_bpc(int nj) {
-  static int v = 0;
-  if (v == 0) {
-    const char *e = getenv("PTGNN_AMD_LINEAR_BPC");
-    v = e ? atoi(e) : 0;
-    if (v <= 0) v = -1;
-  }
-  return v > 0 ? v : (nj == 1 ? 4 : 3);
-}
-
-static int linear_mode() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("PTGNN_AMD_LINEAR_MODE");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
-// persistent grid: `per_cu` workgroups per CU (LDS-limited), a multiple of the XCD count
-static unsigned persistent_grid(int64_t num_tiles, int per_cu = 1) {
-  int64_t g = (int64_t)num_compute_units() * per_cu;
-  if (num_tiles < g) g = num_tiles;
-  g = (g + kNumXcd - 1) / kNumXcd * kNumXcd;
-  return (unsigned)g;
 }
 
 }  // namespace ptgnn_amd
@@ -661,31 +416,13 @@ extern "C" int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int
   const int col_tiles = (n_out + bn - 1) / bn;
   const int64_t num_tiles = row_tiles * col_tiles;
   PTGNN_REQUIRE(num_tiles < ((int64_t)1 << 31), PTGNN_AMD_EUNSUPPORTED, "linear: too many tiles");
-#ifdef PTGNN_AMD_ABLATE
-  const char *ab = getenv("PTGNN_AMD_ABLATE");
-  const int ablate = ab ? atoi(ab) : 0;
-#else
-  const int ablate = 0;
-#endif
-  const bool persistent = linear_mode() == 1;   // 0 shared-tile one-shot (default), 1 persistent
-  const unsigned grid = persistent ? persistent_grid(num_tiles, linear_bpc(nj))
-                                   : (unsigned)xcd_padded_blocks(num_tiles);
+  const unsigned grid = (unsigned)xcd_padded_blocks(num_tiles);
   const bool al = (k % 4 == 0) && (ld_x % 4 == 0) && aligned16(x) && aligned16(w);
   const int vec_store = ((ld_y % 4 == 0) && aligned16(y) ? 1 : 0) | ((bias && aligned16(bias) && n_out % 4 == 0) ? 2 : 0);
   hipStream_t st = (hipStream_t)stream_;
-  // start offset per co-resident slot: one tile's own MFMA time, in s_sleep(127) units (8128 clk)
-  const char *sg = getenv("PTGNN_AMD_LINEAR_STAGGER");
-  const int chunk_clk = nj == 1 ? 2048 : 4096;
-  const int stagger = (sg && atoi(sg) == 0) ? 0 : (int)(((int64_t)((k + 31) / 32) * chunk_clk + 4064) / 8128);
-#define PTGNN_LINEAR_LAUNCH(AL, ACT, NJ)                                                       \
-  do {                                                                                         \
-    if (persistent)                                                                            \
-      k_linear<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y, ld_y,   \
-                                                  num_tiles, col_tiles, vec_store, stagger);   \
-    else                                                                                       \
-      k_linear_tlp<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y, ld_y, \
-                                                      num_tiles, col_tiles, vec_store, ablate); \
-  } while (0)
+#define PTGNN_LINEAR_LAUNCH(AL, ACT, NJ)                                                         \
+  k_linear_tlp<AL, ACT, NJ><<<grid, 256, 0, st>>>(x, rows, k, ld_x, w, n_out, bias, y, ld_y,     \
+                                                  num_tiles, col_tiles, vec_store)
 #define PTGNN_LINEAR_ACT(AL, NJ)                                                          \
   do {                                                                                    \
     if (act == PTGNN_AMD_ACT_TANH) PTGNN_LINEAR_LAUNCH(AL, PTGNN_AMD_ACT_TANH, NJ);       \

@@ -13,12 +13,19 @@ from typing import Optional
 
 import torch
 
-from ptgnn_amd import ops
+from ptgnn_amd import _lib, ops
 
 
 def _kernel_dims_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
-            and x.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0)
+    """fp32 CUDA matrices: everything else is the caller's error (no CPU path) or an AMP dtype the layers
+    up-cast before they get here."""
+    return x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
+
+
+def _pad4(t: torch.Tensor) -> torch.Tensor:
+    """Zero-pad the column count to a multiple of 4 (the split-row weight-gradient kernel reads float4 rows)."""
+    extra = (-t.shape[1]) % 4
+    return t if extra == 0 and t.stride(0) % 4 == 0 else torch.nn.functional.pad(t, (0, extra)).contiguous()
 
 
 class _Linear(torch.autograd.Function):
@@ -39,18 +46,24 @@ class _Linear(torch.autograd.Function):
             d_x = ops.linear(g, weight.detach().t().contiguous())
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            res = ops.linear_weight_grad(x, g, want_bias=want_b)      # bias gradient rides the same pass
+            n_out, k = weight.shape
+            res = ops.linear_weight_grad(_pad4(x), _pad4(g), want_bias=want_b)   # bias gradient rides the same pass
             d_w, d_b = res if want_b else (res, None)
+            if d_w.shape != weight.shape:     # odd widths were zero-padded to the kernel's float4 rows
+                d_w = d_w[:n_out, :k].contiguous()
+                d_b = d_b[:n_out].contiguous() if d_b is not None else None
         elif want_b:
             d_b = g.sum(dim=0)
         return d_x, d_w, d_b
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Differentiable nn.Linear on the HIP kernels; shapes the kernels do not cover go to torch (still on
-    the GPU -- there is no CPU path)."""
+    """Differentiable nn.Linear on the HIP kernels, any widths (odd ones take the kernels' unaligned staging
+    path; the weight-gradient kernel sees them zero-padded to float4 rows).  There is no vendor-BLAS or CPU
+    route: anything that is not a 2-D fp32 CUDA matrix raises."""
     if not _kernel_dims_ok(x, weight):
-        return torch.nn.functional.linear(x, weight, bias)
+        raise _lib.PtgnnAmdError(f"dense.linear needs 2-D float32 CUDA matrices (got x {tuple(x.shape)} {x.dtype} on "
+                                 f"{x.device}, weight {weight.dtype}); AMP dtypes are up-cast by the layers")
     return _Linear.apply(x, weight, bias)
 
 
@@ -81,9 +94,17 @@ class _GruCell(torch.autograd.Function):
 
 
 def gru_cell(cell: torch.nn.GRUCell, a: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
-    """Differentiable nn.GRUCell on the HIP kernels (see `_GruCell`); widths the kernels do not tile fall
-    back to torch's cell (still on the GPU)."""
-    if not (_kernel_dims_ok(a, cell.weight_ih) and _kernel_dims_ok(h, cell.weight_hh) and cell.bias
-            and h.shape[1] % 4 == 0):
-        return cell(a, h)
+    """nn.GRUCell on the HIP kernels: the fused inference cell when nothing needs a gradient, else `_GruCell`."""
+    if not (_kernel_dims_ok(a, cell.weight_ih) and _kernel_dims_ok(h, cell.weight_hh)):
+        raise _lib.PtgnnAmdError(f"dense.gru_cell needs 2-D float32 CUDA matrices (got {a.dtype} / {h.dtype} on "
+                                 f"{a.device}); AMP dtypes are up-cast by the layers")
+    if not cell.bias:
+        raise _lib.PtgnnAmdError("dense.gru_cell: nn.GRUCell(bias=False) is not a reference configuration")
+    needs_grad = torch.is_grad_enabled() and any(
+        t.requires_grad for t in (a, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh))
+    if not needs_grad:
+        return ops.gru_cell(a, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+    if h.shape[1] % 4 != 0 or a.shape[1] % 4 != 0:
+        raise _lib.PtgnnAmdError("dense.gru_cell: training needs state and message widths that are multiples of 4 "
+                                 f"(got {a.shape[1]}, {h.shape[1]})")
     return _GruCell.apply(a, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)

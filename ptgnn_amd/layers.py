@@ -25,9 +25,10 @@ gradient through the same grouped GEMM + HIP segment-sum) with the GGNN layer's 
 in as a counter-based hash mask; the table form differentiates through `scatter.gather_reduce` (backward
 = the gather-reduce kernel over a backward plan); GRU / Linear blocks are `ptgnn_amd/dense.py` nodes.
 
-Edge features, deeper edge MLPs, custom aggregation modules and widths the kernels do not tile take the
-general per-edge path: torch dense ops on the GPU plus the HIP segment-reduce seam with its autograd
-rule.  No path runs on the CPU.
+Edge features, deeper edge MLPs and custom aggregation modules take the general per-edge path: torch only
+gathers / concatenates rows, every Linear runs on the HIP GEMM (`ptgnn_amd/dense.py`, any width) and the
+aggregation on the HIP segment-reduce seam with its autograd rule.  fp16 / bf16 node states (AMP) are up-cast
+to fp32 on entry and the result is cast back.  No path runs on the CPU or on a vendor BLAS.
 """
 import contextlib
 import threading
@@ -136,6 +137,16 @@ def _dropout_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
+_AMP_DTYPES = (torch.float16, torch.bfloat16)
+
+
+def _run_mlp(mlp: "MLP", x: torch.Tensor) -> torch.Tensor:
+    """ptgnn/neuralmodels/mlp.py:79-80 with every nn.Linear on the HIP GEMM (general per-edge path)."""
+    for m in mlp.modules_in_order:
+        x = dense.linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+    return x
+
+
 def _check_device(node_states: torch.Tensor):
     if not node_states.is_cuda:
         raise _lib.PtgnnAmdError(
@@ -173,6 +184,10 @@ class MLP(nn.Module):
     @property
     def linears(self) -> List[nn.Linear]:
         return [m for m in self.__mlp_modules if isinstance(m, nn.Linear)]
+
+    @property
+    def modules_in_order(self) -> List[nn.Module]:
+        return list(self.__mlp_modules)
 
     @property
     def is_single_linear(self) -> bool:
@@ -235,6 +250,14 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                 edge_features: List[torch.Tensor]) -> torch.Tensor:
         assert len(adjacency_lists) == len(self.__edge_message_transformation_layers)
         _check_device(node_states)
+        if node_states.dtype in _AMP_DTYPES:
+            # AMP (trainer.py:205,221): the reference computes messages in the autocast dtype and up-casts them
+            # to fp32 at the aggregation (abstractmessagepassing.py:43-50).  Here the whole layer runs in fp32 on
+            # the HIP kernels -- every intermediate at least as precise as the reference's -- and only the
+            # returned states go back to the caller's dtype.
+            feats = [f.float() if f is not None and f.dtype in _AMP_DTYPES else f for f in edge_features]
+            return self.forward(node_states.float(), adjacency_lists, node_to_graph_idx, reference_node_ids,
+                                reference_node_graph_idx, feats).to(node_states.dtype)
         num_nodes = node_states.shape[0]
         plan = ops.plan_for(adjacency_lists, num_nodes)
         gru = self.__state_update
@@ -265,8 +288,8 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
             return dense.gru_cell(gru, agg, node_states)
 
         if self._table_ok(node_states, edge_features):
-            # training without per-edge dropout, few edge types: torch (rocBLAS) for the dense blocks so
-            # autograd owns them, the HIP kernel (forward + backward) for the aggregation
+            # training without per-edge dropout, few edge types: differentiable HIP GEMM nodes (ptgnn_amd/dense.py)
+            # for the dense blocks, the HIP kernel (forward + backward) for the aggregation
             w = torch.cat([l.weight for l in self.__edge_message_transformation_layers], dim=0)
             y = dense.linear(node_states, w)
             agg = gather_reduce_autograd(y, None, plan, self._message_dimension, self.__aggregation_fn)
@@ -278,40 +301,65 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                                         self.__edge_message_transformation_layers):
             inp = node_states.index_select(0, src)
             if feats is not None and feats.shape[-1] > 0:
-                inp = torch.cat([inp, feats], dim=-1)
-            all_messages.append(lin(self.__dropout(inp)))
+                inp = torch.cat([inp, feats.to(inp.dtype)], dim=-1)
+            all_messages.append(dense.linear(self.__dropout(inp), lin.weight))     # HIP GEMM, K = H + F
         messages = torch.cat(all_messages, dim=0)
-        agg = segment_reduce(messages.to(torch.float32), plan, self.__aggregation_fn).to(messages.dtype)
+        agg = segment_reduce(messages, plan, self.__aggregation_fn)
         return dense.gru_cell(gru, agg, node_states)
 
     def forward_sharded(self, node_states: torch.Tensor, shard) -> torch.Tensor:
-        """One layer over a dst-range shard (ptgnn_amd/sharded.py): `node_states` are this rank's
-        rows; one all-to-all of halo rows, then the same fused kernels as `forward`."""
+        """One layer over a dst-range shard (ptgnn_amd/sharded.py): `node_states` are this rank's rows; one
+        all-to-all of halo rows, then the same kernels as `forward`.  Form per minibatch, like `forward`:
+          * edge form (many sparse edge types, or training with per-edge dropout): the grouped per-edge GEMM
+            gathers its A rows from the local table [own | halo] through the remapped adjacency lists;
+          * table form: per-node pre-transform; the rows that travel are message-table rows when T*M <= H,
+            else node states (pre-transformed after arrival: the weights are replicated)."""
         _check_device(node_states)
         feats = [None] * len(shard.local_adj)
-        assert len(shard.local_adj) == len(self.__edge_message_transformation_layers)
+        T = len(shard.local_adj)
+        assert T == len(self.__edge_message_transformation_layers)
+        if self._edge_feature_dimension != 0 or node_states.dtype != torch.float32:
+            raise _lib.PtgnnAmdError("forward_sharded: edge features / non-fp32 states are not supported on a "
+                                     "sharded graph")
+        M, H = self._message_dimension, self.__state_dimension
+        gru = self.__state_update
+        p = self.__dropout.p if self.training else 0.0
+        ws = [l.weight for l in self.__edge_message_transformation_layers]
+        table_rows = shard.n_local + (shard.n_halo if T * M > H else 0)
+        edge_form = _prefer_edge_path(shard.plan.num_edges, table_rows, T, H, M)
         if not self._fused_ok(node_states, feats):
-            if not self._table_ok(node_states, feats):
-                raise _lib.PtgnnAmdError("forward_sharded: per-edge dropout / edge features are not "
-                                         "supported on a sharded graph")
-            # training: table form with the differentiable halo exchange (backward = transposed exchange)
-            w = torch.cat([l.weight for l in self.__edge_message_transformation_layers], dim=0)
+            # training.  Edge form: differentiable halo exchange (backward = transposed all-to-all + HIP
+            # segment-sum) -> grouped per-edge GEMM node with the hash dropout folded in -> HIP segment reduce
+            if _edge_training_ok(H, M) and (p > 0 or edge_form):
+                table = shard.exchange_autograd(node_states)
+                w_stack = _scoped(self, "edge_w", lambda: torch.stack(ws))
+                seed = (_dropout_seed() ^ (0x9E3779B97F4A7C15 * (shard.rank + 1) & (2 ** 62 - 1))) if p > 0 else 0
+                msgs = edge_linear_autograd(table, shard.plan, w_stack, False, p, seed)
+                agg = segment_reduce(msgs, shard.plan, self.__aggregation_fn)
+                return dense.gru_cell(gru, agg, node_states)
+            if p > 0:
+                raise _lib.PtgnnAmdError("forward_sharded: per-edge dropout needs state and message widths that "
+                                         "are multiples of 32")
+            w = torch.cat(ws, dim=0)
             if w.shape[0] <= w.shape[1]:
                 y = shard.exchange_autograd(dense.linear(node_states, w))
             else:
                 y = dense.linear(shard.exchange_autograd(node_states), w)
-            agg = gather_reduce_autograd(y, None, shard.plan, self._message_dimension, self.__aggregation_fn)
-            return dense.gru_cell(self.__state_update, agg, node_states)
-        w = self._stacked_edge_weights()
-        TM, H = w.shape
-        if TM <= H:   # ship message-table rows: no wider than the state, and no duplicated GEMM work
-            y = shard.new_table(TM, node_states)
-            ops.linear(node_states, w, out=y[: shard.n_local])
-            shard.exchange_into(y)
-        else:         # ship node states, pre-transform own + halo rows locally (weights are replicated)
-            y = ops.linear(shard.exchange(node_states), w)
-        agg = ops.gather_reduce(y, shard.plan, self._message_dimension, self.__aggregation_fn)
-        gru = self.__state_update
+            agg = gather_reduce_autograd(y, None, shard.plan, M, self.__aggregation_fn)
+            return dense.gru_cell(gru, agg, node_states)
+        if edge_form:
+            table = shard.exchange(node_states)
+            msgs = ops.edge_linear(table, shard.local_adj, ws, False)
+            agg = ops.gather_reduce(msgs, shard.plan, M, self.__aggregation_fn, type_bits=0, col=shard.plan.perm)
+        else:
+            w = self._stacked_edge_weights()
+            if T * M <= H:   # ship message-table rows: no wider than the state, and no duplicated GEMM work
+                y = shard.new_table(T * M, node_states)
+                ops.linear(node_states, w, out=y[: shard.n_local])
+                shard.exchange_into(y)
+            else:            # ship node states, pre-transform own + halo rows locally
+                y = ops.linear(shard.exchange(node_states), w)
+            agg = ops.gather_reduce(y, shard.plan, M, self.__aggregation_fn)
         return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
 
     @property
@@ -426,28 +474,41 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
         return self._update(agg, False)
 
     def forward_sharded(self, node_states: torch.Tensor, shard) -> torch.Tensor:
-        """One layer over a dst-range shard (ptgnn_amd/sharded.py): the source term rides the halo
-        all-to-all, the destination term W_t^d x_v is purely local."""
+        """One layer over a dst-range shard (ptgnn_amd/sharded.py).  Table form: the source term rides the halo
+        all-to-all, the destination term W_t^d x_v is purely local.  Edge form (many sparse edge types): the
+        grouped per-edge GEMM reads source AND destination rows from the local table [own | halo]
+        (destinations are always own rows)."""
         _check_device(node_states)
         feats = [None] * len(shard.local_adj)
         assert len(shard.local_adj) == len(self.__edge_message_transformation_layers)
         T, M, H = len(shard.local_adj), self._message_dimension, self.__input_state_dim
+        if not self._table_ok(node_states, feats):
+            raise _lib.PtgnnAmdError("forward_sharded needs a string aggregation and single-Linear edge "
+                                     "transforms without edge features")
+        use_dst = self.__use_target_state_as_message_input
+        ws = [m.linears[0].weight for m in self.__edge_message_transformation_layers]
+        table_rows = shard.n_local + (shard.n_halo if T * M > H else 0)
+        edge_form = _prefer_edge_path(shard.plan.num_edges, table_rows, T, H, M)
         if not self._fused_ok(node_states, feats):
-            if not self._table_ok(node_states, feats):
-                raise _lib.PtgnnAmdError("forward_sharded needs a string aggregation and single-Linear edge "
-                                         "transforms without edge features")
-            # training: table form with the differentiable halo exchange (backward = transposed exchange)
-            ws = [m.linears[0].weight for m in self.__edge_message_transformation_layers]
+            if edge_form and _edge_training_ok(H, M):
+                table = shard.exchange_autograd(node_states)
+                w_stack = _scoped(self, "edge_w", lambda: torch.stack(ws))
+                msgs = edge_linear_autograd(table, shard.plan, w_stack, use_dst)
+                return self._update(segment_reduce(msgs, shard.plan, self.__aggregation_fn), False)
             w_src = torch.cat([w[:, :H] for w in ws], dim=0)
             if T * M <= H:
                 ysrc = shard.exchange_autograd(dense.linear(node_states, w_src))
             else:
                 ysrc = dense.linear(shard.exchange_autograd(node_states), w_src)
             ydst = None
-            if self.__use_target_state_as_message_input:
+            if use_dst:
                 ydst = dense.linear(node_states, torch.cat([w[:, H:2 * H] for w in ws], dim=0))
             agg = gather_reduce_autograd(ysrc, ydst, shard.plan, M, self.__aggregation_fn)
             return self._update(agg, False)
+        if edge_form:
+            table = shard.exchange(node_states)
+            msgs = ops.edge_linear(table, shard.local_adj, ws, use_dst)
+            return self._aggregate_and_update(msgs, None, shard.plan, col=shard.plan.perm, type_bits=0)
         w = self._stacked_edge_weights()
         w_src = w[: T * M]
         if T * M <= H:
@@ -456,7 +517,7 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             shard.exchange_into(ysrc)
         else:
             ysrc = ops.linear(shard.exchange(node_states), w_src)
-        ydst = ops.linear(node_states, w[T * M:]) if self.__use_target_state_as_message_input else None
+        ydst = ops.linear(node_states, w[T * M:]) if use_dst else None
         return self._aggregate_and_update(ysrc, ydst, shard.plan)
 
     def _update(self, agg: torch.Tensor, fused_epilogue_done: bool) -> torch.Tensor:
@@ -467,7 +528,7 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             if self._ln is not None:
                 x = self._ln(x)
         if self._dense is not None:
-            if x.is_cuda and x.dtype == torch.float32 and _no_grad_needed(x, *self._dense.parameters()):
+            if _no_grad_needed(x, *self._dense.parameters()):
                 tanh = isinstance(self._dense_act, nn.Tanh)
                 x = ops.linear(x, self._dense.weight, self._dense.bias, act="tanh" if tanh else None)
                 if self._dense_act is not None and not tanh:
@@ -485,6 +546,10 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
         assert len(adjacency_lists) == len(self.__edge_message_transformation_layers), \
             "The number of adjacency lists must be equal to the number of edge types."
         _check_device(node_states)
+        if node_states.dtype in _AMP_DTYPES:   # see GatedMessagePassingLayer.forward
+            feats = [f.float() if f is not None and f.dtype in _AMP_DTYPES else f for f in edge_features]
+            return self.forward(node_states.float(), adjacency_lists, node_to_graph_idx, reference_node_ids,
+                                reference_node_graph_idx, feats).to(node_states.dtype)
         num_nodes = node_states.shape[0]
         T, M = len(adjacency_lists), self._message_dimension
 
@@ -529,12 +594,12 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             if self.__use_target_state_as_message_input:
                 inp = torch.cat([inp, node_states.index_select(0, dst)], dim=-1)
             if feats is not None and feats.shape[-1] > 0:
-                inp = torch.cat([inp, feats], dim=-1)
-            all_messages.append(edge_mlp(inp))
+                inp = torch.cat([inp, feats.to(inp.dtype)], dim=-1)
+            all_messages.append(_run_mlp(edge_mlp, inp))                           # HIP GEMMs
         messages = torch.cat(all_messages, dim=0)
         if isinstance(self.__aggregation_fn, str):
             plan = ops.plan_for(adjacency_lists, num_nodes)
-            agg = segment_reduce(messages.to(torch.float32), plan, self.__aggregation_fn).to(messages.dtype)
+            agg = segment_reduce(messages, plan, self.__aggregation_fn)
         else:
             agg = self.__aggregation_fn(messages=messages, message_targets=torch.cat(all_targets, dim=0),
                                         num_nodes=num_nodes)
@@ -637,9 +702,11 @@ class LinearResidualLayer(_ResidualBase):
                 reference_node_graph_idx, edge_features):
         x = torch.cat((self._pop(), node_states), dim=-1)
         lin = self.__linear_combination
-        if x.is_cuda and x.dtype == torch.float32 and _no_grad_needed(x, lin.weight):
+        if x.dtype in _AMP_DTYPES:
+            return self.__dropout(dense.linear(x.float(), lin.weight).to(x.dtype))
+        if _no_grad_needed(x, lin.weight):
             return self.__dropout(ops.linear(x, lin.weight))
-        return self.__dropout(lin(x))
+        return self.__dropout(dense.linear(x, lin.weight))
 
     @property
     def input_state_dimension(self) -> int:

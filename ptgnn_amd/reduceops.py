@@ -74,6 +74,10 @@ class SimpleVarSizedElementReduce(AbstractVarSizedElementReduce):
         assert summarization_type in {"sum", "mean", "max", "min"}
         self.__summarization_type = summarization_type
 
+    @property
+    def summarization_type(self) -> str:
+        return self.__summarization_type
+
     def forward(self, inputs: ElementsToSummaryRepresentationInput) -> torch.Tensor:
         return _pool(inputs.element_embeddings, inputs.element_to_sample_map, inputs.num_samples,
                      self.__summarization_type)
@@ -105,6 +109,9 @@ class AbstractGlobalGraphExchange(AbstractMessagePassingLayer):
     def forward(self, node_states, adjacency_lists, node_to_graph_idx, reference_node_ids,
                 reference_node_graph_idx, edge_features) -> torch.Tensor:
         _check_device(node_states)
+        if node_states.dtype in (torch.float16, torch.bfloat16):   # AMP: fp32 inside, caller's dtype outside
+            return self.forward(node_states.float(), adjacency_lists, node_to_graph_idx, reference_node_ids,
+                                reference_node_graph_idx, edge_features).to(node_states.dtype)
         # the reference's `node_to_graph_idx.max() + 1` (globalgraphexchange.py:40) is a host read-back;
         # the same read-back here also tells whether the map is sorted (disjoint-union batches are)
         num_graphs = _index_info(node_to_graph_idx)[1]
@@ -117,6 +124,32 @@ class AbstractGlobalGraphExchange(AbstractMessagePassingLayer):
         else:   # training: HIP row gather whose backward is the HIP segment-sum over the graphs (deterministic)
             plan = _index_plan(node_to_graph_idx, num_graphs)
             per_node = gather_rows_autograd(graph_reps.contiguous(), node_to_graph_idx, plan)
+        return self._update_node_states(node_states, per_node)
+
+    def forward_sharded(self, node_states, shard) -> torch.Tensor:
+        """The same exchange over a dst-range shard (ptgnn_amd/sharded.py): every rank pools ITS nodes per graph,
+        the [num_graphs, D] partial pools are combined with one small all-reduce (a graph may straddle a rank
+        boundary), and the broadcast back + node update are local."""
+        from ptgnn_amd import sharded
+        _check_device(node_states)
+        idx, G = shard.node_to_graph_idx, shard.num_graphs
+        if idx is None:
+            raise _lib.PtgnnAmdError("forward_sharded of a global-exchange layer needs "
+                                     "ShardedGraph.attach_graph_index(node_to_graph_idx_local, num_graphs)")
+        pool = self.__global_graph_representation_module
+        if isinstance(pool, WeightedSumVarSizedElementReduce):
+            kind, local = "sum", pool(ElementsToSummaryRepresentationInput(node_states, idx, G))
+        elif isinstance(pool, SimpleVarSizedElementReduce):
+            kind = pool.summarization_type
+            local = _pool(node_states, idx, G, "sum" if kind == "mean" else kind)
+        else:
+            raise _lib.PtgnnAmdError(f"forward_sharded: cannot combine partial pools of {type(pool).__name__}")
+        counts = torch.bincount(idx, minlength=G)[:G]
+        graph_reps = self.__dropout(sharded.combine_graph_pools(local, counts, kind, shard.group))
+        if _no_grad_needed(graph_reps):
+            per_node = ops.gather_rows(graph_reps.contiguous(), idx)
+        else:
+            per_node = gather_rows_autograd(graph_reps.contiguous(), idx, _index_plan(idx, G))
         return self._update_node_states(node_states, per_node)
 
 

@@ -219,10 +219,14 @@ class _EdgeLinear(torch.autograd.Function):
                 tp = plan.transposed_plan()
                 d_x = ops.gather_reduce(g_in[:, :H] if use_dst else g_in, tp, H, "sum", type_bits=0,
                                         col=tp.perm)
-                if use_dst:
-                    d_x = d_x + ops.gather_reduce(g_in[:, H:], plan, H, "sum", type_bits=0, col=plan.perm)
                 if d_x.shape[0] != x.shape[0]:   # plans over a halo table: rows past the sources are zero
                     d_x = torch.nn.functional.pad(d_x, (0, 0, 0, x.shape[0] - d_x.shape[0]))
+                if use_dst:   # destinations are plan rows: the first plan.num_nodes rows of the table
+                    d_dst = ops.gather_reduce(g_in[:, H:], plan, H, "sum", type_bits=0, col=plan.perm)
+                    if d_dst.shape[0] == d_x.shape[0]:
+                        d_x = d_x + d_dst
+                    else:
+                        d_x[: d_dst.shape[0]] += d_dst
         return d_x, None, None, None, None, d_w
 
 

@@ -186,3 +186,177 @@ def test_halo_exchange_backward_is_the_transposed_exchange(world):
         p.join(timeout=60)
     for r in results:
         assert r[1] == "ok", r[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: the SAME `sharded.run_stack` / `ShardedGraph.build` / `combine_graph_pools` code the GPU path runs,
+# driven over gloo with oracle-backed stand-in layers (the product kernels are GPU-only), on a cfg4-shaped stack
+# ------------------------------------------------------------------------------------------------
+class _OracleShardLayer:
+    """Stand-in for a ptgnn_amd message-passing layer: real halo exchange, CPU oracle arithmetic on the local
+    table [own | halo] (rows past n_local are halo rows without in-edges and are dropped)."""
+
+    def __init__(self, spec):
+        self.spec = spec
+
+    def forward_sharded(self, x_local, shard):
+        from oracle import mp_oracle as O
+        table = shard.exchange(x_local.contiguous())
+        feats = [torch.empty(a[0].shape[0], 0) for a in shard.local_adj]
+        fn = O.mlp_mp_layer if self.spec["kind"] == "mlp" else O.ggnn_layer
+        return fn(table, shard.local_adj, feats, self.spec)[: shard.n_local]
+
+
+class _OracleGlobalExchange:
+    """Stand-in for GruGlobalStateUpdate.forward_sharded: per-rank partial pools (oracle scatter) combined by the
+    product's `combine_graph_pools`, then the oracle GRU cell."""
+
+    def __init__(self, spec):
+        self.spec = spec
+
+    def forward_sharded(self, x_local, shard):
+        from oracle import mp_oracle as O
+        from oracle.scatter_ref import scatter
+        from ptgnn_amd import sharded
+        idx, G, w = shard.node_to_graph_idx, shard.num_graphs, self.spec
+        kind = w["pool"]
+        if kind == "weighted_sum":
+            weights = torch.sigmoid(O.linear(x_local, w["pool_w"]).squeeze(-1))
+            local, kind = scatter(x_local * weights.unsqueeze(-1), idx, dim=0, dim_size=G, reduce="sum"), "sum"
+        else:
+            local = scatter(x_local, idx, dim=0, dim_size=G, reduce="sum" if kind == "mean" else kind)
+        pooled = sharded.combine_graph_pools(local, torch.bincount(idx, minlength=G)[:G], kind, shard.group)
+        return O.gru_cell(pooled[idx], x_local, w["w_ih"], w["w_hh"], w["b_ih"], w["b_hh"])
+
+
+def _cfg4_like(seed):
+    """VarMisuse-shaped problem at toy size: 6 graphs, T0 = 10 -> T = 21 edge types, hidden 16; the MLP stack of
+    varmisuse/train.py:42-74 (8 MLP-MP layers + residuals) and a GGNN + global-exchange tail (:76-107)."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, workloads
+    H = 16
+    mb = workloads.batched_graphs(6, 150, 10, 2.4, refs_per_graph=3, seed=seed)
+    n = mb["num_nodes"]
+    adj = O.augment_adjacency(mb["adjacency_lists"], n, True, True)
+    T = len(adj)
+    torch.manual_seed(seed)
+    mk = lambda: L.MlpMessagePassingLayer(H, H, H, T, "max").export_weights()            # noqa: E731
+    mk2 = lambda: L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, "max").export_weights()    # noqa: E731
+    ggnn = L.GatedMessagePassingLayer(H, H, T, "sum").export_weights()
+    gru = torch.nn.GRUCell(H, H)
+    glob = {"kind": "global_gru", "pool": "weighted_sum", "pool_w": torch.randn(1, H) * 0.3,
+            "w_ih": gru.weight_ih.detach(), "w_hh": gru.weight_hh.detach(), "b_ih": gru.bias_ih.detach(),
+            "b_hh": gru.bias_hh.detach()}
+    glob_max = dict(glob, pool="max")
+    specs = [{"kind": "residual_origin", "name": "r1"}, mk(), mk(), mk(), {"kind": "residual_concat", "name": "r1"},
+             mk2(), {"kind": "residual_origin", "name": "r2"}, mk(), mk(), {"kind": "residual_mean", "name": "r2"},
+             {"kind": "residual_origin", "name": "r3"}, mk(), {"kind": "residual_concat", "name": "r3"}, mk2(),
+             ggnn, glob, ggnn, glob_max]
+    x = workloads.node_states(n, H, seed=seed + 1)
+    return mb, adj, specs, x, H
+
+
+def _worker_run_stack(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import mp_oracle as O
+        from ptgnn_amd import layers as L, sharded
+        mb, adj, specs, x, H = _cfg4_like(61)
+        n, n2g = mb["num_nodes"], mb["node_to_graph_idx"]
+        want = O.run_layer_stack(x, adj, specs, node_to_graph_idx=n2g)
+        indeg = torch.zeros(n, dtype=torch.int64)
+        for _, d in adj:
+            indeg += torch.bincount(d, minlength=n)
+        ranges = sharded.balanced_node_ranges(indeg, world)          # edge-mass cuts: graphs straddle ranks
+        lo, hi = ranges[rank]
+        assert int(n2g[lo]) == int(n2g[lo - 1]) if rank > 0 else True
+        mine = [(s[(d >= lo) & (d < hi)], d[(d >= lo) & (d < hi)]) for s, d in adj]
+        shard = sharded.ShardedGraph.build(mine, (lo, hi), build_plan=False)
+        shard.attach_graph_index(n2g[lo:hi].contiguous(), mb["num_graphs"])
+        # product residual layers (pure node-local glue) + oracle stand-ins for the kernel-backed layers
+        mods, res = [], {}
+        for sp in specs:
+            k = sp["kind"]
+            if k in ("mlp", "ggnn"):
+                mods.append(_OracleShardLayer(sp))
+            elif k == "global_gru":
+                mods.append(_OracleGlobalExchange(sp))
+            elif k == "residual_origin":
+                mods.append(("origin", sp["name"]))
+            else:
+                dim = H
+                r = (L.ConcatResidualLayer if k == "residual_concat" else L.MeanResidualLayer)(dim)
+                i = next(j for j, m in enumerate(mods) if isinstance(m, tuple) and m[1] == sp["name"])
+                mods[i] = r.pass_through_dummy_layer()
+                mods.append(r)
+        got = sharded.run_stack(mods, x[lo:hi].contiguous(), shard)
+        err = float((got - want[lo:hi]).abs().max())
+        assert err <= 1e-5, f"rank {rank}: run_stack vs unsharded oracle: {err:.3e}"
+        out_q.put((rank, "ok", shard.n_halo, err))
+    except Exception:
+        import traceback
+        out_q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_run_stack_cfg4_shape_with_global_exchange_over_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_run_stack, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert r[1] == "ok", r[1]
+    assert all(r[2] > 0 for r in results)       # the cuts go through graphs: every rank exchanges halo rows
+
+
+def _worker_pools(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.scatter_ref import scatter
+        from ptgnn_amd import sharded
+        g = torch.Generator().manual_seed(71)
+        n, G, D = 90, 7, 5
+        idx, _ = torch.sort(torch.randint(0, G - 1, (n,), generator=g))     # graph G-1 is empty everywhere
+        x = torch.randn(n, D, generator=g)
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        for kind in ("sum", "mean", "max", "min"):
+            local = scatter(x[lo:hi], idx[lo:hi], dim=0, dim_size=G, reduce="sum" if kind == "mean" else kind)
+            cnt = torch.bincount(idx[lo:hi], minlength=G)
+            got = sharded.combine_graph_pools(local, cnt, kind)
+            want = scatter(x, idx, dim=0, dim_size=G, reduce=kind)
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+            assert float(got[G - 1].abs().max()) == 0.0
+        # gradient of the differentiable all-reduce: loss = sum over ranks of <c_r, allreduce(x)>
+        xl = x[lo:hi].sum(0, keepdim=True).clone().requires_grad_(True)
+        y = sharded.all_reduce(xl, "sum")
+        (float(rank + 1) * y).sum().backward()
+        np.testing.assert_allclose(xl.grad.numpy(), np.full((1, D), sum(range(1, world + 1)), dtype=np.float32))
+        out_q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        out_q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partial_graph_pools_combine_across_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pools, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert r[1] == "ok", r[1]
