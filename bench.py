@@ -361,21 +361,57 @@ def pmc_traffic(workload, kernel):
 PARITY_TOL = 1e-5   # BASELINE.json north_star: fp32 node states within 1e-5 of the reference CPU path
 
 
+CPU_FORWARD_BUDGET_S = 6.0    # per thread count: a warm-up slower than this is reported as is (no timed repeats)
+
+
 def _timed_forwards(fn, n_timed=3):
-    """1 warm-up + n timed forwards, median (SURVEY.md 8d / BASELINE.md 3)."""
-    fn()
+    """1 warm-up + n timed forwards, median (SURVEY.md 8d / BASELINE.md 3).  Time-boxed: when the warm-up alone
+    exceeds the budget (e.g. 256 threads on a cgroup-limited host: 105 s per forward) its time is the figure and
+    the repeats are skipped, so the default bench run stays within minutes.  Returns (seconds, output, n_timed)."""
+    t0 = time.perf_counter()
+    out = fn()
+    warm = time.perf_counter() - t0
+    if warm > CPU_FORWARD_BUDGET_S:
+        return warm, out, 0
     ts = []
     for _ in range(n_timed):
         t0 = time.perf_counter()
         out = fn()
         ts.append(time.perf_counter() - t0)
     ts.sort()
-    return ts[len(ts) // 2], out
+    return ts[len(ts) // 2], out, n_timed
 
 
 def _thread_counts():
-    allc = os.cpu_count() or 1
-    return sorted({c for c in (1, 8, 32, allc) if c <= allc})
+    """{1, 8, 32, all}, `all` capped at the cores this process may actually use."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    try:   # cgroup v2 CPU quota of the container, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            usable = max(1, min(usable, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return sorted({c for c in (1, 8, 32, usable) if c <= usable})
+
+
+def _sweep(fn):
+    """seconds per forward by thread count.  Counts are tried in increasing order; once doubling-plus the threads
+    no longer buys 20 % (the oracle is bandwidth / framework bound well before 256 threads) larger counts are
+    skipped -- oversubscribed runs cost minutes and are never the baseline."""
+    sweep, out, prev = {}, None, None
+    for c in _thread_counts():
+        if prev is not None and c > 32 and sweep[str(prev[0])] > 0.8 * prev[1]:
+            sweep[str(c)] = None
+            continue
+        torch.set_num_threads(c)
+        sec, out, _ = _timed_forwards(fn)
+        if sweep:
+            prev = (c, min(v for v in sweep.values() if v is not None))
+        sweep[str(c)] = round(sec, 4)
+    return sweep, out
 
 
 def cpu_baseline_cfg2(st, gpu_out):
@@ -387,13 +423,9 @@ def cpu_baseline_cfg2(st, gpu_out):
     spec = st["layer"].export_weights()
     x, adj = st["cpu_x"], st["cpu_adj"]
     feats = [torch.empty(st["E"], 0)]
-    sweep, want = {}, None
     with torch.no_grad():
-        for c in _thread_counts():
-            torch.set_num_threads(c)
-            med, want = _timed_forwards(lambda: O.mlp_mp_layer(x, adj, feats, spec))
-            sweep[str(c)] = round(med, 4)
-    best = min(sweep, key=lambda k: sweep[k])
+        sweep, want = _sweep(lambda: O.mlp_mp_layer(x, adj, feats, spec))
+    best = min((k for k in sweep if sweep[k] is not None), key=lambda k: sweep[k])
     parity = {"max_abs": float((gpu_out.cpu() - want).abs().max()), "tol": PARITY_TOL, "n": st["N"],
               "against": "oracle/mp_oracle.py at full size (N=200k, E=1.1M)"}
     return {"value": round(st["E"] / sweep[best], 1), "unit": "edges/s", "cores": int(best), "kind": "port",
@@ -415,13 +447,9 @@ def cpu_baseline_cfg3(st, gpu_out):
     small = workloads.batched_graphs(8, 2500, 8, 2.2, seed=1234)
     xs = workloads.node_states(small["num_nodes"], st["H"], seed=5)
     e_small = 2 * sum(int(a[0].shape[0]) for a in small["adjacency_lists"]) + small["num_nodes"]
-    sweep = {}
     with torch.no_grad():
-        for c in _thread_counts():
-            torch.set_num_threads(c)
-            med, _ = _timed_forwards(lambda: O.gnn_forward(xs, small["adjacency_lists"], st["specs"], True, True))
-            sweep[str(c)] = round(med, 4)
-        best = min(sweep, key=lambda k: sweep[k])
+        sweep, _ = _sweep(lambda: O.gnn_forward(xs, small["adjacency_lists"], st["specs"], True, True))
+        best = min((k for k in sweep if sweep[k] is not None), key=lambda k: sweep[k])
         torch.set_num_threads(int(best))
         t0 = time.perf_counter()
         want, n_edges = O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True)

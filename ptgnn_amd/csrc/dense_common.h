@@ -81,6 +81,12 @@ struct GateRows {  // GRU weights: tile row (gate*32 + jj) -> gate*H + min(j0 + 
   }
 };
 
+// K order inside a 32-wide chunk, shared by EVERY exact-fp32 kernel of the library (tile and streaming):
+// MFMA step s of a chunk multiplies columns 8 (s >> 2) + (s & 3) (lanes 0-31) and that + 4 (lanes 32-63), i.e.
+// the 16-byte pieces the streaming kernels load per lane (stream_gemm.hip).  One fixed accumulation order per
+// row means a result does not depend on which kernel, tile position, shard or layer form produced it.
+__device__ __forceinline__ constexpr int kcol(int s) { return (s >> 2) * 8 + (s & 3); }
+
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would stall
 // every K-chunk on the prefetch loads still in flight and on the previous tile's epilogue stores
 // (cdna_hip_programming.md section 5: "the ~20% stall").  The staged global loads are ordered by

@@ -75,15 +75,15 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_linear_tlp(
       sa.load(x, ld_x, (c + 1) * BK, K, ra);
       sb.load(w, K, (c + 1) * BK, K, rb);
     }
-    const float *ap = As + (wm * 64 + li) * LDS_LD + hi;
-    const float *bp = Bs + (wn * 32 * NJ + li) * LDS_LD + hi;
+    const float *ap = As + (wm * 64 + li) * LDS_LD + 4 * hi;   // K order of a chunk: kcol()
+    const float *bp = Bs + (wn * 32 * NJ + li) * LDS_LD + 4 * hi;   // K order of a chunk: kcol()
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
       float a[2], b[NJ];
-      a[0] = ap[ks * 2];
-      a[1] = ap[32 * LDS_LD + ks * 2];
+      a[0] = ap[kcol(ks)];
+      a[1] = ap[32 * LDS_LD + kcol(ks)];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + ks * 2];
+      for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + kcol(ks)];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256, 3) void k_gru(const float *__restrict__ a, int
   };
   issue(0);
   const float *arow = As + (wave * 32) * LDS_LD;
-  const float *ap = arow + li * LDS_LD + hi;
-  const float *bp = Bs + li * LDS_LD + hi;
+  const float *ap = arow + li * LDS_LD + 4 * hi;   // K order of a chunk: kcol()
+  const float *bp = Bs + li * LDS_LD + 4 * hi;   // K order of a chunk: kcol()
   for (int c = 0; c < chunks0; ++c) {
     __syncthreads();
     sa.store(As);
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256, 3) void k_gru(const float *__restrict__ a, int
     if (c + 1 < total) issue(c + 1);
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      const float av = ap[ks * 2];
-      const float br = bp[ks * 2], bz = bp[32 * LDS_LD + ks * 2], bn = bp[64 * LDS_LD + ks * 2];
+      const float av = ap[kcol(ks)];
+      const float br = bp[kcol(ks)], bz = bp[32 * LDS_LD + kcol(ks)], bn = bp[64 * LDS_LD + kcol(ks)];
       acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br, acc_r, 0, 0, 0);
       acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bz, acc_z, 0, 0, 0);
       acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bn, acc_in, 0, 0, 0);
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256, 3) void k_gru(const float *__restrict__ a, int
     if (c + 1 < total) issue(c + 1);
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      const float av = ap[ks * 2];
-      const float br = bp[ks * 2], bz = bp[32 * LDS_LD + ks * 2], bn = bp[64 * LDS_LD + ks * 2];
+      const float av = ap[kcol(ks)];
+      const float br = bp[kcol(ks)], bz = bp[32 * LDS_LD + kcol(ks)], bn = bp[64 * LDS_LD + kcol(ks)];
       acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av, br, acc_r, 0, 0, 0);
       acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bz, acc_z, 0, 0, 0);
       acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bn, acc_hn, 0, 0, 0);

@@ -119,24 +119,24 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();
     if constexpr (DROP == 1) {   // mask this chunk's gathered rows in registers on their way into LDS
-      const int kcol = c * BK + (threadIdx.x & 7) * 4;
+      const int dcol = c * BK + (threadIdx.x & 7) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        sa.v[r] = dropout_apply4(drop, out_row0 + (threadIdx.x >> 3) + r * 32, kcol, sa.v[r]);
+        sa.v[r] = dropout_apply4(drop, out_row0 + (threadIdx.x >> 3) + r * 32, dcol, sa.v[r]);
     }
     sa.store(As);
     sb.store(Bs);
     __syncthreads();
     if (c + 1 < nchunks) issue(c + 1);
-    const float *ap = As + (wm * 64 + li) * LDS_LD + hi;
-    const float *bp = Bs + (wn * 32 * NJ + li) * LDS_LD + hi;
+    const float *ap = As + (wm * 64 + li) * LDS_LD + 4 * hi;   // K order of a chunk: kcol()
+    const float *bp = Bs + (wn * 32 * NJ + li) * LDS_LD + 4 * hi;   // K order of a chunk: kcol()
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
       float a[2], b[NJ];
-      a[0] = ap[ks * 2];
-      a[1] = ap[32 * LDS_LD + ks * 2];
+      a[0] = ap[kcol(ks)];
+      a[1] = ap[32 * LDS_LD + kcol(ks)];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + ks * 2];
+      for (int j = 0; j < NJ; ++j) b[j] = bp[j * 32 * LDS_LD + kcol(ks)];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -50,6 +50,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
 constexpr int kLdsBudget = 160 * 1024;
+constexpr size_t kEpiBytes = 16 + 8 * 8 * 36 * sizeof(float);   // unit counter + 8 wave-private transposing slabs
 
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 v;
@@ -103,17 +104,19 @@ template <int NBLK, int NACC, int PH, bool GRU>
 __device__ __forceinline__ void chunk_f32(f32x16 (&acc)[NACC], float4 (&buf)[4], float4 (&bcur)[NBLK],
                                           const float *bl, int cbs, int kofs, int kofs_next, const ARows &rows,
                                           int cnext, int ch0, int nch) {
-  // bcur holds the B fragments of piece 0 on entry and those of the NEXT chunk's piece 0 on exit: the
-  // LDS reads run one piece ahead of the MFMAs.  The sched_barrier pins each refill load behind the 16
-  // MFMAs that consumed its registers (hipcc otherwise sinks all eight loads to the end of the loop body
-  // and drains them with vmcnt(0) at the top: no prefetch left).
+  // bcur holds the B fragments of piece 0 on entry and those of the NEXT chunk's piece 0 on exit: the LDS reads
+  // run one piece ahead of the MFMAs.  The four pieces of a chunk are the four 32-byte sectors of ONE cache line
+  // per row, so they are refilled as a burst once the chunk is consumed (one L2 fetch per line; refilled one at a
+  // time, 16 MFMAs apart, each piece re-fetched the line after the other waves had flushed it from the 32 KB L1:
+  // measured 11 % of the kernel).  sched_barriers pin the order: hipcc otherwise sinks the LDS reads below the MFMAs,
+  // and counts vmcnt per loop only when every path into the loop issued the loads in the same order.
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     float4 bn[NBLK];
     const int ko = g < 3 ? kofs + (g + 1) * 8 : kofs_next;
 #pragma unroll
     for (int n = 0; n < NBLK; ++n) bn[n] = *reinterpret_cast<const float4 *>(bl + n * cbs + ko);
-    __builtin_amdgcn_sched_barrier(0);   // reads first: hipcc otherwise sinks them below the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
     const float4 a = buf[g];
 #define PTGNN_STEP(C)                                                                     \
     _Pragma("unroll") for (int n = 0; n < NBLK; ++n) {                                    \
@@ -122,10 +125,14 @@ __device__ __forceinline__ void chunk_f32(f32x16 (&acc)[NACC], float4 (&buf)[4],
     }
     PTGNN_STEP(x) PTGNN_STEP(y) PTGNN_STEP(z) PTGNN_STEP(w)
 #undef PTGNN_STEP
-    buf[g] = load_piece<false>(rows, cnext, ch0, nch, g);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int n = 0; n < NBLK; ++n) bcur[n] = bn[n];
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    buf[g] = load_piece<false>(rows, cnext, ch0, nch, g);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -276,12 +283,53 @@ __device__ __forceinline__ int claim_unit(int *counter) {
 // ---------------------------------------------------------------------------------------------------
 // linear: y = act(x W^T + b)
 // ---------------------------------------------------------------------------------------------------
+// Epilogue stores.  A C fragment holds, per lane, 4 consecutive ROWS of one column (x 4 row groups): stored as
+// is, a unit costs 64 dword stores of 2 x 128 B each -- store-issue bound, measured 16-21 % of the kernels.  A
+// wave-private 8 x 32 transposing slab in LDS (1.1 KB per wave; DS traffic is free next to fp32 MFMAs) turns a
+// row group into ONE dwordx4 store per lane: 8 rows x 128 contiguous bytes.
+constexpr int kTqLd = 36;                    // floats per slab row (32 + 4: 16-byte aligned rows)
+constexpr int kTqFloats = 8 * kTqLd;         // per wave
+
+// v[i] = value of row (4 hi + i), column li of the row group; returns this lane's float4 = row lane/8, cols 4 (lane%8)
+__device__ __forceinline__ float4 tq_transpose(float *tq, int lane, int li, int hi, float v0, float v1, float v2,
+                                               float v3) {
+  float *w = tq + (4 * hi) * kTqLd + li;
+  w[0] = v0; w[kTqLd] = v1; w[2 * kTqLd] = v2; w[3 * kTqLd] = v3;
+  __builtin_amdgcn_wave_barrier();            // DS ops of one wave execute in order; this pins the compiler
+  const float4 o = *reinterpret_cast<const float4 *>(tq + (lane >> 3) * kTqLd + (lane & 7) * 4);
+  __builtin_amdgcn_wave_barrier();
+  return o;
+}
+
+// the reverse: this lane's float4 (row lane/8, cols 4 (lane%8)) -> values of rows 4 hi + {0..3}, column li
+__device__ __forceinline__ void tq_untranspose(float *tq, int lane, int li, int hi, float4 in, float (&v)[4]) {
+  *reinterpret_cast<float4 *>(tq + (lane >> 3) * kTqLd + (lane & 7) * 4) = in;
+  __builtin_amdgcn_wave_barrier();
+  const float *r = tq + (4 * hi) * kTqLd + li;
+  v[0] = r[0]; v[1] = r[kTqLd]; v[2] = r[2 * kTqLd]; v[3] = r[3 * kTqLd];
+  __builtin_amdgcn_wave_barrier();
+}
+
+// one 32 x 32 C block -> y (bias + activation on the way), 4 dwordx4 stores per lane
+template <int ACT>
+__device__ __forceinline__ void store_block_tq(const f32x16 &c, float *tq, float *yblk /* row0, col0 of the block */,
+                                               int64_t ld_y, float bv, int64_t rows_left, int lane, int li, int hi) {
+  float *yp = yblk + (int64_t)(lane >> 3) * ld_y + (lane & 7) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 o = tq_transpose(tq, lane, li, hi, act_apply<ACT>(c[4 * q] + bv), act_apply<ACT>(c[4 * q + 1] + bv),
+                                  act_apply<ACT>(c[4 * q + 2] + bv), act_apply<ACT>(c[4 * q + 3] + bv));
+    if (8 * q + (lane >> 3) < rows_left) *reinterpret_cast<float4 *>(yp + (int64_t)(8 * q) * ld_y) = o;
+  }
+}
+
 struct LinearArgs {
   const float *x; int64_t rows; int K; int64_t ld_x;
   const float *w; int n_out; const float *bias; int act;
   float *y; int64_t ld_y;
   int nrb, ncs, rps, run_len;
   int lds_floats;            // slab size in floats (the unit counter sits behind it)
+  int vec_store;             // y rows are 16-byte aligned: float4 stores through the transposing slab
 };
 
 template <int ACT>
@@ -322,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
 
   const Slab<SPLIT> sl(p.K, BN);
   int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
+  float *const tq = smem + p.lds_floats + 4 + (threadIdx.x >> 6) * kTqFloats;   // this wave's transposing slab
   if (threadIdx.x == 0) *counter = 0;
   const int col_base = slab * BN;
   {
@@ -366,10 +415,18 @@ __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
       const int col = col_base + n * 32 + li;
       if (col_base + n * 32 < p.n_out) {   // n_out % 32 == 0: whole column blocks
         const float bv = p.bias ? p.bias[col] : 0.f;
-        float *yp = p.y + (row0 + 4 * hi) * p.ld_y + col;
-        if (p.act == PTGNN_AMD_ACT_TANH) store_block<PTGNN_AMD_ACT_TANH>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
-        else if (p.act == PTGNN_AMD_ACT_RELU) store_block<PTGNN_AMD_ACT_RELU>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
-        else store_block<PTGNN_AMD_ACT_NONE>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
+        if (p.vec_store) {
+          float *yb = p.y + row0 * p.ld_y + col_base + n * 32;
+          const int64_t left = p.rows - row0;
+          if (p.act == PTGNN_AMD_ACT_TANH) store_block_tq<PTGNN_AMD_ACT_TANH>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
+          else if (p.act == PTGNN_AMD_ACT_RELU) store_block_tq<PTGNN_AMD_ACT_RELU>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
+          else store_block_tq<PTGNN_AMD_ACT_NONE>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
+        } else {
+          float *yp = p.y + (row0 + 4 * hi) * p.ld_y + col;
+          if (p.act == PTGNN_AMD_ACT_TANH) store_block<PTGNN_AMD_ACT_TANH>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
+          else if (p.act == PTGNN_AMD_ACT_RELU) store_block<PTGNN_AMD_ACT_RELU>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
+          else store_block<PTGNN_AMD_ACT_NONE>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
+        }
       }
       acc[n] = zero16();
     }
@@ -425,6 +482,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
   const int K = p.M + p.H;
   const Slab<SPLIT> sl(K, 96);
   int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
+  float *const tq = smem + p.lds_floats + 4 + (threadIdx.x >> 6) * kTqFloats;
   if (threadIdx.x == 0) *counter = 0;
   const int j0 = slab * 32;
   {
@@ -471,48 +529,49 @@ __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
     unit_fence();
     unit_kloop<3, 4, true, SPLIT>(acc, a0, a1, smem, sl, li, hi, rows, ch0, nch);
     const int64_t row0 = (int64_t)(rb0 + cur) * 32;
-    // previous state of this lane's 16 output elements: re-read (L2-hot, this unit just streamed the rows)
-    float hprev[16];
+    // Epilogue per row group (8 rows): previous state in as one dwordx4 per lane (8 rows x 128 B of the h tile),
+    // un-transposed through the wave's slab into the C layout; gate math per lane; h' (and, in training, the
+    // gates) back through the slab as dwordx4 stores.  No mul+add contraction in the gate math: a row's result must
+    // not depend on which slot of the lane it occupies (sharded == unsharded bit for bit).
+    const int trow = lane >> 3, tcol = (lane & 7) * 4;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      row = row < p.n ? row : p.n - 1;
-      hprev[r] = p.h[row * p.ld_h + j];
-    }
-    float res[16];
-    {
-      // no mul+add contraction: a row's result must not depend on which of the lane's 16 slots it occupies
-      // (sharded == unsharded bit for bit)
+    for (int q = 0; q < 4; ++q) {
+      int64_t hrow = row0 + 8 * q + trow;
+      const bool rvalid = hrow < p.n;
+      hrow = rvalid ? hrow : p.n - 1;
+      float hp[4];
+      tq_untranspose(tq, lane, li, hi, *reinterpret_cast<const float4 *>(p.h + hrow * p.ld_h + j0 + tcol), hp);
+      float res[4], rg[4], zg[4], ng[4], hn[4];
+      {
 #pragma clang fp contract(off)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float rg = fast_sigmoid((acc[0][r] + bir) + bhr);
-        const float zg = fast_sigmoid((acc[1][r] + biz) + bhz);
-        const float hn = acc[3][r] + bhn;
-        const float ng = fast_tanh((acc[2][r] + bin) + rg * hn);
-        res[r] = (1.0f - zg) * ng + zg * hprev[r];
-        if (p.gates) {   // training: r, z, n, gh_n for the backward ([n, 4H], gate-major)
-          const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (row < p.n) {
-            float *gp = p.gates + row * (int64_t)(4 * p.H) + j;
-            gp[0] = rg; gp[p.H] = zg; gp[2 * p.H] = ng; gp[3 * p.H] = hn;
-          }
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * q + i;
+          rg[i] = fast_sigmoid((acc[0][r] + bir) + bhr);
+          zg[i] = fast_sigmoid((acc[1][r] + biz) + bhz);
+          hn[i] = acc[3][r] + bhn;
+          ng[i] = fast_tanh((acc[2][r] + bin) + rg[i] * hn[i]);
+          res[i] = (1.0f - zg[i]) * ng[i] + zg[i] * hp[i];
+        }
+      }
+      const float4 o = tq_transpose(tq, lane, li, hi, res[0], res[1], res[2], res[3]);
+      if (rvalid) *reinterpret_cast<float4 *>(p.out + hrow * p.ld_out + j0 + tcol) = o;
+      if (p.gates) {   // training: r, z, n, gh_n for the backward ([n, 4H], gate-major)
+        float *gp = p.gates + hrow * (int64_t)(4 * p.H) + j0 + tcol;
+        const float4 o_r = tq_transpose(tq, lane, li, hi, rg[0], rg[1], rg[2], rg[3]);
+        const float4 o_z = tq_transpose(tq, lane, li, hi, zg[0], zg[1], zg[2], zg[3]);
+        const float4 o_n = tq_transpose(tq, lane, li, hi, ng[0], ng[1], ng[2], ng[3]);
+        const float4 o_h = tq_transpose(tq, lane, li, hi, hn[0], hn[1], hn[2], hn[3]);
+        if (rvalid) {
+          *reinterpret_cast<float4 *>(gp) = o_r;
+          *reinterpret_cast<float4 *>(gp + p.H) = o_z;
+          *reinterpret_cast<float4 *>(gp + 2 * p.H) = o_n;
+          *reinterpret_cast<float4 *>(gp + 3 * p.H) = o_h;
         }
       }
     }
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = zero16();
-    float *dst = p.out + (row0 + 4 * hi) * p.ld_out + j;
-    if (row0 + 32 <= p.n) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * p.ld_out] = res[r];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2);
-        if (row0 + rr + 4 * hi < p.n) dst[(int64_t)rr * p.ld_out] = res[r];
-      }
-    }
     cur = nxt;
     nxt = nn;
     rows.c0 = rows.n0; rows.c1 = rows.n1;
@@ -544,6 +603,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge(EdgeArgs p) {
   const int K = p.use_dst ? 2 * p.H : p.H;
   const Slab<SPLIT> sl(K, BN);
   int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
+  float *const tq = smem + p.lds_floats + 4 + (threadIdx.x >> 6) * kTqFloats;
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int ch0 = p.H >> 5, nch = K >> 5;
@@ -609,11 +669,12 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge(EdgeArgs p) {
         const int64_t out_row0 = p.msg_row_base + p.tab.edge_off[t] + e_row0;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
-          if (n * 32 < p.M) {
-            float *yp = p.msg + (out_row0 + 4 * hi) * p.ld_msg + n * 32 + li;
-            if (p.act == PTGNN_AMD_ACT_TANH) store_block<PTGNN_AMD_ACT_TANH>(acc[n], yp, p.ld_msg, 0.f, e_row0, n_edges, hi);
-            else if (p.act == PTGNN_AMD_ACT_RELU) store_block<PTGNN_AMD_ACT_RELU>(acc[n], yp, p.ld_msg, 0.f, e_row0, n_edges, hi);
-            else store_block<PTGNN_AMD_ACT_NONE>(acc[n], yp, p.ld_msg, 0.f, e_row0, n_edges, hi);
+          if (n * 32 < p.M) {   // host guarantees 16-byte aligned message rows
+            float *yb = p.msg + out_row0 * p.ld_msg + n * 32;
+            const int64_t left = n_edges - e_row0;
+            if (p.act == PTGNN_AMD_ACT_TANH) store_block_tq<PTGNN_AMD_ACT_TANH>(acc[n], tq, yb, p.ld_msg, 0.f, left, lane, li, hi);
+            else if (p.act == PTGNN_AMD_ACT_RELU) store_block_tq<PTGNN_AMD_ACT_RELU>(acc[n], tq, yb, p.ld_msg, 0.f, left, lane, li, hi);
+            else store_block_tq<PTGNN_AMD_ACT_NONE>(acc[n], tq, yb, p.ld_msg, 0.f, left, lane, li, hi);
           }
           acc[n] = zero16();
         }
@@ -706,11 +767,11 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
     if (!split && (units < (int64_t)num_compute_units() * 8 * 3 || (n_out + bn - 1) / bn > 4)) return 0;
   }
   size_t slab = split ? Slab<true>::bytes(k, bn) : Slab<false>::bytes(k, bn);
-  if (split && slab + 16 > (size_t)kLdsBudget) {   // three bf16 planes do not fit: this shape stays exact fp32
+  if (split && slab + kEpiBytes > (size_t)kLdsBudget) {   // three bf16 planes do not fit: this shape stays exact fp32
     split = false;
     slab = Slab<false>::bytes(k, bn);
   }
-  const size_t lds = slab + 16;
+  const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
   if (lds > (size_t)kLdsBudget) return 0;
   LinearArgs p;
   p.x = x; p.rows = rows; p.K = k; p.ld_x = ld_x; p.w = w; p.n_out = n_out; p.bias = bias; p.act = act;
@@ -719,6 +780,7 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   p.ncs = (n_out + bn - 1) / bn;
   dense_runs(p.nrb, p.ncs, p.rps, p.run_len);
   p.lds_floats = (int)(slab / 4);
+  p.vec_store = (ld_y % 4 == 0 && aligned16(y)) ? 1 : 0;
   const unsigned grid = (unsigned)(p.ncs * p.rps);
 #define PTGNN_K(NBV, SP)                                                            \
   do {                                                                              \
@@ -736,18 +798,18 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
                float *out, int64_t ld_out, float *gates, hipStream_t st) {
   const int mode = stream_gemm_mode();
   if (mode == 0) return 0;
-  if (m % 64 != 0 || hd % 64 != 0 || ld_a % 4 != 0 || ld_h % 4 != 0 || !aligned16(a) || !aligned16(h) ||
-      !aligned16(w_ih) || !aligned16(w_hh))
+  if (m % 64 != 0 || hd % 64 != 0 || ld_a % 4 != 0 || ld_h % 4 != 0 || ld_out % 4 != 0 || !aligned16(a) ||
+      !aligned16(h) || !aligned16(out) || (gates && !aligned16(gates)) || !aligned16(w_ih) || !aligned16(w_hh))
     return 0;
   if (n >= ((int64_t)1 << 31) * 32) return 0;
   bool split = mode == 2;
   const int K = m + hd;
   size_t slab = split ? Slab<true>::bytes(K, 96) : Slab<false>::bytes(K, 96);
-  if (split && slab + 16 > (size_t)kLdsBudget) {
+  if (split && slab + kEpiBytes > (size_t)kLdsBudget) {
     split = false;
     slab = Slab<false>::bytes(K, 96);
   }
-  const size_t lds = slab + 16;
+  const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
   if (lds > (size_t)kLdsBudget) return 0;
   GruArgs p;
   p.a = a; p.ld_a = ld_a; p.h = h; p.ld_h = ld_h; p.w_ih = w_ih; p.w_hh = w_hh; p.b_ih = b_ih; p.b_hh = b_hh;
@@ -774,13 +836,13 @@ static int edge_plan(int32_t state_dim, int32_t msg_dim, int use_dst, size_t *sl
   if (mode == 0) return 0;
   const int K = use_dst ? 2 * state_dim : state_dim;
   if (K % 64 != 0 || state_dim % 32 != 0 || msg_dim % 32 != 0 || msg_dim > 128) return 0;
-  if (mode == 2 && Slab<true>::bytes(K, msg_dim) + 16 <= (size_t)kLdsBudget) {
+  if (mode == 2 && Slab<true>::bytes(K, msg_dim) + kEpiBytes <= (size_t)kLdsBudget) {
     *slab_bytes = Slab<true>::bytes(K, msg_dim);
     return 2;
   }
   // exact fp32: measured equal to the tile kernel at K = 128 and 3 % behind it at K = 256 (one 8-wave
   // workgroup per CU re-loading a 133 KB slab per edge-type segment)
-  if (K <= 128 && Slab<false>::bytes(K, msg_dim) + 16 <= (size_t)kLdsBudget) {
+  if (K <= 128 && Slab<false>::bytes(K, msg_dim) + kEpiBytes <= (size_t)kLdsBudget) {
     *slab_bytes = Slab<false>::bytes(K, msg_dim);
     return 1;
   }
@@ -800,7 +862,7 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   if (kind == 0) return 0;
   const bool split = kind == 2;
   const int nb = msg_dim / 32;
-  const size_t lds = slab + 16;
+  const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
   const int total = tab.unit_off[tab.num_types];
   if (total == 0) return 1;
   EdgeArgs p;
