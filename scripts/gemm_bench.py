@@ -27,18 +27,13 @@ def clock(fn, n=20, w=5):
     return min(ts), sorted(ts)[1]
 
 
-VARIANTS = [("m0", 0, None), ("m1", 1, None), ("m1_nodephase", 1, "0"), ("m2", 2, None), ("m2_nodephase", 2, "0")]
+VARIANTS = [("m0", 0), ("m1", 1), ("m2", 2)]
 
 
 def variants():
-    for name, mode, dephase in VARIANTS:
+    for name, mode in VARIANTS:
         ops.set_gemm_mode(mode)
-        if dephase is None:
-            os.environ.pop("PTGNN_AMD_DEPHASE", None)
-        else:
-            os.environ["PTGNN_AMD_DEPHASE"] = dephase
         yield name
-    os.environ.pop("PTGNN_AMD_DEPHASE", None)
 
 
 def main():
