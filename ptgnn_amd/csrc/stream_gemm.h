@@ -14,6 +14,7 @@ struct StreamEdgeTable {
   const float *w[kStreamMaxTypes];
   int64_t edge_off[kStreamMaxTypes + 1];   // prefix of edges (global message row of the type's edge 0)
   int32_t unit_off[kStreamMaxTypes + 1];   // prefix of 32-edge units
+  int32_t wg_off[kStreamMaxTypes + 1];     // prefix of workgroups apportioned to each type (filled by stream_edge)
   int32_t num_types;
 };
 

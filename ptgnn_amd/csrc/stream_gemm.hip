@@ -596,9 +596,21 @@ template <int NB, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_stream_edge(EdgeArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 512, BN = 32 * NB;
-  const int total = p.tab.unit_off[p.tab.num_types];
-  int u = blockIdx.x * p.run_len;
-  const int u_end = u + p.run_len < total ? u + p.run_len : total;
+  // Workgroups are apportioned to edge types in proportion to their units, and a type's units are split evenly
+  // over its workgroups: no run crosses a type boundary (a mid-run slab reload + barrier made the ~T affected
+  // workgroups the stragglers that set the kernel time).
+  int u, u_end;
+  {
+    int lo = 0, hi_t = p.tab.num_types;
+    while (hi_t - lo > 1) {
+      const int mid = (lo + hi_t) >> 1;
+      if (p.tab.wg_off[mid] <= (int)blockIdx.x) lo = mid; else hi_t = mid;
+    }
+    const int64_t w = p.tab.wg_off[lo + 1] - p.tab.wg_off[lo], part = (int)blockIdx.x - p.tab.wg_off[lo];
+    const int64_t units = p.tab.unit_off[lo + 1] - p.tab.unit_off[lo];
+    u = p.tab.unit_off[lo] + (int)(part * units / w);
+    u_end = p.tab.unit_off[lo] + (int)((part + 1) * units / w);
+  }
   if (u >= u_end) return;
   const int K = p.use_dst ? 2 * p.H : p.H;
   const Slab<SPLIT> sl(K, BN);
@@ -840,9 +852,8 @@ static int edge_plan(int32_t state_dim, int32_t msg_dim, int use_dst, size_t *sl
     *slab_bytes = Slab<true>::bytes(K, msg_dim);
     return 2;
   }
-  // exact fp32: measured equal to the tile kernel at K = 128 and 3 % behind it at K = 256 (one 8-wave
-  // workgroup per CU re-loading a 133 KB slab per edge-type segment)
-  if (K <= 128 && Slab<false>::bytes(K, msg_dim) + kEpiBytes <= (size_t)kLdsBudget) {
+  // exact fp32: 12 % ahead of the tile kernel at K = 128 and 9 % at K = 256 (cfg3's last layer, 133 KB slab)
+  if (Slab<false>::bytes(K, msg_dim) + kEpiBytes <= (size_t)kLdsBudget) {
     *slab_bytes = Slab<false>::bytes(K, msg_dim);
     return 1;
   }
@@ -868,11 +879,42 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   EdgeArgs p;
   p.tab = tab; p.x = x; p.ld_x = ld_x; p.H = state_dim; p.use_dst = use_dst; p.M = msg_dim; p.act = act;
   p.msg = msg; p.ld_msg = ld_msg; p.msg_row_base = msg_row_base; p.num_rows = num_rows;
-  const int max_wg = num_compute_units();
-  p.run_len = (total + max_wg - 1) / max_wg;
-  if (p.run_len < 8) p.run_len = 8;   // at least one unit per wave
+  // apportion the workgroups (one per CU) to the edge types: proportional start, then hand the spare ones to /
+  // take the excess from the type whose load per workgroup moves the maximum least
+  int budget = num_compute_units();
+  if (budget > total / 8 + 1) budget = total / 8 + 1;      // at least ~one unit per wave
+  int w[kStreamMaxTypes], sum = 0, nonempty = 0;
+  for (int t = 0; t < tab.num_types; ++t) {
+    const int64_t u_t = tab.unit_off[t + 1] - tab.unit_off[t];
+    w[t] = u_t == 0 ? 0 : (int)(u_t * budget / total);
+    if (u_t > 0 && w[t] == 0) w[t] = 1;
+    sum += w[t];
+    nonempty += u_t > 0;
+  }
+  if (budget < nonempty) budget = nonempty;
+  while (sum != budget) {
+    int best = -1;
+    double best_v = 0.0;
+    for (int t = 0; t < tab.num_types; ++t) {
+      const double u_t = (double)(tab.unit_off[t + 1] - tab.unit_off[t]);
+      if (u_t == 0) continue;
+      if (sum < budget) {                       // give to the most loaded
+        const double v = u_t / w[t];
+        if (best < 0 || v > best_v) { best = t; best_v = v; }
+      } else if (w[t] > 1) {                    // take where the load after the cut stays smallest
+        const double v = u_t / (w[t] - 1);
+        if (best < 0 || v < best_v) { best = t; best_v = v; }
+      }
+    }
+    if (best < 0) break;
+    w[best] += sum < budget ? 1 : -1;
+    sum += sum < budget ? 1 : -1;
+  }
+  p.tab.wg_off[0] = 0;
+  for (int t = 0; t < tab.num_types; ++t) p.tab.wg_off[t + 1] = p.tab.wg_off[t] + w[t];
+  p.run_len = 0;
   p.lds_floats = (int)(slab / 4);
-  const unsigned grid = (unsigned)((total + p.run_len - 1) / p.run_len);
+  const unsigned grid = (unsigned)p.tab.wg_off[tab.num_types];
 #define PTGNN_K(NBV, SP)                                      \
   do {                                                        \
     auto kern = k_stream_edge<NBV, SP>;                       \
