@@ -567,6 +567,9 @@ def sharded_cfg5(dev, rank, world, k=5):
         with torch.no_grad():
             return sharded.layer_forward(layer, state)
     dt = _clock_collective(step, k, 2, world, dev)
+    state["overlap"] = True      # two-block mode: own-source block aggregated under the halo all-to-all
+    dt2 = _clock_collective(step, k, 2, world, dev)
+    state["overlap"] = False
     shard = sharded.ShardedGraph.build(state["adj_global"], state["range"], all_ranges=state["all_ranges"])
     y = torch.empty(N, H, device=dev)
     t_x = 0.0 if shard.no_cut else _clock_collective(lambda: shard.exchange(y), k, 2, world, dev)
@@ -574,6 +577,7 @@ def sharded_cfg5(dev, rank, world, k=5):
     return {"workload": f"cfg5 shard x{world}: one power-law graph of {world} x 1.25M nodes, 12.5M in-edges per GPU, "
                         f"sources uniform over all GPUs ({world - 1}/{world} of the edges cut), 1 GGNN layer H=M=256, sum",
             "ms_per_step": round(dt * 1e3, 3), "edges_per_sec_per_layer": round(E * world / dt, 1),
+            "ms_per_step_two_block_overlap": round(dt2 * 1e3, 3),
             "halo_rows_all_ranks": int(halo), "halo_bytes_per_layer_all_ranks": int(halo) * H * 4,
             "all_to_all_ms": round(t_x * 1e3, 3), "no_cut": bool(shard.no_cut)}
 
@@ -612,17 +616,22 @@ def sharded_cfg4(dev, rank, world, k=5):
     def step():
         ops.clear_plan_cache()
         with torch.no_grad():
-            shard = sharded.ShardedGraph.build(mine, (lo, hi), all_ranges=ranges)
+            shard = sharded.ShardedGraph.build(mine, (lo, hi), all_ranges=ranges, overlap=holder.get("overlap", False))
             shard.attach_graph_index(n2g_local, mb["num_graphs"])
             holder["shard"] = shard
             return sharded.run_stack(mods, x, shard)
     dt = _clock_collective(step, k, 2, world, dev)
+    holder["overlap"] = True
+    dt2 = _clock_collective(step, k, 2, world, dev)
+    holder["overlap"] = False
+    step()
     shard = holder["shard"]
     halo = sum_over_ranks(shard.n_halo, world, dev)
     edges = sum_over_ranks(e_mine, world, dev)
     return {"workload": f"cfg4 sharded x{world}: VarMisuse batch N={n}, T=21, E={int(edges)}, 8 MLP-MP layers hidden 64 "
                         "(+ residuals), dst ranges balanced by in-edge mass, forward_sharded per layer",
-            "ms_per_forward": round(dt * 1e3, 3), "edges_per_sec_per_layer": round(edges / (dt / 8), 1),
+            "ms_per_forward": round(dt * 1e3, 3), "ms_per_forward_two_block_overlap": round(dt2 * 1e3, 3),
+            "edges_per_sec_per_layer": round(edges / (dt / 8), 1),
             "edges_per_sec_readme_convention": round(edges / dt, 1), "halo_rows_all_ranks": int(halo),
             "halo_bytes_per_layer_all_ranks": int(halo) * H * 4, "no_cut": bool(shard.no_cut)}
 

@@ -140,6 +140,11 @@ def _dropout_seed() -> int:
 _AMP_DTYPES = (torch.float16, torch.bfloat16)
 
 
+def _overlap_reduces():
+    from ptgnn_amd import sharded
+    return sharded.OVERLAP_REDUCES
+
+
 def _run_mlp(mlp: "MLP", x: torch.Tensor) -> torch.Tensor:
     """ptgnn/neuralmodels/mlp.py:79-80 with every nn.Linear on the HIP GEMM (general per-edge path)."""
     for m in mlp.modules_in_order:
@@ -326,7 +331,7 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
         p = self.__dropout.p if self.training else 0.0
         ws = [l.weight for l in self.__edge_message_transformation_layers]
         table_rows = shard.n_local + (shard.n_halo if T * M > H else 0)
-        edge_form = _prefer_edge_path(shard.plan.num_edges, table_rows, T, H, M)
+        edge_form = _prefer_edge_path(shard.num_edges, table_rows, T, H, M)
         if not self._fused_ok(node_states, feats):
             # training.  Edge form: differentiable halo exchange (backward = transposed all-to-all + HIP
             # segment-sum) -> grouped per-edge GEMM node with the hash dropout folded in -> HIP segment reduce
@@ -347,7 +352,36 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                 y = dense.linear(shard.exchange_autograd(node_states), w)
             agg = gather_reduce_autograd(y, None, shard.plan, M, self.__aggregation_fn)
             return dense.gru_cell(gru, agg, node_states)
-        if edge_form:
+        if shard.overlap and self.__aggregation_fn in _overlap_reduces():
+            # two-block mode: the own-source block aggregates while the halo rows travel (sharded.py)
+            from ptgnn_amd import sharded
+            n = shard.n_local
+            if edge_form or T * M > H:      # node states travel
+                table = shard.new_table(H, node_states)
+                table[:n].copy_(node_states)
+                work = shard.begin_exchange(table)
+                if edge_form:
+                    def table_of(block):
+                        adj, plan = (shard.adj_own, shard.plan_own) if block == "own" else (shard.adj_halo, shard.plan_halo)
+                        return ops.edge_linear(table, adj, ws, False), plan.perm, 0
+                else:
+                    w = self._stacked_edge_weights()
+                    y = shard.new_table(T * M, node_states)
+                    ops.linear(node_states, w, out=y[:n])
+
+                    def table_of(block):
+                        if block == "halo":
+                            ops.linear(table[n:], w, out=y[n:])
+                        return y, None, None
+            else:                           # message-table rows travel
+                y = shard.new_table(T * M, node_states)
+                ops.linear(node_states, self._stacked_edge_weights(), out=y[:n])
+                work = shard.begin_exchange(y)
+
+                def table_of(block):
+                    return y, None, None
+            agg = sharded.aggregate_two_blocks(shard, work, table_of, M, self.__aggregation_fn)
+        elif edge_form:
             table = shard.exchange(node_states)
             msgs = ops.edge_linear(table, shard.local_adj, ws, False)
             agg = ops.gather_reduce(msgs, shard.plan, M, self.__aggregation_fn, type_bits=0, col=shard.plan.perm)
@@ -455,23 +489,28 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             return False
         return (not torch.is_grad_enabled()) or _no_grad_needed(node_states, *self.parameters())
 
-    def _aggregate_and_update(self, ysrc, ydst, plan, col=None, type_bits=None) -> torch.Tensor:
+    def _aggregate_and_update(self, ysrc, ydst, plan, col=None, type_bits=None, two_block=None) -> torch.Tensor:
         """Fused gather/reduce with GELU + LayerNorm folded into the kernel epilogue when the
-        layer's activation/normalisation are the stock ones, then the dense update."""
+        layer's activation/normalisation are the stock ones, then the dense update.  `two_block` =
+        (shard, work, table_of): the sharded two-block aggregation instead (epilogue in its combine pass)."""
         M = self._message_dimension
         act = self.__message_activation
         gelu_ok = act is None or (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none")
         ln_ok = self._ln is None or (M <= 512 and self._ln.elementwise_affine and self._ln.bias is not None)
-        if gelu_ok and ln_ok:
-            epi = (ops.EPI_GELU if act is not None else 0) | (ops.EPI_LAYERNORM if self._ln is not None else 0)
-            agg = ops.gather_reduce(
-                ysrc, plan, M, self.__aggregation_fn, ydst=ydst, epilogue=epi,
-                ln_weight=self._ln.weight if self._ln is not None else None,
-                ln_bias=self._ln.bias if self._ln is not None else None,
-                ln_eps=self._ln.eps if self._ln is not None else 1e-5, col=col, type_bits=type_bits)
-            return self._update(agg, True)
-        agg = ops.gather_reduce(ysrc, plan, M, self.__aggregation_fn, ydst=ydst, col=col, type_bits=type_bits)
-        return self._update(agg, False)
+        fused = gelu_ok and ln_ok
+        epi = {}
+        if fused:
+            epi = dict(epilogue=(ops.EPI_GELU if act is not None else 0) | (ops.EPI_LAYERNORM if self._ln is not None else 0),
+                       ln_weight=self._ln.weight if self._ln is not None else None,
+                       ln_bias=self._ln.bias if self._ln is not None else None,
+                       ln_eps=self._ln.eps if self._ln is not None else 1e-5)
+        if two_block is not None:
+            from ptgnn_amd import sharded
+            shard, work, table_of = two_block
+            agg = sharded.aggregate_two_blocks(shard, work, table_of, M, self.__aggregation_fn, ydst=ydst, **epi)
+        else:
+            agg = ops.gather_reduce(ysrc, plan, M, self.__aggregation_fn, ydst=ydst, col=col, type_bits=type_bits, **epi)
+        return self._update(agg, fused)
 
     def forward_sharded(self, node_states: torch.Tensor, shard) -> torch.Tensor:
         """One layer over a dst-range shard (ptgnn_amd/sharded.py).  Table form: the source term rides the halo
@@ -488,7 +527,7 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
         use_dst = self.__use_target_state_as_message_input
         ws = [m.linears[0].weight for m in self.__edge_message_transformation_layers]
         table_rows = shard.n_local + (shard.n_halo if T * M > H else 0)
-        edge_form = _prefer_edge_path(shard.plan.num_edges, table_rows, T, H, M)
+        edge_form = _prefer_edge_path(shard.num_edges, table_rows, T, H, M)
         if not self._fused_ok(node_states, feats):
             if edge_form and _edge_training_ok(H, M):
                 table = shard.exchange_autograd(node_states)
@@ -505,6 +544,36 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
                 ydst = dense.linear(node_states, torch.cat([w[:, H:2 * H] for w in ws], dim=0))
             agg = gather_reduce_autograd(ysrc, ydst, shard.plan, M, self.__aggregation_fn)
             return self._update(agg, False)
+        if shard.overlap and self.__aggregation_fn in _overlap_reduces():
+            n = shard.n_local
+            w = self._stacked_edge_weights()
+            ydst = None
+            if edge_form or T * M > H:      # node states travel
+                table = shard.new_table(H, node_states)
+                table[:n].copy_(node_states)
+                work = shard.begin_exchange(table)
+                if edge_form:
+                    def table_of(block):
+                        adj, plan = (shard.adj_own, shard.plan_own) if block == "own" else (shard.adj_halo, shard.plan_halo)
+                        return ops.edge_linear(table, adj, ws, use_dst), plan.perm, 0
+                else:
+                    ysrc = shard.new_table(T * M, node_states)
+                    ops.linear(node_states, w[: T * M], out=ysrc[:n])
+
+                    def table_of(block):
+                        if block == "halo":
+                            ops.linear(table[n:], w[: T * M], out=ysrc[n:])
+                        return ysrc, None, None
+            else:                           # message-table rows travel
+                ysrc = shard.new_table(T * M, node_states)
+                ops.linear(node_states, w[: T * M], out=ysrc[:n])
+                work = shard.begin_exchange(ysrc)
+
+                def table_of(block):
+                    return ysrc, None, None
+            if use_dst and not edge_form:
+                ydst = ops.linear(node_states, w[T * M:])
+            return self._aggregate_and_update(None, ydst, None, two_block=(shard, work, table_of))
         if edge_form:
             table = shard.exchange(node_states)
             msgs = ops.edge_linear(table, shard.local_adj, ws, use_dst)

@@ -472,8 +472,9 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
                   ydst: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
                   ln_weight: Optional[torch.Tensor] = None, ln_bias: Optional[torch.Tensor] = None,
                   ln_eps: float = 1e-5, return_arg: bool = False, type_bits: Optional[int] = None,
-                  col: Optional[torch.Tensor] = None):
-    """out[v] = EPI(reduce_{slots of v} ysrc[src, t*M:(t+1)*M] (+ ydst[v, t*M:(t+1)*M]))."""
+                  col: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """out[v] = EPI(reduce_{slots of v} ysrc[src, t*M:(t+1)*M] (+ ydst[v, t*M:(t+1)*M])).
+    `out`: optional caller-owned [num_nodes, msg_dim] fp32 destination (e.g. one half of a stacked buffer)."""
     lib = _lib.load()
     _require_cuda_f32("ysrc", ysrc)
     ysrc = _rowmajor(ysrc)
@@ -486,7 +487,10 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
     if reduce not in REDUCE_IDS:
         raise ValueError(f"unknown aggregation function {reduce!r}")
     N = plan.num_nodes
-    out = torch.empty(N, msg_dim, dtype=torch.float32, device=ysrc.device)
+    if out is None:
+        out = torch.empty(N, msg_dim, dtype=torch.float32, device=ysrc.device)
+    elif tuple(out.shape) != (N, msg_dim) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise _lib.PtgnnAmdError(f"gather_reduce: `out` must be a contiguous float32 [{N}, {msg_dim}] tensor")
     arg = None
     if return_arg:
         arg = torch.empty(N, msg_dim, dtype=torch.int32, device=ysrc.device)

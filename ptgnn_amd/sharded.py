@@ -22,6 +22,8 @@ the compute stays in the HIP kernels and refuses CPU tensors.
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -59,24 +61,36 @@ class ShardedGraph:
         self.send_splits: List[int] = []
         self.recv_splits: List[int] = []
         self.local_adj: Adj = []
-        self.plan: Optional["ops.GraphPlan"] = None
+        self._plan: Optional["ops.GraphPlan"] = None
         self.group = None
         self.no_cut = False    # True when NO rank has a remote source: the exchange is skipped entirely
         # global-exchange layers (globalgraphexchange.py): graph id of every OWN node (global graph ids) and the
         # number of graphs of the whole batch; set by the caller (`attach_graph_index`)
         self.node_to_graph_idx: Optional[torch.Tensor] = None
         self.num_graphs: int = 0
+        # two-block mode (`overlap=True`): edges split by where their SOURCE lives, so the own-source block can be
+        # aggregated while the halo all-to-all is in flight (SURVEY.md 8e "two CSR blocks")
+        self.overlap = False
+        self.adj_own: Adj = []
+        self.adj_halo: Adj = []
+        self.plan_own: Optional["ops.GraphPlan"] = None
+        self.plan_halo: Optional["ops.GraphPlan"] = None
+        self.plan_comb: Optional["ops.GraphPlan"] = None
 
     # -- construction ---------------------------------------------------------------------------
     @staticmethod
     def build(adjacency_lists: Adj, node_range: Tuple[int, int], group=None,
-              build_plan: bool = True, all_ranges: Optional[Sequence[Tuple[int, int]]] = None
-              ) -> "ShardedGraph":
+              build_plan: bool = True, all_ranges: Optional[Sequence[Tuple[int, int]]] = None,
+              overlap: Optional[bool] = None) -> "ShardedGraph":
         """adjacency_lists: int64 (src, dst) per edge type in GLOBAL node ids, holding exactly the
         edges whose dst lies in this rank's `node_range`.  `all_ranges` (every rank's range, in rank
-        order) skips the all-gather when the partition is static."""
+        order) skips the all-gather when the partition is static.  `overlap` (default: env
+        PTGNN_AMD_SHARD_OVERLAP, off): split the edges into an own-source and a halo-source block so that
+        inference layers aggregate the first while the halo rows travel (see `aggregate_two_blocks`)."""
         g = ShardedGraph()
         g.group = group
+        if overlap is None:
+            overlap = os.environ.get("PTGNN_AMD_SHARD_OVERLAP", "0") not in ("", "0")
         g.rank, g.world = dist.get_rank(group), dist.get_world_size(group)
         g.lo, g.hi = int(node_range[0]), int(node_range[1])
         g.n_local = g.hi - g.lo
@@ -112,16 +126,20 @@ class ShardedGraph:
         need_counts = g.index_locally(adjacency_lists)                # device int64 [world], no host sync yet
         got_counts = torch.empty_like(need_counts)
         dist.all_to_all_single(got_counts, need_counts, group=group)
-        # ONE host read-back per minibatch: all_to_all_single wants its split sizes as host ints
-        both = torch.cat([need_counts, got_counts]).tolist()
+        # ONE host read-back per minibatch: all_to_all_single wants its split sizes as host ints (and the
+        # two-block mode its per-type own-source edge counts)
+        extra = [g.own_source_counts(adjacency_lists)] if overlap else []
+        both = torch.cat([need_counts, got_counts] + extra).tolist()
         g.recv_splits = [int(v) for v in both[: g.world]]            # halo rows I receive per owner
-        g.send_splits = [int(v) for v in both[g.world:]]             # rows I send per peer
+        g.send_splits = [int(v) for v in both[g.world: 2 * g.world]]  # rows I send per peer
         g.n_halo = sum(g.recv_splits)
         g.finish_local_index()
+        if overlap:
+            g.split_blocks([int(v) for v in both[2 * g.world:]])
         wanted = torch.empty(sum(g.send_splits), dtype=torch.int64, device=dev)
         dist.all_to_all_single(wanted, g.need_ids, g.send_splits, g.recv_splits, group=group)
         g.send_ids = wanted - g.lo                                    # owners trust their peers' requests
-        if build_plan:
+        if build_plan and not overlap:
             g.build_plan()
         return g
 
@@ -174,8 +192,65 @@ class ShardedGraph:
             self.local_adj.append((ls.contiguous(), (d - self.lo).contiguous()))
         self._slot = self._mark = self._adj_global = None
 
+    # -- two-block mode -----------------------------------------------------------------------------
+    def own_source_counts(self, adjacency_lists: Adj) -> torch.Tensor:
+        """int64 [T] on the device: edges per type whose source is an own row."""
+        dev = adjacency_lists[0][0].device
+        return torch.stack([((s >= self.lo) & (s < self.hi)).sum() if s.numel() else
+                            torch.zeros((), dtype=torch.int64, device=dev) for s, _ in adjacency_lists])
+
+    def split_blocks(self, own_counts: Sequence[int]) -> None:
+        """Per type: own-source edges first, then halo-source edges (stable), as two adjacency lists over the SAME
+        local table [own rows | halo rows]; one plan per block and the 2-slot plan that combines the two partial
+        aggregates.  Uses the host counts that came back with the split sizes: no further synchronisation."""
+        n = self.n_local
+        self.adj_own, self.adj_halo = [], []
+        for (ls, ld), c in zip(self.local_adj, own_counts):
+            order = torch.sort((ls >= n).to(torch.int8), stable=True).indices
+            ls, ld = ls[order], ld[order]
+            self.adj_own.append((ls[:c].contiguous(), ld[:c].contiguous()))
+            self.adj_halo.append((ls[c:].contiguous(), ld[c:].contiguous()))
+        self.overlap = True
+        if ls.is_cuda:
+            rows = n + self.n_halo
+            self.plan_own = ops.build_plan(self.adj_own, n, num_src_rows=rows)
+            self.plan_halo = ops.build_plan(self.adj_halo, n, num_src_rows=rows)
+            self.plan_comb = self._combine_plan(self.plan_own.rowptr, self.plan_halo.rowptr)
+
+    def _combine_plan(self, rowptr_own: torch.Tensor, rowptr_halo: torch.Tensor) -> "ops.GraphPlan":
+        """Plan over the stacked partial table [agg_own ; agg_halo] (2 n rows): row v reduces slot v if the own
+        block has an edge into v and slot n + v if the halo block has one.  Blocks WITHOUT an edge into v are left
+        out, so their torch_scatter-style 0 can never win a max over negative values; a row with no edge in either
+        block stays empty and yields 0.  Built with prefix sums and scatters only (no host read-back)."""
+        n = self.n_local
+        dev = rowptr_own.device
+        has_o = (rowptr_own[1:] > rowptr_own[:-1])
+        has_h = (rowptr_halo[1:] > rowptr_halo[:-1])
+        cnt = has_o.to(torch.int32) + has_h.to(torch.int32)
+        rowptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        torch.cumsum(cnt, 0, out=rowptr[1:])
+        v = torch.arange(n, dtype=torch.int64, device=dev)
+        start = rowptr[:-1].to(torch.int64)
+        col = torch.zeros(2 * n + 1, dtype=torch.int32, device=dev)       # last element: dump slot
+        col.scatter_(0, torch.where(has_o, start, torch.full_like(start, 2 * n)), v.to(torch.int32))
+        col.scatter_(0, torch.where(has_h, start + has_o.to(torch.int64), torch.full_like(start, 2 * n)),
+                     (v + n).to(torch.int32))
+        plan = ops.GraphPlan(rowptr, col, col, 0, n, 2 * n, 1)
+        plan.num_src_rows = 2 * n
+        return plan
+
+    def begin_exchange(self, table: torch.Tensor):
+        """Start the halo all-to-all into table[n_local:] (table[:n_local] holds this rank's rows) and return the
+        work handle; `wait()` on it orders the CURRENT stream behind the arrival -- kernels launched in between
+        (the own-source block) run while the rows travel over xGMI."""
+        own = table[: self.n_local]
+        send = ops.gather_rows(own, self.send_ids) if own.is_cuda else own.index_select(0, self.send_ids)
+        return dist.all_to_all_single(table[self.n_local:], send, self.recv_splits, self.send_splits,
+                                      group=self.group, async_op=True)
+
     @staticmethod
-    def build_local(adjacency_lists: Adj, all_ranges: Sequence[Tuple[int, int]], rank: int) -> "ShardedGraph":
+    def build_local(adjacency_lists: Adj, all_ranges: Sequence[Tuple[int, int]], rank: int,
+                    overlap: bool = False) -> "ShardedGraph":
         """Collective-free construction of ONE rank's view (no process group): everything `build` derives from
         this rank's own edges -- halo ids, remapped adjacency, plan.  The send side (`send_ids`) needs the peers
         and stays empty, so this serves single-process simulations of a sharded run (tests, dry runs) where
@@ -191,12 +266,27 @@ class ShardedGraph:
         g.finish_local_index()
         g.send_splits = [0] * g.world
         g.send_ids = g.need_ids[:0]
+        own_counts = [int(v) for v in g.own_source_counts(adjacency_lists).tolist()] if overlap else None
         if adjacency_lists[0][0].is_cuda:
             g.build_plan()
+        if overlap:
+            g.split_blocks(own_counts)
         return g
 
     def build_plan(self) -> None:
-        self.plan = ops.build_plan(self.local_adj, self.n_local, num_src_rows=self.n_local + self.n_halo)
+        self._plan = ops.build_plan(self.local_adj, self.n_local, num_src_rows=self.n_local + self.n_halo)
+
+    @property
+    def plan(self) -> Optional["ops.GraphPlan"]:
+        """The single-block plan over the local table; in two-block mode it is only built when a layer asks for
+        it (training, mean aggregation)."""
+        if self._plan is None and self.overlap and self.local_adj and self.local_adj[0][0].is_cuda:
+            self.build_plan()
+        return self._plan
+
+    @property
+    def num_edges(self) -> int:
+        return sum(int(a[0].shape[0]) for a in self.local_adj)
 
     # -- per-layer exchange -----------------------------------------------------------------------
     def new_table(self, dim: int, like: torch.Tensor) -> torch.Tensor:
@@ -260,6 +350,35 @@ class _HaloExchange(torch.autograd.Function):
         return d_own + extra, None
 
 
+OVERLAP_REDUCES = ("sum", "add", "max", "min")   # mean of partial means is not the mean: it takes the plain path
+
+
+def aggregate_two_blocks(shard: "ShardedGraph", work, table_of, msg_dim: int, reduce: str, ydst=None, **epilogue):
+    """The two-block aggregation of one layer (inference):
+
+        work = shard.begin_exchange(...)                     halo rows start travelling
+        part[:n] = aggregate(own-source block)               runs under the exchange
+        work.wait()                                          current stream waits for the halo rows
+        part[n:] = aggregate(halo-source block)
+        out      = REDUCE over the (<= 2) non-empty partials of every row, with the row epilogue
+
+    `table_of(block)` returns (message table, col, type_bits) for block "own" / "halo" -- called for "halo" only
+    after the wait, so it may read the halo rows.  The combine is the same HIP gather/segment-reduce kernel over
+    the stacked partial table: max / min stay exact; a sum becomes (own partial) + (halo partial), i.e. not the
+    unsharded fold order (|delta| ~ 1e-7) -- which is why the mode is opt-in."""
+    n = shard.n_local
+    part = None
+    for block, plan in (("own", shard.plan_own), ("halo", shard.plan_halo)):
+        if block == "halo" and work is not None:
+            work.wait()
+        tab, col, tb = table_of(block)
+        if part is None:
+            part = torch.empty(2 * n, msg_dim, dtype=torch.float32, device=tab.device)
+        ops.gather_reduce(tab, plan, msg_dim, reduce, ydst=ydst, col=col, type_bits=tb,
+                          out=part[:n] if block == "own" else part[n:])
+    return ops.gather_reduce(part, shard.plan_comb, msg_dim, reduce, type_bits=0, **epilogue)
+
+
 # ------------------------------------------------------------------------------------------------
 # bench / test helpers
 # ------------------------------------------------------------------------------------------------
@@ -288,10 +407,11 @@ def layer_forward(layer, state: Dict) -> torch.Tensor:
     """One sharded message-passing layer: (re)build the shard plan for the minibatch, exchange halo
     rows, aggregate, update.  Nothing is cached across calls (bench.py times the whole thing)."""
     shard = ShardedGraph.build(state["adj_global"], state["range"], build_plan=False,
-                               all_ranges=state.get("all_ranges"))
+                               all_ranges=state.get("all_ranges"), overlap=state.get("overlap"))
     if shard.no_cut:   # no edge crosses a rank boundary: exactly the single-GPU layer on the local block
         return layer(state["x"], shard.local_adj, None, {}, {}, [None] * len(shard.local_adj))
-    shard.build_plan()
+    if not shard.overlap:
+        shard.build_plan()
     return layer.forward_sharded(state["x"], shard)
 
 

@@ -1715,3 +1715,74 @@ def test_odd_widths_and_general_path_run_on_the_hip_kernels(monkeypatch):
         cell = torch.nn.GRUCell(M, H).cuda()
         dense.gru_cell(cell, torch.randn(n, M, device="cuda", requires_grad=True), x.cuda())
     assert calls == [], calls
+
+
+class _DoneWork:
+    def wait(self):
+        return True
+
+
+def _emulate_begin_exchange(shard, global_rows):
+    def begin_exchange(table):
+        table[shard.n_local:] = global_rows().index_select(0, shard.need_ids)
+        return _DoneWork()
+    shard.begin_exchange = begin_exchange
+
+
+@pytest.mark.parametrize("case", ["ggnn_edge_max", "ggnn_edge_sum", "ggnn_table_states_max", "mlp_table_rows_sum",
+                                  "mlp_table_rows_max", "mlp_edge_max", "mlp_table_states_min"])
+def test_sharded_two_block_overlap_mode_equals_unsharded(case, monkeypatch):
+    """`ShardedGraph(overlap=True)`: edges split into an own-source and a halo-source block, two partial
+    aggregations (the first one would run under the halo all-to-all) and a combine pass with the row epilogue.
+    max / min: bit-identical to the unsharded layer; sum: (own partial) + (halo partial) instead of the CSR fold
+    order => within 1e-6.  Every way the rows can travel is covered (node states for the edge form and for wide
+    tables, message-table rows for narrow ones)."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, ops, sharded, workloads
+    H, world = 64, 3
+    kind, form, agg = case.split("_")[0], "_".join(case.split("_")[1:-1]), case.split("_")[-1]
+    # the layer form is picked per (sub)graph from its edge / row counts; pin it so that the shard and the whole
+    # graph take the SAME form (for the MLP layer with target state the two forms differ by fp32 re-association:
+    # one K = 2H chain vs two K = H chains)
+    monkeypatch.setattr(L, "EDGE_PATH_BIAS", 0.0 if form == "edge" else 1e9)
+    if form == "edge":
+        mb = workloads.batched_graphs(6, 700, 8, 2.2, seed=31)
+        n = mb["num_nodes"]
+        adj = O.augment_adjacency(mb["adjacency_lists"], n, True, True)      # T = 17 -> edge form
+    else:
+        n = 3000
+        g = torch.Generator().manual_seed(17)
+        counts = [16000] if form == "table_rows" else [9000, 0, 4000]       # T*M <= H ships message rows
+        adj = [(torch.randint(0, n, (c,), generator=g), torch.randint(0, n, (c,), generator=g)) for c in counts]
+    T = len(adj)
+    x = workloads.node_states(n, H, seed=32).cuda()
+    torch.manual_seed(33)
+    layer = (L.GatedMessagePassingLayer(H, H, T, agg) if kind == "ggnn" else L.MlpMessagePassingLayer(H, H, H, T, agg))
+    layer = layer.cuda().eval()
+    ops.clear_plan_cache()
+    cadj = to_cuda_adj(adj)
+    with torch.no_grad():
+        want = layer(x, cadj, None, {}, {}, empty_feats(cadj, "cuda"))
+    indeg = torch.zeros(n, dtype=torch.int64)
+    for _, d in adj:
+        indeg += torch.bincount(d, minlength=n)
+    ranges = sharded.balanced_node_ranges(indeg, world)
+    outs = []
+    with torch.no_grad():
+        for p, (lo, hi) in enumerate(ranges):
+            mine = [(s[(d >= lo) & (d < hi)].cuda(), d[(d >= lo) & (d < hi)].cuda()) for s, d in adj]
+            sh = sharded.ShardedGraph.build_local(mine, ranges, p, overlap=True)
+            assert sh.overlap and sh.n_halo > 0
+            assert sh.plan_own.num_edges + sh.plan_halo.num_edges == sh.num_edges and sh.plan_halo.num_edges > 0
+            if kind == "mlp" and form == "table_rows":      # message-table rows travel
+                w = layer._stacked_edge_weights()[: T * H]
+                rows = ops.linear(x, w)
+                _emulate_begin_exchange(sh, lambda rows=rows: rows)
+            else:
+                _emulate_begin_exchange(sh, lambda: x)
+            outs.append(layer.forward_sharded(x[lo:hi].contiguous(), sh))
+    got = torch.cat(outs)
+    if agg in ("max", "min"):
+        np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
+    else:
+        assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))

@@ -360,3 +360,74 @@ def test_partial_graph_pools_combine_across_ranks():
         p.join(timeout=60)
     for r in results:
         assert r[1] == "ok", r[1]
+
+
+def _worker_two_blocks(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import scatter_ref
+        from ptgnn_amd import sharded
+        n = 300
+        adj, x = _global_graph(n, [1500, 0, 700], 13)
+        ranges = [(p * n // world, (p + 1) * n // world) for p in range(world)]
+        lo, hi = ranges[rank]
+        mine = [(s[(d >= lo) & (d < hi)], d[(d >= lo) & (d < hi)]) for s, d in adj]
+        shard = sharded.ShardedGraph.build(mine, (lo, hi), build_plan=False, all_ranges=ranges, overlap=True)
+        nl = shard.n_local
+        assert shard.overlap and shard.plan is None          # CPU tensors: plans are the GPU path's business
+        # the two blocks partition this rank's edges by where the source lives, per type, order preserved
+        for (ls, ld), (so, do), (sh_, dh) in zip(shard.local_adj, shard.adj_own, shard.adj_halo):
+            assert bool((so < nl).all()) and bool((sh_ >= nl).all())
+            own_mask = ls < nl
+            assert torch.equal(so, ls[own_mask]) and torch.equal(do, ld[own_mask])
+            assert torch.equal(sh_, ls[~own_mask]) and torch.equal(dh, ld[~own_mask])
+        # async exchange: the own block is aggregated before wait(), the halo block after it
+        table = shard.new_table(x.shape[1], x)
+        table[:nl] = x[lo:hi]
+        work = shard.begin_exchange(table)
+        def agg(block, reduce):
+            msgs = torch.cat([table.index_select(0, s) for s, _ in block])
+            tgt = torch.cat([d for _, d in block])
+            return scatter_ref.scatter(msgs, tgt, dim=0, dim_size=nl, reduce=reduce), torch.bincount(tgt, minlength=nl)
+        own_sum, deg_o = agg(shard.adj_own, "sum")
+        own_max, _ = agg(shard.adj_own, "max")
+        work.wait()
+        halo_sum, deg_h = agg(shard.adj_halo, "sum")
+        halo_max, _ = agg(shard.adj_halo, "max")
+        # combine through the product's 2-slot plan (rowptr / col), evaluated with the oracle scatter
+        plan_rowptr = lambda deg: torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(deg, 0).to(torch.int32)])
+        comb = shard._combine_plan(plan_rowptr(deg_o), plan_rowptr(deg_h))
+        E = int(comb.rowptr[-1])
+        slot_row = torch.repeat_interleave(torch.arange(nl), (comb.rowptr[1:] - comb.rowptr[:-1]).to(torch.int64))
+        gm = torch.cat([x.index_select(0, s) for s, _ in adj])
+        gt = torch.cat([d for _, d in adj])
+        for reduce, parts in (("sum", (own_sum, halo_sum)), ("max", (own_max, halo_max))):
+            stacked = torch.cat(parts)
+            got = scatter_ref.scatter(stacked[comb.col[:E].to(torch.int64)], slot_row, dim=0, dim_size=nl, reduce=reduce)
+            want = scatter_ref.scatter(gm, gt, dim=0, dim_size=n, reduce=reduce)[lo:hi]
+            if reduce == "max":
+                np.testing.assert_array_equal(got.numpy(), want.numpy())
+            else:
+                np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+        out_q.put((rank, "ok", shard.n_halo))
+    except Exception:
+        import traceback
+        out_q.put((rank, traceback.format_exc(), 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_block_split_async_exchange_and_combine_plan_over_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_blocks, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert r[1] == "ok", r[1]
+    assert all(r[2] > 0 for r in results)
