@@ -358,6 +358,7 @@ def pmc_traffic(workload, kernel):
     return {"traffic": None}
 
 
+VARIANT_DEADLINE_S = 240   # wall-clock budget of the sharded cut-edge variants at N > 1
 PARITY_TOL = 1e-5   # BASELINE.json north_star: fp32 node states within 1e-5 of the reference CPU path
 
 
@@ -708,8 +709,23 @@ def main():
                 result[key] = {"error": f"{type(exc).__name__}: {exc}"}
                 break              # ranks may have diverged: do not enter another collective section
     if (world > 1 and not args.no_sharded_variants) or args.sharded_variants:
-        # the north-star split: every rank enters these together; a failure cannot cost the primary line
+        # the north-star split: every rank enters these together; neither a failure nor a hang can cost the
+        # primary line (an exception on one rank leaves its peers inside a collective: every rank therefore
+        # carries a watchdog that prints the line measured so far and ends the process)
+        import threading
         variants = {}
+        result["cut_edges_variant"] = variants
+
+        def bail_out():
+            variants.setdefault("error", f"timed out after {VARIANT_DEADLINE_S} s (a rank failed or a collective hung)")
+            _log("sharded variants timed out: emitting the primary line")
+            if rank == 0:
+                sys.stdout.flush()
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(VARIANT_DEADLINE_S, bail_out)
+        watchdog.daemon = True
+        watchdog.start()
         for key, fn in (("cfg5_shard", sharded_cfg5), ("cfg4_stack", sharded_cfg4)):
             try:
                 _log(f"sharded cut-edge variant {key}")
@@ -717,8 +733,11 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:  # noqa: BLE001
                 variants[key] = {"error": f"{type(exc).__name__}: {exc}"}
-                break              # ranks may have diverged: do not enter another collective section
-        result["cut_edges_variant"] = variants
+                _log(f"variant {key} failed on rank {rank}: {exc}")
+                if world > 1:
+                    threading.Event().wait()   # peers are inside a collective: let the watchdog end every rank
+                break
+        watchdog.cancel()
     if rank == 0 and world == 1 and not args.force_sharded:
         result["repeats"] = repeat_stats(step, args.steps)
         if not args.no_secondary:
