@@ -1142,12 +1142,14 @@ def test_forward_is_hip_graph_capturable():
 
 
 @pytest.mark.parametrize("pool", ["weighted_sum", "max"])
-def test_global_exchange_training_gradients_match_oracle_autograd(pool):
+@pytest.mark.parametrize("sizes", [[700, 1, 1300, 64], [6000, 3, 4500]], ids=["small_graphs", "hub_graphs"])
+def test_global_exchange_training_gradients_match_oracle_autograd(pool, sizes):
     """GruGlobalStateUpdate (globalgraphexchange.py:29-64) in training mode: pooling, broadcast-gather and GRU
-    cell all on the HIP autograd nodes; gradients w.r.t. the node states and the GRU weights vs the oracle."""
+    cell all on the HIP autograd nodes; gradients w.r.t. the node states and the GRU weights vs the oracle.
+    `hub_graphs`: graphs of more than 4096 nodes are hub rows of the sort-free pooling plan
+    (`plan_from_sorted_index` + the chunk-parallel hub kernel), forward and backward."""
     from oracle import mp_oracle as O
     from ptgnn_amd import reduceops as R, workloads
-    sizes = [700, 1, 1300, 64]
     n2g = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
     N, H = int(n2g.shape[0]), 64
     torch.manual_seed(8)
@@ -1170,7 +1172,9 @@ def test_global_exchange_training_gradients_match_oracle_autograd(pool):
     xg = x.cuda().requires_grad_(True)
     yg = mod(xg, [], n2g.cuda(), {}, {}, [])
     yg.backward(gout.cuda())
-    np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=0, atol=TOL)
+    # a hub row (a graph of thousands of nodes) is folded chunk-wise, not in the reference's serial order: its pooled
+    # sum of O(10^3) terms differs by fp32 re-association before it enters the GRU
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=0, atol=TOL * (1 if max(sizes) <= 4096 else 3))
     sc = max(1.0, float(xo.grad.abs().max()))
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=0, atol=2e-5 * sc)
     got_w = mod.state_dict(keep_vars=True)["_GruGlobalStateUpdate__gru_cell.weight_ih"].grad
