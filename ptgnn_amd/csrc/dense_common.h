@@ -95,9 +95,16 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// tanh on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each; absolute error ~1.2e-7): libm tanhf is
+// ~40 VALU instructions per element, and VALU work is not hidden under fp32 MFMAs (profiles/r02_notes.md) -- in the
+// MLP-MP update GEMM (mlpmessagepassing.py:62-63: Tanh after the dense layer) it was a third of the kernel
+__device__ __forceinline__ float fast_tanh(float v) {
+  return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * v)) - 1.0f;
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_apply(float v) {
-  if constexpr (ACT == PTGNN_AMD_ACT_TANH) return tanhf(v);
+  if constexpr (ACT == PTGNN_AMD_ACT_TANH) return fast_tanh(v);
   if constexpr (ACT == PTGNN_AMD_ACT_RELU) return v > 0.f ? v : 0.f;
   return v;
 }

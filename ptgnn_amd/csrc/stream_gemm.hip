@@ -456,9 +456,6 @@ struct GruArgs {
 __device__ __forceinline__ float fast_sigmoid(float v) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
-__device__ __forceinline__ float fast_tanh(float v) {
-  return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * v)) - 1.0f;
-}
 
 template <bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
