@@ -12,7 +12,11 @@
 // (program graphs: T ~ 17-23, E/N ~ 5.4) this kernel needs 2 E H M FLOP (3x less) and writes [E, M].
 // The host picks per minibatch (ptgnn_amd/layers.py).
 //
-// Structure: the occupancy-driven one-tile-per-workgroup fp32-MFMA kernel of dense_f32.hip with
+// Two kernels behind the entry points: the streaming weight-stationary kernel (stream_gemm.hip: `k_stream_edge`,
+// GEMM modes 1 / 2, every shape whose [M, K] weight slab fits LDS) and, here, the 128-row tile kernel for GEMM
+// mode 0, the remaining shapes and the two dropout forms (training).  Both accumulate K in the same order.
+//
+// Structure of the tile kernel: the one-tile-per-workgroup fp32-MFMA kernel of dense_f32.hip with
 //   * a tile -> (edge type, first edge) decode through a small table in the kernel arguments,
 //   * the A-operand row map replaced by the int64 source (and destination) indices of the tile's
 //     128 edges, read straight from ptgnn's adjacency tensors once per tile,

@@ -6,26 +6,32 @@
 // K = 128; GRU gates: 116 k rows x K = 256; MLP update: 200 k rows x K = 128).  The round-1 kernels
 // tiled it like a square GEMM -- 128 x 128 output tile per workgroup, both operands staged through LDS
 // per 32-wide K chunk, two workgroup barriers per chunk -- and landed at 0.64 of the fp32-MFMA peak
-// with "time = t(MFMA) + t(memory)" (profiles/r01_notes.md): co-resident workgroups run in lockstep,
-// so the load/store phases of a tile never hide under another tile's MFMAs.
+// with "time = t(MFMA) + t(everything else)".  What round 2 measured (profiles/r02_notes.md): the
+// f32-input MFMA sustains 155 TFLOP/s on its own, but it runs at the fp32 VECTOR rate and VALU work
+// beyond about one instruction per MFMA is not hidden under it -- it adds to it; LDS reads are free.  So
+// the rule for exact fp32 on CDNA4 is: as few non-MFMA instructions per MFMA as possible.
 //
-// This kernel turns the structure inside out (MI355X-first: 160 KB LDS per CU, 512 VGPRs per SIMD):
-//   * the WEIGHT SLAB is stationary: a persistent workgroup copies its [BN, K] slice of W into LDS
-//     once per run (BN = 128 columns, or the 3 x 32 gate rows of one GRU feature tile) -- 68 KB at
-//     K = 128, 100-150 KB for the GRU at K = 256-384;
+// Structure (MI355X-first: 160 KB LDS per CU, 512 VGPRs per SIMD):
+//   * the WEIGHT SLAB is stationary: a persistent 8-wave workgroup (one per CU) copies its [BN, K] slice
+//     of W into LDS once per run (BN = 128 columns, or the 3 x 32 gate rows of one GRU feature tile) --
+//     68 KB at K = 128, 100-150 KB for the GRU at K = 256-384;
 //   * A never touches LDS: a wave owns 32 rows ("unit") and loads its MFMA A fragments straight from
 //     global memory.  The K index of an MFMA step is a free permutation as long as A and B agree, so
-//     lane (row li, half hi) takes the 16-byte pieces k = 32c + 8g + 4hi + {0..3}: every global load is
-//     a dwordx4 and every LDS read of the matching B fragment is a conflict-free ds_read_b128;
-//   * there is NO workgroup barrier in steady state: the waves of a workgroup share only the read-only
-//     slab, run their units independently and drift out of phase, so one wave's loads, epilogue math
-//     and stores overlap the MFMAs of the other wave on its SIMD;
-//   * A is register-prefetched two K-chunks ahead ACROSS unit boundaries (the next unit's first chunks
-//     load under the current unit's last MFMAs and its epilogue);
-//   * work = static, balanced runs of units in group-major order (group = column slab or edge type);
-//     the dense kernels map runs so that the column slabs of one row range share an XCD (L2 reuse).
-// The accumulation order over K inside a row is fixed (a permutation of 0..K-1 that does not depend on
-// where the row sits), so results are independent of tiling / sharding, like the round-1 kernels'.
+//     lane (row li, half hi) takes the 16-byte pieces k = 32c + 8g + 4hi + {0..3} (`kcol()` in
+//     dense_common.h): every global load is a dwordx4, every LDS read of the matching B fragment a
+//     conflict-free ds_read_b128, and there is no staging VALU, ds_write or workgroup barrier in steady
+//     state;
+//   * the four pieces of a chunk are the four sectors of one cache line per row and are refilled as a burst,
+//     one chunk pair ahead and ACROSS unit boundaries (the next unit's first chunks load under the current
+//     unit's last MFMAs and its epilogue);
+//   * epilogues go through a wave-private 8 x 32 transposing slab: dwordx4 stores of 8 rows x 128 B instead
+//     of dword stores in the C-fragment layout; the GRU's gate math runs on v_exp_f32 / v_rcp_f32;
+//   * work = balanced runs of units in group-major order (group = column slab / GRU feature tile / edge type;
+//     the edge kernel apportions its workgroups to the types), units claimed dynamically from an LDS
+//     counter inside a run; the dense kernels map runs so that the column slabs of one row range share an
+//     XCD (L2 reuse of A).
+// The accumulation order over K inside a row is ONE fixed permutation shared with the tile kernels, so a
+// result does not depend on the kernel, the tile position, the shard or the layer form that produced it.
 //
 // Arithmetic modes (ptgnn_amd_set_gemm_mode / PTGNN_AMD_GEMM):
 //   1  exact fp32: v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain (default);
@@ -99,7 +105,6 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast
 
 // ---- one K chunk (32 columns) of one unit ---------------------------------------------------------
 // NBLK column blocks of the slab per step; GRU maps block 2 to accumulator 3 in phase 1 (h_n).
-// After a piece is consumed its registers are refilled with the piece two chunks ahead.
 template <int NBLK, int NACC, int PH, bool GRU>
 __device__ __forceinline__ void chunk_f32(f32x16 (&acc)[NACC], float4 (&buf)[4], float4 (&bcur)[NBLK],
                                           const float *bl, int cbs, int kofs, int kofs_next, const ARows &rows,
