@@ -84,13 +84,21 @@ def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Validation hook for 1-GPU boxes: PTGNN_AMD_BENCH_BACKEND=gloo PTGNN_AMD_BENCH_SHARE_GPU=1 runs the N > 1 code
+    # (sharding, all-to-all, rank reductions) with every rank on cuda:0 -- RCCL refuses two ranks per device.  The
+    # numbers of such a run mean nothing; the default (one GPU per rank over RCCL) is what the driver launches.
+    backend = os.environ.get("PTGNN_AMD_BENCH_BACKEND", "nccl")
+    if os.environ.get("PTGNN_AMD_BENCH_SHARE_GPU", "0") not in ("", "0"):
+        local = 0
     if world > 1 or args.force_sharded or args.sharded_variants:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     if world != args.gpus:

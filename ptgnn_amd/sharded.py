@@ -32,6 +32,30 @@ from ptgnn_amd import ops
 Adj = List[Tuple[torch.Tensor, torch.Tensor]]
 
 
+def _flatten(adjacency_lists: Adj):
+    """The T per-type lists as ONE (src, dst) pair + the per-type edge counts (host ints, from the shapes).  All
+    the per-minibatch bookkeeping below runs once over the concatenation -- a program graph has T ~ 20 edge types
+    and a per-type loop of tiny torch kernels costs more than the layers it prepares (cfg4: 1.8 ms of launches
+    against a 1.6 ms forward)."""
+    counts = [int(s_.shape[0]) for s_, _ in adjacency_lists]
+    if len(adjacency_lists) == 1:
+        return adjacency_lists[0][0], adjacency_lists[0][1], counts
+    return (torch.cat([s_ for s_, _ in adjacency_lists]), torch.cat([d_ for _, d_ in adjacency_lists]), counts)
+
+
+def _unflatten(src: torch.Tensor, dst: torch.Tensor, counts: Sequence[int]) -> Adj:
+    """Per-type views (contiguous slices) of a concatenated pair."""
+    return list(zip(src.split(list(counts)), dst.split(list(counts))))
+
+
+def _to_device_ints(values: Sequence[int], device) -> torch.Tensor:
+    """Small host list -> device int64 without stalling the stream (pinned staging for CUDA)."""
+    t = torch.tensor(list(values), dtype=torch.int64)
+    if torch.device(device).type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
 def balanced_node_ranges(in_degree: torch.Tensor, world: int) -> List[Tuple[int, int]]:
     """Contiguous ranges with ~equal numbers of in-edges (+1 per node so empty rows count a bit):
     the balance criterion that matters for power-law graphs."""
@@ -76,6 +100,7 @@ class ShardedGraph:
         self.plan_own: Optional["ops.GraphPlan"] = None
         self.plan_halo: Optional["ops.GraphPlan"] = None
         self.plan_comb: Optional["ops.GraphPlan"] = None
+        self._flat = self._local_flat = None             # concatenated edge list (global ids / local table ids)
 
     # -- construction ---------------------------------------------------------------------------
     @staticmethod
@@ -106,11 +131,11 @@ class ShardedGraph:
         # partitioned on graph boundaries (graphneuralnetwork.py:418-423 keeps a graph's node ids
         # contiguous) has none: every rank then runs the single-GPU path with no data-path collective
         # and skips the halo bookkeeping altogether.
+        src, dst, counts = _flatten(adjacency_lists)
         flag = torch.zeros(1, dtype=torch.int64, device=dev)
-        for s_, _ in adjacency_lists:
-            if s_.numel():
-                lo_s, hi_s = torch.aminmax(s_)
-                flag += ((lo_s < g.lo) | (hi_s >= g.hi)).to(torch.int64)
+        if src.numel():
+            lo_s, hi_s = torch.aminmax(src)
+            flag = ((lo_s < g.lo) | (hi_s >= g.hi)).to(torch.int64).reshape(1)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
         if int(flag.item()) == 0:
             g.no_cut = True
@@ -119,16 +144,16 @@ class ShardedGraph:
             g.send_ids = g.need_ids
             g.send_splits = [0] * g.world
             g.recv_splits = [0] * g.world
-            g.local_adj = [((s_ - g.lo), (d_ - g.lo)) for s_, d_ in adjacency_lists]
+            g.local_adj = _unflatten(src - g.lo, dst - g.lo, counts)
             if build_plan:
                 g.build_plan()
             return g
-        need_counts = g.index_locally(adjacency_lists)                # device int64 [world], no host sync yet
+        need_counts = g.index_locally(adjacency_lists, (src, dst, counts))   # device int64 [world], no host sync yet
         got_counts = torch.empty_like(need_counts)
         dist.all_to_all_single(got_counts, need_counts, group=group)
         # ONE host read-back per minibatch: all_to_all_single wants its split sizes as host ints (and the
         # two-block mode its per-type own-source edge counts)
-        extra = [g.own_source_counts(adjacency_lists)] if overlap else []
+        extra = [g.own_source_counts()] if overlap else []
         both = torch.cat([need_counts, got_counts] + extra).tolist()
         g.recv_splits = [int(v) for v in both[: g.world]]            # halo rows I receive per owner
         g.send_splits = [int(v) for v in both[g.world: 2 * g.world]]  # rows I send per peer
@@ -136,6 +161,7 @@ class ShardedGraph:
         g.finish_local_index()
         if overlap:
             g.split_blocks([int(v) for v in both[2 * g.world:]])
+        g._flat = None
         wanted = torch.empty(sum(g.send_splits), dtype=torch.int64, device=dev)
         dist.all_to_all_single(wanted, g.need_ids, g.send_splits, g.recv_splits, group=group)
         g.send_ids = wanted - g.lo                                    # owners trust their peers' requests
@@ -159,57 +185,74 @@ class ShardedGraph:
         self.bounds_host = los + [his[-1]]
         self.bounds = torch.tensor(self.bounds_host, dtype=torch.int64, device=device)
 
-    def index_locally(self, adjacency_lists: Adj) -> torch.Tensor:
+    def index_locally(self, adjacency_lists: Adj, flat=None) -> torch.Tensor:
         """The collective-free part of `build`: which halo rows this rank needs (de-duplicated, sorted, hence
         grouped by owner because the ranges are ordered).  Mark-and-compact over the global id space: one bool
         per node of the batch and one int32 prefix sum -- streaming passes at HBM speed (10 M nodes: 10 + 40 MB),
         against a sort of every remote endpoint for the alternative.  Returns the per-owner halo row counts as
         a DEVICE tensor; nothing here synchronises with the host."""
-        dev = adjacency_lists[0][0].device
+        src, dst, counts = flat if flat is not None else _flatten(adjacency_lists)
+        dev = src.device
         total = self.bounds_host[-1]            # global node count
         mark = torch.zeros(total + 1, dtype=torch.bool, device=dev)
-        for s, _ in adjacency_lists:
-            mark.index_fill_(0, s, True)
+        mark.index_fill_(0, src, True)
         mark[self.lo:self.hi] = False           # own rows are not halo rows
         mark[total] = False
         self._slot = torch.cumsum(mark, 0, dtype=torch.int32) - mark.to(torch.int32)   # halo slot of every marked id
         self._mark = mark
-        self._adj_global = adjacency_lists
+        self._flat = (src, dst, counts)
         upto = self._slot[self.bounds].to(torch.int64)                # marked ids below each range boundary
         return (upto[1:] - upto[:-1]).contiguous()
 
     def finish_local_index(self) -> None:
         """After the split sizes are known on the host: the sorted halo ids and the edge endpoints remapped into
-        the local table [own rows | halo rows]."""
+        the local table [own rows | halo rows] (one pass over the concatenated edge list; the per-type lists are
+        views of it)."""
         dev = self._mark.device
         self.need_ids = (torch.nonzero(self._mark, as_tuple=False).flatten() if self.n_halo
                          else torch.zeros(0, dtype=torch.int64, device=dev))
-        slot = self._slot
-        self.local_adj = []
-        for s, d in self._adj_global:
-            rem = (s < self.lo) | (s >= self.hi)
-            ls = torch.where(rem, slot[s].to(torch.int64) + self.n_local, s - self.lo)
-            self.local_adj.append((ls.contiguous(), (d - self.lo).contiguous()))
-        self._slot = self._mark = self._adj_global = None
+        src, dst, counts = self._flat
+        rem = (src < self.lo) | (src >= self.hi)
+        ls = torch.where(rem, self._slot[src].to(torch.int64) + self.n_local, src - self.lo)
+        ld = dst - self.lo
+        self._local_flat = (ls, ld, counts)
+        self.local_adj = _unflatten(ls, ld, counts)
+        self._slot = self._mark = None
+
+    def _type_ids(self) -> torch.Tensor:
+        """Edge type of every edge of the concatenated list (int64 [E])."""
+        src, _, counts = self._flat
+        t = len(counts)
+        return torch.repeat_interleave(torch.arange(t, dtype=torch.int64, device=src.device),
+                                       _to_device_ints(counts, src.device), output_size=sum(counts))
 
     # -- two-block mode -----------------------------------------------------------------------------
-    def own_source_counts(self, adjacency_lists: Adj) -> torch.Tensor:
-        """int64 [T] on the device: edges per type whose source is an own row."""
-        dev = adjacency_lists[0][0].device
-        return torch.stack([((s >= self.lo) & (s < self.hi)).sum() if s.numel() else
-                            torch.zeros((), dtype=torch.int64, device=dev) for s, _ in adjacency_lists])
+    def own_source_counts(self) -> torch.Tensor:
+        """int64 [T] on the device: edges per type whose source is an own row (after `index_locally`)."""
+        src, _, counts = self._flat
+        own = ((src >= self.lo) & (src < self.hi)).to(torch.int64)
+        if len(counts) == 1:
+            return own.sum().reshape(1)
+        return torch.zeros(len(counts), dtype=torch.int64, device=src.device).index_add_(0, self._type_ids(), own)
 
     def split_blocks(self, own_counts: Sequence[int]) -> None:
         """Per type: own-source edges first, then halo-source edges (stable), as two adjacency lists over the SAME
         local table [own rows | halo rows]; one plan per block and the 2-slot plan that combines the two partial
-        aggregates.  Uses the host counts that came back with the split sizes: no further synchronisation."""
+        aggregates.  ONE stable sort of the concatenated list by (type, source-is-halo); the slices come from the
+        host counts that travelled back with the split sizes: no further synchronisation."""
         n = self.n_local
+        ls, ld, counts = self._local_flat
+        key = (ls >= n).to(torch.int64)
+        if len(counts) > 1:
+            key = key + 2 * self._type_ids()
+        order = torch.sort(key, stable=True).indices
+        ls, ld = ls[order], ld[order]
         self.adj_own, self.adj_halo = [], []
-        for (ls, ld), c in zip(self.local_adj, own_counts):
-            order = torch.sort((ls >= n).to(torch.int8), stable=True).indices
-            ls, ld = ls[order], ld[order]
-            self.adj_own.append((ls[:c].contiguous(), ld[:c].contiguous()))
-            self.adj_halo.append((ls[c:].contiguous(), ld[c:].contiguous()))
+        at = 0
+        for c_all, c in zip(counts, own_counts):
+            self.adj_own.append((ls[at: at + c], ld[at: at + c]))
+            self.adj_halo.append((ls[at + c: at + c_all], ld[at + c: at + c_all]))
+            at += c_all
         self.overlap = True
         if ls.is_cuda:
             rows = n + self.n_halo
@@ -266,11 +309,12 @@ class ShardedGraph:
         g.finish_local_index()
         g.send_splits = [0] * g.world
         g.send_ids = g.need_ids[:0]
-        own_counts = [int(v) for v in g.own_source_counts(adjacency_lists).tolist()] if overlap else None
+        own_counts = [int(v) for v in g.own_source_counts().tolist()] if overlap else None
         if adjacency_lists[0][0].is_cuda:
             g.build_plan()
         if overlap:
             g.split_blocks(own_counts)
+        g._flat = None
         return g
 
     def build_plan(self) -> None:

@@ -1,0 +1,184 @@
+"""Worker of tests/test_gpu_two_rank.py: REAL separate processes, one per rank, all on cuda:0, process group
+`gloo` (its CUDA all-to-all / all-reduce paths), so that the per-minibatch halo bookkeeping, the per-layer
+all-to-all(v), the asynchronous two-block exchange, the transposed exchange of the backward and the pool
+all-reduce of the global-exchange layers run over an actual rendezvous instead of the single-process
+"virtual rank" stand-ins of test_gpu_parity.py.  (RCCL refuses two ranks on one device and `gpurun` boxes have
+one GPU; the collectives' semantics are the backend-independent part, and that is what is checked here.)
+
+Launch: python -m torch.distributed.run --nproc-per-node W --master-addr 127.0.0.1 --master-port P \
+            tests/two_rank_gpu_check.py
+Every rank computes the UNSHARDED result itself (same seeds) and compares its own row range.
+Prints one line `rank R ok <case>` per passed case; exits non-zero on the first mismatch."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _ranges(adj, n, world):
+    from ptgnn_amd import sharded
+    indeg = torch.zeros(n, dtype=torch.int64)
+    for _, d in adj:
+        indeg += torch.bincount(d, minlength=n)
+    return sharded.balanced_node_ranges(indeg, world)
+
+
+def _mine(adj, lo, hi):
+    return [(s[(d >= lo) & (d < hi)].cuda(), d[(d >= lo) & (d < hi)].cuda()) for s, d in adj]
+
+
+def _cuda_adj(adj):
+    return [(s.cuda(), d.cuda()) for s, d in adj]
+
+
+def _ok(rank, case):
+    print(f"rank {rank} ok {case}", flush=True)
+
+
+def case_layers(rank, world):
+    """Single layers, inference: edge form (T = 17, ships node states), table form (T = 1, ships message rows),
+    plain and two-block (asynchronous all-to-all) modes -- bit-identical to the unsharded layer (two-block sums:
+    within 1e-6, the partials re-associate)."""
+    from oracle import mp_oracle as O          # augmentation helper only (tests may use the oracle)
+    from ptgnn_amd import layers as L, ops, sharded, workloads
+    H = 64
+    mb = workloads.batched_graphs(6, 700, 8, 2.2, seed=31)
+    n = mb["num_nodes"]
+    adj17 = O.augment_adjacency(mb["adjacency_lists"], n, True, True)
+    g = torch.Generator().manual_seed(17)
+    adj1 = [(torch.randint(0, n, (5 * n,), generator=g), torch.randint(0, n, (5 * n,), generator=g))]
+    x = workloads.node_states(n, H, seed=32).cuda()
+    for name, adj, make in (
+            ("ggnn_edge_max", adj17, lambda T: L.GatedMessagePassingLayer(H, H, T, "max")),
+            ("mlp_edge_sum", adj17, lambda T: L.MlpMessagePassingLayer(H, H, H, T, "sum")),
+            ("mlp_table_sum", adj1, lambda T: L.MlpMessagePassingLayer(H, H, H, T, "sum")),
+            ("ggnn_table_min", adj1, lambda T: L.GatedMessagePassingLayer(H, H, T, "min"))):
+        # pin the form: a shard and the whole graph must not land on different sides of the edge / table choice
+        L.EDGE_PATH_BIAS = 0.0 if adj is adj17 else 1e9
+        torch.manual_seed(33)
+        layer = make(len(adj)).cuda().eval()
+        cadj = _cuda_adj(adj)
+        ops.clear_plan_cache()
+        with torch.no_grad():
+            want = layer(x, cadj, None, {}, {}, [None] * len(cadj))
+        ranges = _ranges(adj, n, world)
+        lo, hi = ranges[rank]
+        for overlap in (False, True):
+            shard = sharded.ShardedGraph.build(_mine(adj, lo, hi), (lo, hi), overlap=overlap,
+                                               all_ranges=None if overlap else ranges)
+            assert shard.n_halo > 0 and not shard.no_cut
+            with torch.no_grad():
+                got = layer.forward_sharded(x[lo:hi].contiguous(), shard)
+            if overlap and name.endswith("sum"):
+                # two-block mode: (own partial) + (halo partial) instead of the CSR fold order (sharded.py)
+                err = float((got - want[lo:hi]).abs().max())
+                assert err <= 1e-6 * max(1.0, float(want.abs().max())), err
+            else:
+                np.testing.assert_array_equal(got.cpu().numpy(), want[lo:hi].cpu().numpy())
+            _ok(rank, f"{name}{'_two_block' if overlap else ''}")
+
+
+def case_stack(rank, world):
+    """varmisuse/train.py:76-107 through sharded.run_stack with graphs that STRADDLE the rank boundaries: the
+    per-graph pools are combined across ranks (all-reduce), which re-associates the fp32 sums: <= 1e-5."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, ops, reduceops as R, sharded, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    H = 64
+    L.EDGE_PATH_BIAS = 1.25                      # the shipped default (earlier cases pinned it)
+    mb = workloads.batched_graphs(5, 900, 4, 2.2, seed=41)
+    n, n2g = mb["num_nodes"], mb["node_to_graph_idx"]
+    adj = O.augment_adjacency(mb["adjacency_lists"], n, True, True)
+    T = len(adj)
+    torch.manual_seed(42)
+    ggnn = L.GatedMessagePassingLayer(H, H, T, "sum")
+    r1, r2 = L.MeanResidualLayer(H), L.MeanResidualLayer(H)
+    g1 = R.GruGlobalStateUpdate(R.WeightedSumVarSizedElementReduce(H), H, H)
+    g2 = R.GruGlobalStateUpdate(R.SimpleVarSizedElementReduce("max"), H, H)
+    mods = [r1.pass_through_dummy_layer(), r2.pass_through_dummy_layer(), ggnn, ggnn, g1, ggnn, r1,
+            ggnn, g2, ggnn, r2]
+    net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).cuda().eval()
+    x = workloads.node_states(n, H, seed=43).cuda()
+    ops.clear_plan_cache()
+    with torch.no_grad():
+        want = net(node_data={"input": x}, adjacency_lists=_cuda_adj(mb["adjacency_lists"]), edge_feature_data=[],
+                   node_to_graph_idx=n2g.cuda(), reference_node_ids={}, reference_node_graph_idx={},
+                   num_graphs=mb["num_graphs"]).output_node_representations
+    ranges = _ranges(adj, n, world)
+    lo, hi = ranges[rank]
+    assert int(n2g[lo]) == int(n2g[lo - 1]) if rank > 0 else True          # the cut is inside a graph
+    shard = sharded.ShardedGraph.build(_mine(adj, lo, hi), (lo, hi))
+    shard.attach_graph_index(n2g[lo:hi].cuda(), mb["num_graphs"])
+    with torch.no_grad():
+        got = sharded.run_stack(mods, x[lo:hi].contiguous(), shard)
+    err = float((got - want[lo:hi]).abs().max())
+    assert err <= 1e-5, err
+    _ok(rank, f"ggnn_stack_global_exchange err={err:.2e}")
+
+
+def case_training(rank, world):
+    """One training step over the shard (edge form and table form): loss = sum over ranks of <y_local, g_local>;
+    parameter gradients summed over ranks (what DDP does) and the input gradient of the own rows must equal the
+    whole-graph step's (fp32 re-association only: 2e-5 x scale, the tolerance of the single-GPU gradient tests)."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, ops, sharded, workloads
+    H = 64
+    mb = workloads.batched_graphs(4, 600, 6, 2.2, seed=51)
+    n = mb["num_nodes"]
+    adj13 = O.augment_adjacency(mb["adjacency_lists"], n, True, True)
+    g = torch.Generator().manual_seed(52)
+    adj1 = [(torch.randint(0, n, (4 * n,), generator=g), torch.randint(0, n, (4 * n,), generator=g))]
+    x = workloads.node_states(n, H, seed=53).cuda()
+    gout = torch.randn(n, H, generator=g).cuda()
+    for name, adj, make in (
+            ("train_ggnn_edge_max", adj13, lambda T: L.GatedMessagePassingLayer(H, H, T, "max")),
+            ("train_mlp_table_sum", adj1, lambda T: L.MlpMessagePassingLayer(H, H, H, T, "sum"))):
+        L.EDGE_PATH_BIAS = 0.0 if adj is adj13 else 1e9
+        torch.manual_seed(54)
+        layer = make(len(adj)).cuda().train()
+        cadj = _cuda_adj(adj)
+        layer.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        ops.clear_plan_cache()
+        y = layer(xi, cadj, None, {}, {}, [None] * len(cadj))
+        y.backward(gout)
+        want = [y.detach(), xi.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+        ranges = _ranges(adj, n, world)
+        lo, hi = ranges[rank]
+        layer.zero_grad()
+        shard = sharded.ShardedGraph.build(_mine(adj, lo, hi), (lo, hi), all_ranges=ranges)
+        xl = x[lo:hi].clone().requires_grad_(True)
+        yl = layer.forward_sharded(xl, shard)
+        yl.backward(gout[lo:hi])
+        got_p = []
+        for p in layer.parameters():
+            gp = p.grad.clone() if p.grad is not None else torch.zeros_like(p)
+            dist.all_reduce(gp)
+            got_p.append(gp)
+        pairs = [(yl.detach(), want[0][lo:hi]), (xl.grad, want[1][lo:hi])] + list(zip(got_p, want[2:]))
+        worst = 0.0
+        for a, b in pairs:
+            sc = max(1.0, float(b.abs().max()))
+            worst = max(worst, float((a - b).abs().max()) / sc)
+        assert worst <= 2e-5, worst
+        _ok(rank, f"{name} rel_err={worst:.2e}")
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for case in (case_layers, case_stack, case_training):
+            case(rank, world)
+            dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
