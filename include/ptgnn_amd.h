@@ -89,6 +89,7 @@ int ptgnn_amd_get_gemm_mode(void);
  * Requires num_src_rows << type_bits < 2^31 and num_edges < 2^31, else EUNSUPPORTED.
  * ---------------------------------------------------------------------------------------- */
 size_t ptgnn_amd_csr_workspace_bytes(int64_t num_edges, int64_t num_nodes);
+size_t ptgnn_amd_csr_control_bytes(void);
 int ptgnn_amd_type_bits(int32_t num_types);
 int ptgnn_amd_csr_build(const int64_t *const *src_per_type, /* host [num_types] of device ptrs */
                         const int64_t *const *dst_per_type, /* host [num_types] of device ptrs */
@@ -109,6 +110,11 @@ int ptgnn_amd_csr_build(const int64_t *const *src_per_type, /* host [num_types] 
                                                   * (gatedmessagepassing.py:54-56); here they are clamped to *
                                                   * row 0 so nothing is read or written out of bounds, and   *
                                                   * counted so the host can raise                            */,
+                        void *control /* nullable: ptgnn_amd_csr_control_bytes() of device memory that is ZERO  *
+                                       * AT REST: zero-filled once by the caller, used by the builds of ONE   *
+                                       * stream at a time, left zero-filled by every build (digit totals and  *
+                                       * tile counters of the three-launch build).  Null: the library zeroes  *
+                                       * a block inside `workspace` with one extra memset per build          */,
                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* The hub (chunk, row) list of an existing rowptr (plans that are not built by ptgnn_amd_csr_build,

@@ -184,22 +184,46 @@ __global__ __launch_bounds__(kSortBlock) void k_radix_scatter(
   }
 }
 
-// ---- two-level plan build for minibatch-sized graphs (rows <= 2^18, <= 64 edge types) -------------
+// ---- two-level plan build for minibatch-sized graphs (rows <= 2^18, <= 64 edge types, <= 4 M edges) --
 // The LSD sort above needs 2 x (histogram, scan, scatter) + pack + finish + hub list = 11 dependent
 // launches whose 4-byte scatters land two-at-a-time in random cache lines.  Rows are node ids, i.e.
-// roughly uniformly populated, so:
-//   k_msd_hist     per-1024-edge block histogram of the HIGH row bits, straight from the int64 lists
-//   k_msd_scan     per-digit exclusive scan over the blocks + digit totals          (one WG per digit)
-//   k_msd_scatter  stable scatter of 16-byte records (row, position, payload) into <= 512 buckets of
-//                  2^low_bits consecutive rows each
-//   k_msd_buckets  one workgroup per bucket: histogram of the LOW bits = the in-degrees -> rowptr and
-//                  the hub list directly; stable counting sort of the bucket into col / perm
-// 4 launches, keys never materialised, the second level works inside a few-KiB window of the output.
-// Stability of both levels = the order of a numpy stable argsort (tests: bit-exact).
+// roughly uniformly populated, so the plan is built MSD-first in THREE launches:
+//   k_plan_count    digit totals of the HIGH row bits (reads only the key column of the int64 lists: LDS
+//                   histogram per 4096-edge tile, one global atomic per (tile, digit) into the control block)
+//                   and zeroes the look-back status rows of the next kernel
+//   k_plan_scatter  one pass over the lists: stable scatter of 8-byte records (low row bits | position,
+//                   payload) into <= 512 buckets of 2^low_bits consecutive rows.  The cross-tile prefix of every
+//                   digit comes from a decoupled look-back over per-(tile, digit) status words (aggregate /
+//                   inclusive-prefix flag + value in ONE 32-bit word, agent-scope atomics, so no fences); tiles
+//                   take their id from a ticket counter, hence every tile a block waits on has already started
+//                   (forward progress without co-residency, the rocPRIM / onesweep argument)
+//   k_plan_buckets  one workgroup per bucket: histogram of the LOW bits = the in-degrees -> rowptr and
+//                   the hub list directly; stable counting sort of the bucket into col / perm; the last
+//                   workgroup to have read the control block zeroes it again
+// Keys are never materialised, the second level works inside a few-KiB window of the output, and the edge
+// lists are read 1.5 times (8 + 16 B/edge) against 2 x 16 B/edge + a scan launch for the histogram/scan/scatter
+// form this replaces.  Stability of both levels = the order of a numpy stable argsort (tests: bit-exact).
+//
+// Control block (PlanControl, ptgnn_amd_csr_control_bytes()): digit totals + two counters, ZERO AT REST -- the
+// caller zero-fills it once, hands it to every build on ONE stream, and finds it zero-filled again after each
+// build.  A null control pointer makes the library carve one out of the workspace and zero it with a memset
+// node per build.
 constexpr int kMsdBlock = 1024;
+constexpr int kTileRounds = 4;
+constexpr int kTileEdges = kMsdBlock * kTileRounds;   // edges per tile of k_plan_count / k_plan_scatter
+constexpr int kPosBits = 22;                          // record.x = low row bits << 22 | position (E <= 4 M)
+
+struct PlanControl {
+  int32_t totals[kMaxBins];
+  int32_t ticket;   // next tile id of k_plan_scatter
+  int32_t done;     // k_plan_buckets workgroups that have finished reading `totals`
+  int32_t pad[2];
+};
+
+constexpr uint32_t kFlagAggregate = 1u << 30, kFlagInclusive = 2u << 30, kValueMask = (1u << 30) - 1u;
 
 // exclusive scan of v over threads 0 .. 511 of a 1024-thread block (tmp: 8 ints of LDS); returns the
-// exclusive prefix, *total (LDS broadcast slot tmp[8]) gets the grand total
+// exclusive prefix
 __device__ __forceinline__ int block_scan_512(int v, int *tmp) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = v;
@@ -216,48 +240,45 @@ __device__ __forceinline__ int block_scan_512(int v, int *tmp) {
   return prior + inc - v;
 }
 
-__global__ __launch_bounds__(kMsdBlock) void k_msd_hist(TypeTable tab, int32_t type_bits, int mode,
-                                                        int total_types, int64_t n, int low_bits,
-                                                        int bins, int32_t *__restrict__ hist,
-                                                        int64_t nblocks, int32_t *hub_count, RangeGuard guard) {
-  __shared__ int lh[kMaxBins];
-  for (int j = threadIdx.x; j < bins; j += kMsdBlock) lh[j] = 0;
-  if (hub_count && blockIdx.x == 0 && threadIdx.x == 0) *hub_count = 0;
-  __syncthreads();
-  const int64_t e = blockIdx.x * (int64_t)kMsdBlock + threadIdx.x;
-  if (e < n) atomicAdd(&lh[edge_record(tab, e, type_bits, mode, total_types, guard, true).key >> low_bits], 1);
-  __syncthreads();
-  for (int j = threadIdx.x; j < bins; j += kMsdBlock) hist[(int64_t)j * nblocks + blockIdx.x] = lh[j];
+// plan row of edge e (the sort key), reading only the column that holds it; same clamping as edge_record
+__device__ __forceinline__ uint32_t edge_key(const TypeTable &tab, int64_t e, int mode, int total_types,
+                                             const RangeGuard &guard) {
+  int lo = 0, hi = tab.num_types;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tab.offset[mid] <= e) lo = mid; else hi = mid;
+  }
+  const int64_t i = e - tab.offset[lo];
+  int64_t key;
+  if (mode == 2) {
+    const int64_t s_ = tab.src[lo][i];
+    key = s_ < 0 ? -1 : s_ * total_types + (tab.type_base + lo);
+  } else {
+    key = mode == 1 ? tab.src[lo][i] : tab.dst[lo][i];
+  }
+  return (key < 0 || key >= guard.num_rows) ? 0u : (uint32_t)key;
 }
 
-// hist[d][0 .. nblocks) -> exclusive prefix in place; totals[d] = row sum.  One 256-thread WG per digit.
-__global__ __launch_bounds__(256) void k_msd_scan(int32_t *__restrict__ hist, int64_t nblocks,
-                                                  int32_t *__restrict__ totals) {
-  __shared__ int wsum[4];
-  __shared__ int carry_s;
-  int32_t *row = hist + (int64_t)blockIdx.x * nblocks;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int64_t base = 0; base < nblocks; base += 256) {
-    const int64_t j = base + threadIdx.x;
-    const int v = j < nblocks ? row[j] : 0;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int prior = carry_s;
-    for (int w = 0; w < wave; ++w) prior += wsum[w];
-    if (j < nblocks) row[j] = prior + inc - v;
-    __syncthreads();
-    if (threadIdx.x == 255) carry_s = prior + inc;
-    __syncthreads();
+__global__ __launch_bounds__(kMsdBlock) void k_plan_count(TypeTable tab, int mode, int total_types, int64_t n,
+                                                          int low_bits, int bins, PlanControl *ctl,
+                                                          uint32_t *__restrict__ status, int32_t *hub_count,
+                                                          RangeGuard guard) {
+  __shared__ int lh[kMaxBins];
+  for (int j = threadIdx.x; j < bins; j += kMsdBlock) {
+    lh[j] = 0;
+    status[(int64_t)blockIdx.x * bins + j] = 0u;   // "not ready" for the look-back of the next kernel
   }
-  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+  if (hub_count && blockIdx.x == 0 && threadIdx.x == 0) *hub_count = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kTileEdges;
+#pragma unroll
+  for (int r = 0; r < kTileRounds; ++r) {
+    const int64_t e = base + r * kMsdBlock + threadIdx.x;
+    if (e < n) atomicAdd(&lh[edge_key(tab, e, mode, total_types, guard) >> low_bits], 1);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < bins; j += kMsdBlock)
+    if (lh[j]) atomicAdd(&ctl->totals[j], lh[j]);
 }
 
 // stable rank of this lane's digit inside a 1024-thread block: (earlier waves' count, rank in wave)
@@ -291,55 +312,114 @@ __device__ __forceinline__ int block_stable_rank(bool valid, int digit, int bits
   return valid ? wave_cnt[wave * bins + digit] + rank : 0;
 }
 
-__global__ __launch_bounds__(kMsdBlock) void k_msd_scatter(TypeTable tab, int32_t type_bits, int mode,
-                                                           int total_types, int64_t n, int low_bits,
-                                                           int high_bits, int bins,
-                                                           const int32_t *__restrict__ hist_prefix,
-                                                           const int32_t *__restrict__ totals,
-                                                           int64_t nblocks, int4 *__restrict__ recs,
-                                                           RangeGuard guard) {
+__global__ __launch_bounds__(kMsdBlock) void k_plan_scatter(TypeTable tab, int32_t type_bits, int mode,
+                                                            int total_types, int64_t n, int low_bits,
+                                                            int high_bits, int bins, PlanControl *ctl,
+                                                            uint32_t *status, int2 *__restrict__ recs,
+                                                            RangeGuard guard) {
   __shared__ int wave_cnt[(kMsdBlock / 64) * kMaxBins];
   __shared__ int base[kMaxBins];
+  __shared__ int tile_excl[kMaxBins];
+  __shared__ int round_base[kTileRounds][kMaxBins];
   __shared__ int tmp[8];
-  {
-    const int v = threadIdx.x < bins ? totals[threadIdx.x] : 0;
-    const int ex = block_scan_512(v, tmp);
+  __shared__ int tile_s;
+  if (threadIdx.x == 0) tile_s = atomicAdd(&ctl->ticket, 1);
+  {   // where each bucket starts in the record array: prefix of the digit totals (complete: previous launch)
+    const int v = threadIdx.x < bins ? ctl->totals[threadIdx.x] : 0;
+    const int ex = block_scan_512(v, tmp);          // synchronises: tile_s is visible afterwards
     if (threadIdx.x < bins) base[threadIdx.x] = ex;
   }
-  const int64_t e = blockIdx.x * (int64_t)kMsdBlock + threadIdx.x;
-  const bool valid = e < n;
-  EdgeRec r{0u, 0};
-  if (valid) r = edge_record(tab, e, type_bits, mode, total_types, guard, false);
-  const int digit = (int)(r.key >> low_bits);
-  int run;
-  const int local = block_stable_rank(valid, digit, high_bits, bins, wave_cnt, &run);   // syncs inside
-  if (valid) {
-    const int64_t pos = (int64_t)base[digit] + hist_prefix[(int64_t)digit * nblocks + blockIdx.x] + local;
-    recs[pos] = make_int4((int)r.key, (int)e, r.packed, 0);
+  const int tile = tile_s;
+  const uint32_t low_mask = (1u << low_bits) - 1u;
+  EdgeRec rec[kTileRounds];
+  int local[kTileRounds];
+  int mine = 0;                                      // threads < bins: this tile's count of digit threadIdx.x
+#pragma unroll
+  for (int r = 0; r < kTileRounds; ++r) {
+    const int64_t e = (int64_t)tile * kTileEdges + r * kMsdBlock + threadIdx.x;
+    const bool valid = e < n;
+    rec[r] = EdgeRec{0u, 0};
+    if (valid) rec[r] = edge_record(tab, e, type_bits, mode, total_types, guard, true);
+    int run;
+    local[r] = block_stable_rank(valid, (int)(rec[r].key >> low_bits), high_bits, bins, wave_cnt, &run);
+    if (threadIdx.x < bins) {
+      round_base[r][threadIdx.x] = mine;
+      mine += run;
+    }
+    __syncthreads();                                 // wave_cnt is cleared again by the next round
+  }
+  if (threadIdx.x < bins) {
+    // decoupled look-back: publish this tile's aggregate, sum the predecessors' back to the first tile that
+    // already knows its inclusive prefix, publish ours
+    uint32_t *my = status + (int64_t)tile * bins + threadIdx.x;
+    uint32_t excl = 0;
+    if (tile == 0) {
+      __hip_atomic_store(my, kFlagInclusive | (uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(my, kFlagAggregate | (uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int t = tile - 1;
+      int spins = 0;
+      while (true) {
+        const uint32_t v = __hip_atomic_load(status + (int64_t)t * bins + threadIdx.x, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 30) == 0u) {
+          // predecessor still counting.  It holds a lower ticket, so it is running; the bound only turns a
+          // broken invariant into a flagged build (bad-index counter) instead of a hung GPU.
+          if (++spins > (1 << 24)) {
+            if (guard.bad) atomicAdd(guard.bad, 1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        excl += v & kValueMask;
+        if (v & kFlagInclusive) break;
+        --t;
+      }
+      __hip_atomic_store(my, kFlagInclusive | (excl + (uint32_t)mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    tile_excl[threadIdx.x] = (int)excl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kTileRounds; ++r) {
+    const int64_t e = (int64_t)tile * kTileEdges + r * kMsdBlock + threadIdx.x;
+    if (e < n) {
+      const int digit = (int)(rec[r].key >> low_bits);
+      const int64_t pos = (int64_t)base[digit] + tile_excl[digit] + round_base[r][digit] + local[r];
+      recs[pos] = make_int2((int)(((rec[r].key & low_mask) << kPosBits) | (uint32_t)e), rec[r].packed);
+    }
   }
 }
 
-__global__ __launch_bounds__(kMsdBlock) void k_msd_buckets(
-    const int4 *__restrict__ recs, const int32_t *__restrict__ totals, int bins, int low_bits,
+__global__ __launch_bounds__(kMsdBlock) void k_plan_buckets(
+    const int2 *__restrict__ recs, PlanControl *ctl, int bins, int low_bits,
     int64_t num_rows, int64_t num_edges, int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
     int32_t *__restrict__ perm, int32_t hub_threshold, int32_t hub_chunk, int32_t *__restrict__ hub_entries,
     int32_t *__restrict__ hub_count) {
   __shared__ int wave_cnt[(kMsdBlock / 64) * kMaxBins];
   __shared__ int offs[kMaxBins];
   __shared__ int tmp[8];
-  __shared__ int bucket_start_s;
+  __shared__ int bucket_start_s, bucket_size_s, last_s;
   const int b = blockIdx.x;
   const int lbins = 1 << low_bits, mask = lbins - 1;
   {   // where this bucket starts in the record array: prefix of the digit totals
-    const int v = threadIdx.x < bins ? totals[threadIdx.x] : 0;
+    const int v = threadIdx.x < bins ? ctl->totals[threadIdx.x] : 0;
     const int ex = block_scan_512(v, tmp);
-    if (threadIdx.x == b) bucket_start_s = ex;
+    if (threadIdx.x == b) { bucket_start_s = ex; bucket_size_s = v; }
   }
   for (int j = threadIdx.x; j < lbins; j += kMsdBlock) offs[j] = 0;
   __syncthreads();
-  const int s = bucket_start_s, e = s + totals[b];
-  for (int i = s + threadIdx.x; i < e; i += kMsdBlock) atomicAdd(&offs[recs[i].x & mask], 1);
+  // every thread of this workgroup has its totals in registers: the last workgroup to get here puts the
+  // control block back to its zero-at-rest state
+  if (threadIdx.x == 0) last_s = atomicAdd(&ctl->done, 1) == (int)gridDim.x - 1;
+  const int s = bucket_start_s, e = s + bucket_size_s;
+  for (int i = s + threadIdx.x; i < e; i += kMsdBlock) atomicAdd(&offs[(recs[i].x >> kPosBits) & mask], 1);
   __syncthreads();
+  if (last_s) {
+    for (int j = threadIdx.x; j < kMaxBins; j += kMsdBlock) ctl->totals[j] = 0;
+    if (threadIdx.x == 0) { ctl->ticket = 0; ctl->done = 0; }
+  }
   {   // in-degrees -> rowptr (+ hub rows); offs becomes the running write cursor of each row
     const int deg = threadIdx.x < lbins ? offs[threadIdx.x] : 0;
     __syncthreads();
@@ -366,15 +446,15 @@ __global__ __launch_bounds__(kMsdBlock) void k_msd_buckets(
   for (int cb = s; cb < e; cb += kMsdBlock) {
     const int i = cb + threadIdx.x;
     const bool valid = i < e;
-    int4 r = make_int4(0, 0, 0, 0);
+    int2 r = make_int2(0, 0);
     if (valid) r = recs[i];
-    const int digit = r.x & mask;
+    const int digit = (r.x >> kPosBits) & mask;
     int run;
     const int local = block_stable_rank(valid, digit, low_bits, lbins, wave_cnt, &run);   // syncs inside
     if (valid) {
       const int pos = s + offs[digit] + local;
-      col[pos] = r.z;
-      if (perm) perm[pos] = r.y;
+      col[pos] = r.y;
+      if (perm) perm[pos] = r.x & ((1 << kPosBits) - 1);
     }
     __syncthreads();
     if (threadIdx.x < lbins) offs[threadIdx.x] += run;
@@ -431,7 +511,7 @@ __global__ __launch_bounds__(256) void k_validate(const int64_t *__restrict__ id
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t keys_in, keys_out, pos_in, pos_out, packed, sort_tmp, sort_tmp_bytes, hist, hist_scan, total;
+  size_t keys_in, keys_out, pos_in, pos_out, packed, sort_tmp, sort_tmp_bytes, hist, hist_scan, control, total;
 };
 
 // The one-pair-per-lane kernels win up to a few million edges (minibatch sizes: 0.11 vs 0.15 ms at
@@ -493,6 +573,7 @@ bool layout(int64_t num_edges, int64_t num_nodes, WsLayout *L) {
   const size_t nh = align_up((size_t)kMaxBins * (size_t)((num_edges + kSortBlock - 1) / kSortBlock) * 4, 256);
   L->hist = o;      o += nh;
   L->hist_scan = o; o += nh;
+  L->control = o;   o += align_up(sizeof(PlanControl), 256);   // only used when the caller passes no control block
   L->total = o + 256;
   return true;
 }
@@ -508,6 +589,8 @@ extern "C" int ptgnn_amd_type_bits(int32_t num_types) {
   return b;
 }
 
+extern "C" size_t ptgnn_amd_csr_control_bytes(void) { return sizeof(PlanControl); }
+
 extern "C" size_t ptgnn_amd_csr_workspace_bytes(int64_t num_edges, int64_t num_nodes) {
   if (num_edges < 0 || num_nodes < 0) return 0;
   WsLayout L;
@@ -522,7 +605,7 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
                                    int32_t *rowptr,
                                    int32_t *col, int32_t *perm, int32_t *max_degree,
                                    int32_t hub_threshold, int32_t *hub_entries, int32_t *hub_count,
-                                   int32_t *bad_index_count,
+                                   int32_t *bad_index_count, void *control,
                                    void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PTGNN_REQUIRE(num_types >= 0 && num_nodes >= 0, PTGNN_AMD_EINVAL, "csr_build: negative size");
@@ -575,23 +658,24 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
     if (total_bits - low_bits > 9) low_bits = total_bits - 9;
     const int high_bits = total_bits - low_bits;
     const int bins = (int)((num_nodes + ((int64_t)1 << low_bits) - 1) >> low_bits);
-    const int64_t nblocks = (num_edges + kMsdBlock - 1) / kMsdBlock;
-    int32_t *hist = (int32_t *)(ws + L.hist), *totals = (int32_t *)(ws + L.hist_scan);
-    int4 *recs = (int4 *)ws;   // 16 B/edge over the (unused) key/pos/payload buffers of the LSD path
+    const int64_t ntiles = (num_edges + kTileEdges - 1) / kTileEdges;
+    uint32_t *status = (uint32_t *)(ws + L.hist);   // [ntiles][bins] look-back words (<= the LSD path's histograms)
+    int2 *recs = (int2 *)ws;      // 8 B/edge over the (unused) key/pos/payload buffers of the LSD path
+    PlanControl *ctl = (PlanControl *)control;
+    if (ctl == nullptr) {         // no caller-owned control block: one inside the workspace, zeroed per build
+      ctl = (PlanControl *)(ws + L.control);
+      PTGNN_HIP(hipMemsetAsync(ctl, 0, sizeof(PlanControl), stream));
+    }
     const bool hubs = hub_entries && hub_count && hub_threshold > 0;
-    k_msd_hist<<<(unsigned)nblocks, kMsdBlock, 0, stream>>>(tab, type_bits, swap_src_dst, num_types, num_edges,
-                                                            low_bits, bins, hist, nblocks,
-                                                            hubs ? hub_count : nullptr, guard);
+    k_plan_count<<<(unsigned)ntiles, kMsdBlock, 0, stream>>>(tab, swap_src_dst, num_types, num_edges, low_bits, bins,
+                                                            ctl, status, hubs ? hub_count : nullptr, guard);
     PTGNN_LAUNCH_CHECK();
-    k_msd_scan<<<(unsigned)bins, 256, 0, stream>>>(hist, nblocks, totals);
+    k_plan_scatter<<<(unsigned)ntiles, kMsdBlock, 0, stream>>>(tab, type_bits, swap_src_dst, num_types, num_edges,
+                                                              low_bits, high_bits, bins, ctl, status, recs, guard);
     PTGNN_LAUNCH_CHECK();
-    k_msd_scatter<<<(unsigned)nblocks, kMsdBlock, 0, stream>>>(tab, type_bits, swap_src_dst, num_types,
-                                                               num_edges, low_bits, high_bits, bins, hist,
-                                                               totals, nblocks, recs, guard);
-    PTGNN_LAUNCH_CHECK();
-    k_msd_buckets<<<(unsigned)bins, kMsdBlock, 0, stream>>>(recs, totals, bins, low_bits, num_nodes, num_edges,
-                                                            rowptr, col, perm, hubs ? hub_threshold : 0, 1024,
-                                                            hub_entries, hub_count);
+    k_plan_buckets<<<(unsigned)bins, kMsdBlock, 0, stream>>>(recs, ctl, bins, low_bits, num_nodes, num_edges,
+                                                             rowptr, col, perm, hubs ? hub_threshold : 0, 1024,
+                                                             hub_entries, hub_count);
     PTGNN_LAUNCH_CHECK();
     if (max_degree) {
       PTGNN_HIP(hipMemsetAsync(max_degree, 0, sizeof(int32_t), stream));

@@ -289,6 +289,24 @@ def _post_plan_readback(st) -> None:
         st["event"] = ev
 
 
+_PLAN_CONTROL = {}   # (device index, stream handle) -> zero-at-rest control block of the plan build
+
+
+def _plan_control(dev: torch.device) -> torch.Tensor:
+    """The control block ptgnn_amd_csr_build wants (include/ptgnn_amd.h): zero-filled once, then owned by the
+    builds of ONE stream -- stream order serialises them and every build leaves it zero-filled.  Under graph
+    capture a fresh zero-filled block is captured with the build instead (a cached one could be shared with
+    eager builds that run while the graph replays)."""
+    nbytes = int(_lib.load().ptgnn_amd_csr_control_bytes())
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ctl = _PLAN_CONTROL.get(key)
+    if ctl is None:
+        ctl = _PLAN_CONTROL[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    return ctl
+
+
 def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num_nodes: int,
                transposed: bool = False, want_perm: bool = True,
                num_src_rows: Optional[int] = None, mode: Optional[int] = None) -> GraphPlan:
@@ -323,6 +341,7 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
     perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if want_perm else None
     ws_bytes = lib.ptgnn_amd_csr_workspace_bytes(E, num_nodes)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    control = _plan_control(dev)
     hub_entries = hub_count = None
     if HUB_THRESHOLD > 0 and E > HUB_THRESHOLD:
         hub_entries = torch.empty(2 * ((E + 1023) // 1024), 2, dtype=torch.int32, device=dev)
@@ -349,6 +368,7 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
                                      hub_entries.data_ptr() if hub_entries is not None else None,
                                      hub_count.data_ptr() if hub_count is not None else None,
                                      bad["dev"].data_ptr() if bad is not None else None,
+                                     control.data_ptr(),
                                      ws.data_ptr(), ws_bytes, _stream(rowptr))
     _lib.check(rc, "ptgnn_amd_csr_build")
     if bad is not None:

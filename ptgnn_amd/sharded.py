@@ -121,7 +121,7 @@ class ShardedGraph:
         g.n_local = g.hi - g.lo
         dev = adjacency_lists[0][0].device
         if all_ranges is None:   # every rank learns all range boundaries
-            mine = torch.tensor([g.lo, g.hi], dtype=torch.int64, device=dev)
+            mine = _to_device_ints([g.lo, g.hi], dev)
             allr = [torch.empty_like(mine) for _ in range(g.world)]
             dist.all_gather(allr, mine, group=group)
             all_ranges = torch.stack(allr).tolist()
@@ -137,7 +137,14 @@ class ShardedGraph:
             lo_s, hi_s = torch.aminmax(src)
             flag = ((lo_s < g.lo) | (hi_s >= g.hi)).to(torch.int64).reshape(1)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-        if int(flag.item()) == 0:
+        need_counts = g.index_locally(adjacency_lists, (src, dst, counts))   # device int64 [world], no host sync yet
+        got_counts = torch.empty_like(need_counts)
+        dist.all_to_all_single(got_counts, need_counts, group=group)
+        # ONE host read-back per minibatch: the no-cut flag, the split sizes all_to_all_single wants as host ints
+        # and (two-block mode) the per-type own-source edge counts
+        extra = [g.own_source_counts()] if overlap else []
+        both = torch.cat([flag, need_counts, got_counts] + extra).tolist()
+        if int(both[0]) == 0:
             g.no_cut = True
             g.n_halo = 0
             g.need_ids = torch.zeros(0, dtype=torch.int64, device=dev)
@@ -145,16 +152,11 @@ class ShardedGraph:
             g.send_splits = [0] * g.world
             g.recv_splits = [0] * g.world
             g.local_adj = _unflatten(src - g.lo, dst - g.lo, counts)
+            g._flat = g._slot = g._mark = None
             if build_plan:
                 g.build_plan()
             return g
-        need_counts = g.index_locally(adjacency_lists, (src, dst, counts))   # device int64 [world], no host sync yet
-        got_counts = torch.empty_like(need_counts)
-        dist.all_to_all_single(got_counts, need_counts, group=group)
-        # ONE host read-back per minibatch: all_to_all_single wants its split sizes as host ints (and the
-        # two-block mode its per-type own-source edge counts)
-        extra = [g.own_source_counts()] if overlap else []
-        both = torch.cat([need_counts, got_counts] + extra).tolist()
+        both = both[1:]
         g.recv_splits = [int(v) for v in both[: g.world]]            # halo rows I receive per owner
         g.send_splits = [int(v) for v in both[g.world: 2 * g.world]]  # rows I send per peer
         g.n_halo = sum(g.recv_splits)
@@ -183,7 +185,7 @@ class ShardedGraph:
         if any(a != b for a, b in zip(los[1:], his[:-1])) or (los[self.rank], his[self.rank]) != (self.lo, self.hi):
             raise ValueError("node ranges must be contiguous, ordered by rank and contain this rank's range")
         self.bounds_host = los + [his[-1]]
-        self.bounds = torch.tensor(self.bounds_host, dtype=torch.int64, device=device)
+        self.bounds = _to_device_ints(self.bounds_host, device)
 
     def index_locally(self, adjacency_lists: Adj, flat=None) -> torch.Tensor:
         """The collective-free part of `build`: which halo rows this rank needs (de-duplicated, sorted, hence

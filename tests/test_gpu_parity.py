@@ -48,7 +48,8 @@ def ref_csr(adj, num_nodes, transposed=False):
 # plan (integer work: bit exact)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", ["random3", "one_empty_type", "all_empty", "hub", "single", "many_types",
-                                  "types_over_table", "rows_over_2p18", "dense_tiny", "one_row_graph"])
+                                  "types_over_table", "rows_over_2p18", "dense_tiny", "one_row_graph",
+                                  "tile_multiple", "tiles_over_residency"])
 @pytest.mark.parametrize("transposed", [False, True])
 def test_csr_build_bit_exact(case, transposed):
     from ptgnn_amd import ops
@@ -71,9 +72,17 @@ def test_csr_build_bit_exact(case, transposed):
         # 750 edges per row: every bucket of the two-level build spans many 1024-edge chunks
         "dense_tiny": [(torch.randint(0, 40, (30_000,), generator=g), torch.randint(0, 40, (30_000,), generator=g))],
         "one_row_graph": [(torch.zeros(5, dtype=torch.int64), torch.zeros(5, dtype=torch.int64))],
+        # exactly two 4096-edge tiles of the scatter pass
+        "tile_multiple": [(ri(8192), ri(8192))],
+        # 733 tiles: more workgroups than fit on the chip at once, so the look-back of the scatter pass crosses
+        # tiles that were not resident together (ticket order keeps it deadlock-free)
+        "tiles_over_residency": [(torch.randint(0, 200_000, (c,), generator=g), torch.randint(0, 200_000, (c,), generator=g))
+                                 for c in (2_000_000, 1_000_000)],
     }[case]
-    n = {"rows_over_2p18": 300_000, "dense_tiny": 40, "one_row_graph": 1}.get(case, n)
-    plan = ops.build_plan(to_cuda_adj(adj), n, transposed=transposed)
+    n = {"rows_over_2p18": 300_000, "dense_tiny": 40, "one_row_graph": 1, "tiles_over_residency": 200_000}.get(case, n)
+    cadj = to_cuda_adj(adj)
+    ops.build_plan(cadj, n, transposed=transposed)     # a first build: the second one reuses its control block
+    plan = ops.build_plan(cadj, n, transposed=transposed)
     rowptr, col, perm, tb = ref_csr(adj, n, transposed)
     E = len(col)
     assert plan.num_edges == E and plan.type_bits == tb and plan.num_types == len(adj)
@@ -1800,3 +1809,30 @@ def test_sharded_two_block_overlap_mode_equals_unsharded(case, monkeypatch):
         np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
     else:
         assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# the ctypes stub printed there is the documented way into the C ABI -- run it verbatim
+# (also the build path WITHOUT a caller-owned control block: the library zeroes one inside the workspace)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("reduce_id,reduce", [(0, "sum"), (2, "max")])
+def test_integration_md_ctypes_stub_runs_as_printed(reduce_id, reduce):
+    import re
+    from oracle import scatter_ref
+    from ptgnn_amd import _lib
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def aggregate(" in b]
+    assert len(blocks) == 1
+    ns = {}
+    exec(blocks[0].replace('ctypes.CDLL("libptgnn_amd.so")', f'ctypes.CDLL({_lib.LIB_PATH!r})'), ns)
+    g = torch.Generator().manual_seed(77)
+    n, counts = 5000, [9000, 0, 4000, 1]
+    adj = [(torch.randint(0, n, (c,), generator=g), torch.randint(0, n, (c,), generator=g)) for c in counts]
+    msgs = torch.randn(sum(counts), 48, generator=g)
+    for _ in range(2):     # twice: the second build must find the in-workspace control block usable again
+        got = ns["aggregate"](msgs.cuda(), to_cuda_adj(adj), n, reduce_id)
+    want = scatter_ref.scatter(msgs, torch.cat([d for _, d in adj]), dim=0, dim_size=n, reduce=reduce)
+    if reduce == "max":
+        np.testing.assert_array_equal(got.cpu().numpy(), want.numpy())
+    else:
+        assert float((got.cpu() - want).abs().max()) <= TOL
