@@ -61,14 +61,34 @@ __device__ __forceinline__ void guard_record(const RangeGuard &g, int64_t &key, 
   if ((kbad || pbad) && count && g.bad) atomicAdd(g.bad, 1);
 }
 
-// edge e of the type-major concatenation -> (plan row, col payload)
-__device__ __forceinline__ EdgeRec edge_record(const TypeTable &tab, int64_t e, int32_t type_bits, int mode,
-                                               int total_types, const RangeGuard &guard, bool count) {
-  int lo = 0, hi = tab.num_types;   // binary search for the type (<= 6 steps; table lives in SGPRs)
+// type of edge e of the type-major concatenation, known to lie in [lo, hi): binary search over the offsets
+// (<= 6 steps; the table is a kernel argument).  Among equal offsets (empty types) the last one wins, which
+// is the non-empty one.
+__device__ __forceinline__ int type_of(const TypeTable &tab, int64_t e, int lo, int hi) {
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (tab.offset[mid] <= e) lo = mid; else hi = mid;
   }
+  return lo;
+}
+
+// Types the edges [e_first, e_last] of one workgroup's tile can have, [lo, hi).  Both ends are workgroup-uniform,
+// so the two searches run on the scalar unit; a tile inside ONE type (the rule: 4096 consecutive edges) then needs
+// no per-lane search at all and indexes the pointer table with a uniform value (scalar loads instead of a
+// per-lane walk over the argument table).
+struct TypeSpan { int lo, hi; };
+__device__ __forceinline__ TypeSpan tile_types(const TypeTable &tab, int64_t e_first, int64_t e_last) {
+  TypeSpan sp;
+  sp.lo = __builtin_amdgcn_readfirstlane(type_of(tab, e_first, 0, tab.num_types));
+  sp.hi = __builtin_amdgcn_readfirstlane(type_of(tab, e_last, sp.lo, tab.num_types)) + 1;
+  return sp;
+}
+
+// edge e of the type-major concatenation -> (plan row, col payload); `span`: see tile_types
+__device__ __forceinline__ EdgeRec edge_record(const TypeTable &tab, int64_t e, int32_t type_bits, int mode,
+                                               int total_types, const RangeGuard &guard, bool count,
+                                               TypeSpan span) {
+  const int lo = span.hi - span.lo == 1 ? span.lo : type_of(tab, e, span.lo, span.hi);
   const int64_t i = e - tab.offset[lo];
   int64_t s = tab.src[lo][i], d = tab.dst[lo][i];
   const int64_t ty = tab.type_base + lo;
@@ -96,7 +116,7 @@ __global__ __launch_bounds__(256) void k_pack(TypeTable tab, int32_t type_bits, 
   const int64_t total = tab.offset[tab.num_types];
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
-    const EdgeRec r = edge_record(tab, e, type_bits, mode, total_types, guard, true);
+    const EdgeRec r = edge_record(tab, e, type_bits, mode, total_types, guard, true, TypeSpan{0, tab.num_types});
     const int64_t g = pos_base + e;
     pos[g] = (int32_t)g;
     keys[g] = r.key;
@@ -188,15 +208,18 @@ __global__ __launch_bounds__(kSortBlock) void k_radix_scatter(
 // The LSD sort above needs 2 x (histogram, scan, scatter) + pack + finish + hub list = 11 dependent
 // launches whose 4-byte scatters land two-at-a-time in random cache lines.  Rows are node ids, i.e.
 // roughly uniformly populated, so the plan is built MSD-first in THREE launches:
-//   k_plan_count    digit totals of the HIGH row bits (reads only the key column of the int64 lists: LDS
-//                   histogram per 4096-edge tile, one global atomic per (tile, digit) into the control block)
-//                   and zeroes the look-back status rows of the next kernel
+//   k_plan_count    per 4096-edge tile: LDS histogram of the HIGH row bits (reads only the key column of the
+//                   int64 lists), stored as the tile's row of the aggregate table; digit totals by one global
+//                   atomic per (tile, digit) into the control block (4 replicas against same-address contention)
 //   k_plan_scatter  one pass over the lists: stable scatter of 8-byte records (low row bits | position,
 //                   payload) into <= 512 buckets of 2^low_bits consecutive rows.  The cross-tile prefix of every
-//                   digit comes from a decoupled look-back over per-(tile, digit) status words (aggregate /
-//                   inclusive-prefix flag + value in ONE 32-bit word, agent-scope atomics, so no fences); tiles
-//                   take their id from a ticket counter, hence every tile a block waits on has already started
-//                   (forward progress without co-residency, the rocPRIM / onesweep argument)
+//                   digit is the column sum of the aggregate rows of all earlier tiles (complete: previous
+//                   launch): all 1024 threads, dwordx4, 32 rows per step, plain cached loads -- no flags, no
+//                   inter-workgroup communication or ordering.  Quadratic in the tile count, which the 4 M-edge
+//                   ceiling of this path bounds at 1024 (72 MB of L2 reads at 1.1 M edges).  A decoupled
+//                   look-back over (flag | value) status words was measured against it: its agent-scope loads go
+//                   to the memory side on this multi-L2 part (~1 us per dependent step) and it was never faster
+//                   (625 k edges / 153 tiles: 18.0 vs 15.7 us per launch; 1.1 M edges / 269 tiles: 28.2 vs 28.5)
 //   k_plan_buckets  one workgroup per bucket: histogram of the LOW bits = the in-degrees -> rowptr and
 //                   the hub list directly; stable counting sort of the bucket into col / perm; the last
 //                   workgroup to have read the control block zeroes it again
@@ -204,7 +227,7 @@ __global__ __launch_bounds__(kSortBlock) void k_radix_scatter(
 // lists are read 1.5 times (8 + 16 B/edge) against 2 x 16 B/edge + a scan launch for the histogram/scan/scatter
 // form this replaces.  Stability of both levels = the order of a numpy stable argsort (tests: bit-exact).
 //
-// Control block (PlanControl, ptgnn_amd_csr_control_bytes()): digit totals + two counters, ZERO AT REST -- the
+// Control block (PlanControl, ptgnn_amd_csr_control_bytes()): digit totals + one counter, ZERO AT REST -- the
 // caller zero-fills it once, hands it to every build on ONE stream, and finds it zero-filled again after each
 // build.  A null control pointer makes the library carve one out of the workspace and zero it with a memset
 // node per build.
@@ -213,14 +236,19 @@ constexpr int kTileRounds = 4;
 constexpr int kTileEdges = kMsdBlock * kTileRounds;   // edges per tile of k_plan_count / k_plan_scatter
 constexpr int kPosBits = 22;                          // record.x = low row bits << 22 | position (E <= 4 M)
 
+constexpr int kTotalReplicas = 4;
 struct PlanControl {
-  int32_t totals[kMaxBins];
-  int32_t ticket;   // next tile id of k_plan_scatter
-  int32_t done;     // k_plan_buckets workgroups that have finished reading `totals`
-  int32_t pad[2];
+  int32_t totals[kTotalReplicas][kMaxBins];   // digit totals, replica = tile % 4
+  int32_t done;                               // k_plan_buckets workgroups that have finished reading `totals`
+  int32_t pad[3];
 };
 
-constexpr uint32_t kFlagAggregate = 1u << 30, kFlagInclusive = 2u << 30, kValueMask = (1u << 30) - 1u;
+__device__ __forceinline__ int digit_total(const PlanControl *ctl, int d) {
+  int v = 0;
+#pragma unroll
+  for (int r = 0; r < kTotalReplicas; ++r) v += ctl->totals[r][d];
+  return v;
+}
 
 // exclusive scan of v over threads 0 .. 511 of a 1024-thread block (tmp: 8 ints of LDS); returns the
 // exclusive prefix
@@ -242,12 +270,8 @@ __device__ __forceinline__ int block_scan_512(int v, int *tmp) {
 
 // plan row of edge e (the sort key), reading only the column that holds it; same clamping as edge_record
 __device__ __forceinline__ uint32_t edge_key(const TypeTable &tab, int64_t e, int mode, int total_types,
-                                             const RangeGuard &guard) {
-  int lo = 0, hi = tab.num_types;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (tab.offset[mid] <= e) lo = mid; else hi = mid;
-  }
+                                             const RangeGuard &guard, TypeSpan span) {
+  const int lo = span.hi - span.lo == 1 ? span.lo : type_of(tab, e, span.lo, span.hi);
   const int64_t i = e - tab.offset[lo];
   int64_t key;
   if (mode == 2) {
@@ -261,24 +285,26 @@ __device__ __forceinline__ uint32_t edge_key(const TypeTable &tab, int64_t e, in
 
 __global__ __launch_bounds__(kMsdBlock) void k_plan_count(TypeTable tab, int mode, int total_types, int64_t n,
                                                           int low_bits, int bins, PlanControl *ctl,
-                                                          uint32_t *__restrict__ status, int32_t *hub_count,
+                                                          int32_t *__restrict__ agg, int32_t *hub_count,
                                                           RangeGuard guard) {
   __shared__ int lh[kMaxBins];
-  for (int j = threadIdx.x; j < bins; j += kMsdBlock) {
-    lh[j] = 0;
-    status[(int64_t)blockIdx.x * bins + j] = 0u;   // "not ready" for the look-back of the next kernel
-  }
+  for (int j = threadIdx.x; j < bins; j += kMsdBlock) lh[j] = 0;
   if (hub_count && blockIdx.x == 0 && threadIdx.x == 0) *hub_count = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kTileEdges;
+  const TypeSpan span = tile_types(tab, base, (base + kTileEdges < n ? base + kTileEdges : n) - 1);
 #pragma unroll
   for (int r = 0; r < kTileRounds; ++r) {
     const int64_t e = base + r * kMsdBlock + threadIdx.x;
-    if (e < n) atomicAdd(&lh[edge_key(tab, e, mode, total_types, guard) >> low_bits], 1);
+    if (e < n) atomicAdd(&lh[edge_key(tab, e, mode, total_types, guard, span) >> low_bits], 1);
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < bins; j += kMsdBlock)
-    if (lh[j]) atomicAdd(&ctl->totals[j], lh[j]);
+  const int bp = (bins + 3) & ~3;                     // row stride of the aggregate table (dwordx4 reads)
+  for (int j = threadIdx.x; j < bp; j += kMsdBlock) {
+    const int c = j < bins ? lh[j] : 0;
+    agg[(int64_t)blockIdx.x * bp + j] = c;
+    if (c) atomicAdd(&ctl->totals[blockIdx.x % kTotalReplicas][j], c);
+  }
 }
 
 // stable rank of this lane's digit inside a 1024-thread block: (earlier waves' count, rank in wave)
@@ -300,11 +326,17 @@ __device__ __forceinline__ int block_stable_rank(bool valid, int digit, int bits
   if (valid && rank == 0) wave_cnt[wave * bins + digit] = __popcll(same);
   __syncthreads();
   int run = 0;
-  for (int d = threadIdx.x; d < bins; d += kMsdBlock) {     // bins <= 512 < block: one digit per thread
-    for (int w = 0; w < kMsdBlock / 64; ++w) {
-      const int t = wave_cnt[w * bins + d];
-      wave_cnt[w * bins + d] = run;
-      run += t;
+  if (threadIdx.x < bins) {     // bins <= 512 < block: one digit per thread
+    // all 16 counts first (independent LDS reads in flight together), then the prefix: written as a
+    // read-modify-write loop the accesses form a 16-deep dependent chain of LDS round trips
+    constexpr int W = kMsdBlock / 64;
+    int c[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) c[w] = wave_cnt[w * bins + threadIdx.x];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      wave_cnt[w * bins + threadIdx.x] = run;
+      run += c[w];
     }
   }
   *run_out = run;
@@ -312,75 +344,71 @@ __device__ __forceinline__ int block_stable_rank(bool valid, int digit, int bits
   return valid ? wave_cnt[wave * bins + digit] + rank : 0;
 }
 
-__global__ __launch_bounds__(kMsdBlock) void k_plan_scatter(TypeTable tab, int32_t type_bits, int mode,
+// 8 waves per SIMD = two 16-wave workgroups per CU (<= 64 VGPRs): with one, the tiles beyond 256 run as a second
+// round and double the kernel time at cfg2's 269 tiles
+__global__ __launch_bounds__(kMsdBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_plan_scatter(TypeTable tab, int32_t type_bits, int mode,
                                                             int total_types, int64_t n, int low_bits,
-                                                            int high_bits, int bins, PlanControl *ctl,
-                                                            uint32_t *status, int2 *__restrict__ recs,
-                                                            RangeGuard guard) {
-  __shared__ int wave_cnt[(kMsdBlock / 64) * kMaxBins];
+                                                            int high_bits, int bins, const PlanControl *ctl,
+                                                            const int32_t *__restrict__ agg,
+                                                            int2 *__restrict__ recs, RangeGuard guard) {
+  __shared__ __attribute__((aligned(16))) int wave_cnt[(kMsdBlock / 64) * kMaxBins];
   __shared__ int base[kMaxBins];
   __shared__ int tile_excl[kMaxBins];
   __shared__ int round_base[kTileRounds][kMaxBins];
   __shared__ int tmp[8];
-  __shared__ int tile_s;
-  if (threadIdx.x == 0) tile_s = atomicAdd(&ctl->ticket, 1);
+  const int tile = blockIdx.x;
   {   // where each bucket starts in the record array: prefix of the digit totals (complete: previous launch)
-    const int v = threadIdx.x < bins ? ctl->totals[threadIdx.x] : 0;
-    const int ex = block_scan_512(v, tmp);          // synchronises: tile_s is visible afterwards
+    const int v = threadIdx.x < bins ? digit_total(ctl, threadIdx.x) : 0;
+    const int ex = block_scan_512(v, tmp);
     if (threadIdx.x < bins) base[threadIdx.x] = ex;
   }
-  const int tile = tile_s;
   const uint32_t low_mask = (1u << low_bits) - 1u;
   EdgeRec rec[kTileRounds];
+  const TypeSpan span = tile_types(tab, (int64_t)tile * kTileEdges,
+                                   ((int64_t)(tile + 1) * kTileEdges < n ? (int64_t)(tile + 1) * kTileEdges : n) - 1);
+#pragma unroll
+  for (int r = 0; r < kTileRounds; ++r) {            // issued first: in flight under the prefix sums
+    const int64_t e = (int64_t)tile * kTileEdges + r * kMsdBlock + threadIdx.x;
+    rec[r] = EdgeRec{0u, 0};
+    if (e < n) rec[r] = edge_record(tab, e, type_bits, mode, total_types, guard, true, span);
+  }
+  {
+    // exclusive cross-tile prefix of every digit = column sums of the aggregate rows of tiles 0 .. tile-1:
+    // thread (g, q) adds rows g, g+8, ... for digits 4q .. 4q+3; the 8 partials meet in LDS (the rank table's
+    // storage, not yet in use)
+    const int bp = (bins + 3) & ~3;
+    const int q = threadIdx.x & 127, g = threadIdx.x >> 7;
+    int4 acc = make_int4(0, 0, 0, 0);
+    if (4 * q < bp) {
+#pragma unroll 4
+      for (int r = g; r < tile; r += 8) {
+        const int4 v = *reinterpret_cast<const int4 *>(agg + (int64_t)r * bp + 4 * q);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<int4 *>(wave_cnt + g * kMaxBins + 4 * q) = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < bins) {
+      int e8 = 0;
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) e8 += wave_cnt[gg * kMaxBins + threadIdx.x];
+      tile_excl[threadIdx.x] = e8;
+    }
+    __syncthreads();                                 // the rank rounds clear wave_cnt next
+  }
   int local[kTileRounds];
   int mine = 0;                                      // threads < bins: this tile's count of digit threadIdx.x
 #pragma unroll
   for (int r = 0; r < kTileRounds; ++r) {
     const int64_t e = (int64_t)tile * kTileEdges + r * kMsdBlock + threadIdx.x;
-    const bool valid = e < n;
-    rec[r] = EdgeRec{0u, 0};
-    if (valid) rec[r] = edge_record(tab, e, type_bits, mode, total_types, guard, true);
     int run;
-    local[r] = block_stable_rank(valid, (int)(rec[r].key >> low_bits), high_bits, bins, wave_cnt, &run);
+    local[r] = block_stable_rank(e < n, (int)(rec[r].key >> low_bits), high_bits, bins, wave_cnt, &run);
     if (threadIdx.x < bins) {
       round_base[r][threadIdx.x] = mine;
       mine += run;
     }
     __syncthreads();                                 // wave_cnt is cleared again by the next round
   }
-  if (threadIdx.x < bins) {
-    // decoupled look-back: publish this tile's aggregate, sum the predecessors' back to the first tile that
-    // already knows its inclusive prefix, publish ours
-    uint32_t *my = status + (int64_t)tile * bins + threadIdx.x;
-    uint32_t excl = 0;
-    if (tile == 0) {
-      __hip_atomic_store(my, kFlagInclusive | (uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __hip_atomic_store(my, kFlagAggregate | (uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int t = tile - 1;
-      int spins = 0;
-      while (true) {
-        const uint32_t v = __hip_atomic_load(status + (int64_t)t * bins + threadIdx.x, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
-        if ((v >> 30) == 0u) {
-          // predecessor still counting.  It holds a lower ticket, so it is running; the bound only turns a
-          // broken invariant into a flagged build (bad-index counter) instead of a hung GPU.
-          if (++spins > (1 << 24)) {
-            if (guard.bad) atomicAdd(guard.bad, 1);
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
-          continue;
-        }
-        excl += v & kValueMask;
-        if (v & kFlagInclusive) break;
-        --t;
-      }
-      __hip_atomic_store(my, kFlagInclusive | (excl + (uint32_t)mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    tile_excl[threadIdx.x] = (int)excl;
-  }
-  __syncthreads();
 #pragma unroll
   for (int r = 0; r < kTileRounds; ++r) {
     const int64_t e = (int64_t)tile * kTileEdges + r * kMsdBlock + threadIdx.x;
@@ -404,7 +432,7 @@ __global__ __launch_bounds__(kMsdBlock) void k_plan_buckets(
   const int b = blockIdx.x;
   const int lbins = 1 << low_bits, mask = lbins - 1;
   {   // where this bucket starts in the record array: prefix of the digit totals
-    const int v = threadIdx.x < bins ? ctl->totals[threadIdx.x] : 0;
+    const int v = threadIdx.x < bins ? digit_total(ctl, threadIdx.x) : 0;
     const int ex = block_scan_512(v, tmp);
     if (threadIdx.x == b) { bucket_start_s = ex; bucket_size_s = v; }
   }
@@ -417,8 +445,8 @@ __global__ __launch_bounds__(kMsdBlock) void k_plan_buckets(
   for (int i = s + threadIdx.x; i < e; i += kMsdBlock) atomicAdd(&offs[(recs[i].x >> kPosBits) & mask], 1);
   __syncthreads();
   if (last_s) {
-    for (int j = threadIdx.x; j < kMaxBins; j += kMsdBlock) ctl->totals[j] = 0;
-    if (threadIdx.x == 0) { ctl->ticket = 0; ctl->done = 0; }
+    for (int j = threadIdx.x; j < kTotalReplicas * kMaxBins; j += kMsdBlock) (&ctl->totals[0][0])[j] = 0;
+    if (threadIdx.x == 0) ctl->done = 0;
   }
   {   // in-degrees -> rowptr (+ hub rows); offs becomes the running write cursor of each row
     const int deg = threadIdx.x < lbins ? offs[threadIdx.x] : 0;
@@ -659,7 +687,7 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
     const int high_bits = total_bits - low_bits;
     const int bins = (int)((num_nodes + ((int64_t)1 << low_bits) - 1) >> low_bits);
     const int64_t ntiles = (num_edges + kTileEdges - 1) / kTileEdges;
-    uint32_t *status = (uint32_t *)(ws + L.hist);   // [ntiles][bins] look-back words (<= the LSD path's histograms)
+    int32_t *agg = (int32_t *)(ws + L.hist);        // [ntiles][bins rounded up to 4] per-tile digit counts
     int2 *recs = (int2 *)ws;      // 8 B/edge over the (unused) key/pos/payload buffers of the LSD path
     PlanControl *ctl = (PlanControl *)control;
     if (ctl == nullptr) {         // no caller-owned control block: one inside the workspace, zeroed per build
@@ -668,10 +696,10 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
     }
     const bool hubs = hub_entries && hub_count && hub_threshold > 0;
     k_plan_count<<<(unsigned)ntiles, kMsdBlock, 0, stream>>>(tab, swap_src_dst, num_types, num_edges, low_bits, bins,
-                                                            ctl, status, hubs ? hub_count : nullptr, guard);
+                                                            ctl, agg, hubs ? hub_count : nullptr, guard);
     PTGNN_LAUNCH_CHECK();
     k_plan_scatter<<<(unsigned)ntiles, kMsdBlock, 0, stream>>>(tab, type_bits, swap_src_dst, num_types, num_edges,
-                                                              low_bits, high_bits, bins, ctl, status, recs, guard);
+                                                              low_bits, high_bits, bins, ctl, agg, recs, guard);
     PTGNN_LAUNCH_CHECK();
     k_plan_buckets<<<(unsigned)bins, kMsdBlock, 0, stream>>>(recs, ctl, bins, low_bits, num_nodes, num_edges,
                                                              rowptr, col, perm, hubs ? hub_threshold : 0, 1024,
