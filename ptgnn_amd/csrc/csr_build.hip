@@ -442,7 +442,20 @@ __global__ __launch_bounds__(kMsdBlock) void k_plan_buckets(
   // control block back to its zero-at-rest state
   if (threadIdx.x == 0) last_s = atomicAdd(&ctl->done, 1) == (int)gridDim.x - 1;
   const int s = bucket_start_s, e = s + bucket_size_s;
-  for (int i = s + threadIdx.x; i < e; i += kMsdBlock) atomicAdd(&offs[(recs[i].x >> kPosBits) & mask], 1);
+  // the first 4096 records of the bucket (all of it, as a rule) stay in registers for both passes: one memory
+  // round trip with four loads in flight instead of two passes of dependent ones
+  constexpr int KC = kTileRounds;
+  int2 rc[KC];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    const int i = s + k * kMsdBlock + threadIdx.x;
+    rc[k] = i < e ? recs[i] : make_int2(0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < KC; ++k)
+    if (s + k * kMsdBlock + (int)threadIdx.x < e) atomicAdd(&offs[(rc[k].x >> kPosBits) & mask], 1);
+  for (int i = s + KC * kMsdBlock + threadIdx.x; i < e; i += kMsdBlock)
+    atomicAdd(&offs[(recs[i].x >> kPosBits) & mask], 1);
   __syncthreads();
   if (last_s) {
     for (int j = threadIdx.x; j < kTotalReplicas * kMaxBins; j += kMsdBlock) (&ctl->totals[0][0])[j] = 0;
@@ -471,11 +484,7 @@ __global__ __launch_bounds__(kMsdBlock) void k_plan_buckets(
     }
   }
   __syncthreads();
-  for (int cb = s; cb < e; cb += kMsdBlock) {
-    const int i = cb + threadIdx.x;
-    const bool valid = i < e;
-    int2 r = make_int2(0, 0);
-    if (valid) r = recs[i];
+  auto place = [&](bool valid, int2 r) {   // one 1024-record chunk, in record order
     const int digit = (r.x >> kPosBits) & mask;
     int run;
     const int local = block_stable_rank(valid, digit, low_bits, lbins, wave_cnt, &run);   // syncs inside
@@ -486,7 +495,14 @@ __global__ __launch_bounds__(kMsdBlock) void k_plan_buckets(
     }
     __syncthreads();
     if (threadIdx.x < lbins) offs[threadIdx.x] += run;
-    // the next iteration's block_stable_rank synchronises before offs is read again
+    // the next chunk's block_stable_rank synchronises before offs is read again
+  };
+#pragma unroll
+  for (int k = 0; k < KC; ++k)
+    if (s + k * kMsdBlock < e) place(s + k * kMsdBlock + (int)threadIdx.x < e, rc[k]);   // workgroup-uniform test
+  for (int cb = s + KC * kMsdBlock; cb < e; cb += kMsdBlock) {
+    const int i = cb + threadIdx.x;
+    place(i < e, i < e ? recs[i] : make_int2(0, 0));
   }
 }
 
