@@ -322,6 +322,28 @@ int ptgnn_amd_segment_spread_f32(const float *grad, int64_t ld_grad, const int32
                                  int32_t dim, float *out, int64_t ld_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Row epilogue of the MLP message-passing layer as a differentiable pair (the training step; in inference the
+ * same arithmetic is the `epilogue` of ptgnn_amd_gather_reduce_f32):
+ *   y = LayerNorm(GELU(x))   with `flags` = PTGNN_AMD_EPI_* naming which of the two apply
+ * Replaces: nn.GELU() -> nn.LayerNorm(message_dimension) at mlpmessagepassing.py:20,44-47,114-116 and their autograd
+ *   (exact-erf GELU; LayerNorm eps / affine as given; two-pass mean / variance), x, y, grad_* [rows, dim] fp32,
+ *   dim <= 512.  The forward equals the fused inference epilogue bit for bit.
+ * Backward: grad_x [rows, dim]; grad_gamma / grad_beta [dim] (LayerNorm only; OVERWRITTEN, deterministic: per-
+ *   workgroup partial rows in `workspace` (ptgnn_amd_row_epilogue_workspace_bytes) summed in a fixed order).
+ * ---------------------------------------------------------------------------------------- */
+int ptgnn_amd_row_epilogue_f32(const float *x, int64_t ld_x, int64_t rows, int32_t dim, int32_t flags,
+                               const float *ln_gamma /* nullable without LayerNorm */,
+                               const float *ln_beta /* nullable without LayerNorm */, float ln_eps, float *y,
+                               int64_t ld_y, void *stream);
+size_t ptgnn_amd_row_epilogue_workspace_bytes(int64_t rows, int32_t dim);
+int ptgnn_amd_row_epilogue_backward_f32(const float *x, int64_t ld_x, const float *grad_y, int64_t ld_gy,
+                                        int64_t rows, int32_t dim, int32_t flags, const float *ln_gamma,
+                                        float ln_eps, float *grad_x, int64_t ld_gx,
+                                        float *grad_gamma /* nullable without LayerNorm */,
+                                        float *grad_beta /* nullable without LayerNorm */, void *workspace,
+                                        size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * h' = GRUCell(a, h)  (gate order r, z, n), gatedmessagepassing.py:25,69.
  *   a [n, m], h [n, hd], w_ih [3hd, m], w_hh [3hd, hd], b_ih/b_hh [3hd], out [n, hd].
  *   Gate GEMMs run on fp32 MFMA with the gate non-linearities fused in the epilogue; no

@@ -1,0 +1,334 @@
+// Row epilogue of the MLP message-passing layer as a differentiable pair: y = LayerNorm(GELU(x)) over the rows
+// of the aggregated message matrix, and its backward.  Contract + reference lines: include/ptgnn_amd.h
+// (ptgnn_amd_row_epilogue_f32 / _backward_f32).
+//
+// In inference the same arithmetic is the epilogue of the gather/segment-reduce kernel (gather_reduce.hip); the
+// training step needs it as an autograd node: the pre-activation rows must survive for the backward, and the
+// backward itself (d LayerNorm -> d GELU -> column sums for d gamma / d beta) was three torch kernels of
+// ~100 us each at [116 k, 64] -- their row reductions are written for wide rows -- plus the exact-erf GELU pair.
+//
+// Mapping (HBM-bound: forward reads + writes N*M floats, backward reads 2, writes 1): one row per group of LPR
+// lanes, LPR = M/4 rounded up to {16, 32, 64} (float4 columns, CH column chunks per lane), like the aggregation
+// kernel, so a wave moves 1 KiB per instruction whatever the row width; the row statistics are LPR-wide
+// shuffles.  The backward walks rows with a grid stride so that every lane accumulates d gamma / d beta of ITS
+// columns in registers; a workgroup folds its row groups through LDS and stores one partial row, and a second
+// small kernel sums the partial rows in a fixed order (deterministic, no float atomics).
+// Numerics: the forward is statement for statement the epilogue of gather_reduce.hip (two-pass mean / variance,
+// exact-erf GELU), so the training forward equals the inference forward bit for bit.
+#include <type_traits>
+
+#include "common.h"
+
+namespace ptgnn_amd {
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR);
+  return v;
+}
+
+struct RowArgs {
+  const float *x; int64_t ld_x;
+  const float *dy; int64_t ld_dy;
+  float *out; int64_t ld_out;          // forward: y; backward: dx
+  const float *gamma, *beta;
+  float eps;
+  int64_t rows;
+  int M;
+  int flags;                           // PTGNN_AMD_EPI_*
+  float *partial;                      // backward: [gridDim.x][2 * M] (d gamma | d beta) per workgroup
+};
+
+// Row state of one lane group: CH chunks of VEC columns per lane; column of (c, v) = (g + c * LPR) * VEC + v.
+template <int VEC, int LPR, int CH>
+struct Row {
+  float a[CH][VEC];
+  __device__ __forceinline__ void load(const float *row, int g, int M, float fill = 0.f) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (g + c * LPR) * VEC;
+      if constexpr (VEC == 4) {
+        if (col < M) {
+          const float4 t = *reinterpret_cast<const float4 *>(row + col);
+          a[c][0] = t.x; a[c][1] = t.y; a[c][2] = t.z; a[c][3] = t.w;
+        } else {
+          a[c][0] = a[c][1] = a[c][2] = a[c][3] = fill;
+        }
+      } else {
+        a[c][0] = col < M ? row[col] : fill;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float *row, int g, int M) const {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (g + c * LPR) * VEC;
+      if (col >= M) continue;
+      if constexpr (VEC == 4) *reinterpret_cast<float4 *>(row + col) = make_float4(a[c][0], a[c][1], a[c][2], a[c][3]);
+      else row[col] = a[c][0];
+    }
+  }
+};
+
+// mean and 1/std of the row held in `r` (two passes, as the aggregation epilogue does)
+template <int VEC, int LPR, int CH>
+__device__ __forceinline__ void row_stats(const Row<VEC, LPR, CH> &r, int g, int M, float eps, float &mean, float &rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s += ((g + c * LPR) * VEC + v < M) ? r.a[c][v] : 0.f;
+  mean = group_sum<LPR>(s) / (float)M;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float d = r.a[c][v] - mean;
+      q += ((g + c * LPR) * VEC + v < M) ? d * d : 0.f;
+    }
+  rstd = 1.0f / sqrtf(group_sum<LPR>(q) / (float)M + eps);
+}
+
+template <int VEC, int LPR, int CH>
+__global__ __launch_bounds__(kBlock) void k_row_epilogue(RowArgs p) {
+  constexpr int G = kBlock / LPR;
+  const int g = threadIdx.x % LPR;
+  const int64_t row = (int64_t)blockIdx.x * G + threadIdx.x / LPR;
+  if (row >= p.rows) return;          // whole lane group leaves together
+  Row<VEC, LPR, CH> r;
+  r.load(p.x + row * p.ld_x, g, p.M);
+  if (p.flags & PTGNN_AMD_EPI_GELU) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) r.a[c][v] = gelu_erf(r.a[c][v]);
+  }
+  if (p.flags & PTGNN_AMD_EPI_LAYERNORM) {
+    float mean, rstd;
+    row_stats(r, g, p.M, p.eps, mean, rstd);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const int col = (g + c * LPR) * VEC + v;
+        if (col < p.M) r.a[c][v] = (r.a[c][v] - mean) * rstd * p.gamma[col] + p.beta[col];
+      }
+  }
+  r.store(p.out + row * p.ld_out, g, p.M);
+}
+
+template <int VEC, int LPR, int CH>
+__global__ __launch_bounds__(kBlock) void k_row_epilogue_backward(RowArgs p) {
+  constexpr int G = kBlock / LPR;
+  __shared__ float fold[kBlock * VEC * CH * 2];
+  const int g = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  const bool ln = (p.flags & PTGNN_AMD_EPI_LAYERNORM) != 0, gelu = (p.flags & PTGNN_AMD_EPI_GELU) != 0;
+  float gam[CH][VEC], dgam[CH][VEC], dbet[CH][VEC];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int col = (g + c * LPR) * VEC + v;
+      gam[c][v] = (ln && col < p.M) ? p.gamma[col] : 0.f;
+      dgam[c][v] = dbet[c][v] = 0.f;
+    }
+  // rows this lane group owns: group index, then a grid stride (all groups of the grid interleave)
+  for (int64_t row = (int64_t)blockIdx.x * G + grp; row < p.rows; row += (int64_t)gridDim.x * G) {
+    Row<VEC, LPR, CH> x, d, h;
+    x.load(p.x + row * p.ld_x, g, p.M);
+    d.load(p.dy + row * p.ld_dy, g, p.M);
+    h = x;
+    if (gelu) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) h.a[c][v] = gelu_erf(x.a[c][v]);
+    }
+    if (ln) {
+      float mean, rstd;
+      row_stats(h, g, p.M, p.eps, mean, rstd);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const bool in = (g + c * LPR) * VEC + v < p.M;
+          const float xhat = in ? (h.a[c][v] - mean) * rstd : 0.f;
+          const float dy = in ? d.a[c][v] : 0.f;
+          dgam[c][v] += dy * xhat;
+          dbet[c][v] += dy;
+          const float dxh = dy * gam[c][v];
+          h.a[c][v] = xhat;            // keep x-hat
+          d.a[c][v] = dxh;             // and d x-hat
+          s1 += dxh;
+          s2 += dxh * xhat;
+        }
+      const float m1 = group_sum<LPR>(s1) / (float)p.M, m2 = group_sum<LPR>(s2) / (float)p.M;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) d.a[c][v] = rstd * (d.a[c][v] - m1 - h.a[c][v] * m2);
+    }
+    if (gelu) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) d.a[c][v] *= gelu_erf_grad(x.a[c][v]);
+    }
+    d.store(p.out + row * p.ld_out, g, p.M);
+  }
+  if (!ln) return;
+  // fold the G lane groups of this workgroup (fixed order) and store one partial row
+  constexpr int W = LPR * VEC * CH;       // padded row width held by one group
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      fold[(grp * W + (g + c * LPR) * VEC + v) * 2] = dgam[c][v];
+      fold[(grp * W + (g + c * LPR) * VEC + v) * 2 + 1] = dbet[c][v];
+    }
+  __syncthreads();
+  for (int col = threadIdx.x; col < p.M; col += kBlock) {
+    float sg = 0.f, sb = 0.f;
+    for (int q = 0; q < G; ++q) {
+      sg += fold[(q * W + col) * 2];
+      sb += fold[(q * W + col) * 2 + 1];
+    }
+    p.partial[(int64_t)blockIdx.x * 2 * p.M + col] = sg;
+    p.partial[(int64_t)blockIdx.x * 2 * p.M + p.M + col] = sb;
+  }
+}
+
+// out[j] = sum over partial rows (fixed order: 4 interleaved slices, then the slices); j < 2 M
+__global__ __launch_bounds__(kBlock) void k_partial_rows_sum(const float *__restrict__ partial, int nrows, int width,
+                                                             float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                             int M) {
+  __shared__ float s[4][64];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (j < width)
+    for (int r = slice; r < nrows; r += 4) acc += partial[(int64_t)r * width + j];
+  s[slice][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (slice == 0 && j < width) {
+    const float t = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    if (j < M) dgamma[j] = t; else dbeta[j - M] = t;
+  }
+}
+
+int backward_blocks(int64_t rows, int groups_per_block) {
+  // enough workgroups to fill the chip several times over, few enough partial rows to sum cheaply
+  int64_t b = (rows + groups_per_block - 1) / groups_per_block;
+  if (b > 2048) b = 2048;
+  return (int)(b < 1 ? 1 : b);
+}
+
+template <typename F>
+int dispatch(bool vec4, int M, F f) {
+  if (vec4) {
+    if (M <= 64) return f(std::integral_constant<int, 4>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
+    if (M <= 128) return f(std::integral_constant<int, 4>{}, std::integral_constant<int, 32>{}, std::integral_constant<int, 1>{});
+    if (M <= 256) return f(std::integral_constant<int, 4>{}, std::integral_constant<int, 64>{}, std::integral_constant<int, 1>{});
+    return f(std::integral_constant<int, 4>{}, std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{});
+  }
+  if (M <= 64) return f(std::integral_constant<int, 1>{}, std::integral_constant<int, 64>{}, std::integral_constant<int, 1>{});
+  if (M <= 256) return f(std::integral_constant<int, 1>{}, std::integral_constant<int, 64>{}, std::integral_constant<int, 4>{});
+  return f(std::integral_constant<int, 1>{}, std::integral_constant<int, 64>{}, std::integral_constant<int, 8>{});
+}
+
+int check_common(const char *who, const float *x, int64_t ld_x, int64_t rows, int32_t dim, int32_t flags,
+                 const float *gamma) {
+  PTGNN_REQUIRE(rows >= 0 && dim > 0 && dim <= 512, PTGNN_AMD_EUNSUPPORTED, "%s: row width %d outside (0, 512]", who, dim);
+  PTGNN_REQUIRE(flags > 0 && flags <= PTGNN_AMD_EPI_GELU_LAYERNORM, PTGNN_AMD_EINVAL, "%s: flags must name GELU and/or LayerNorm", who);
+  PTGNN_REQUIRE(rows == 0 || (x != nullptr && ld_x >= dim), PTGNN_AMD_EINVAL, "%s: bad input matrix", who);
+  PTGNN_REQUIRE(!(flags & PTGNN_AMD_EPI_LAYERNORM) || gamma != nullptr, PTGNN_AMD_EINVAL, "%s: LayerNorm needs gamma", who);
+  return PTGNN_AMD_OK;
+}
+
+}  // namespace
+}  // namespace ptgnn_amd
+
+using namespace ptgnn_amd;
+
+extern "C" int ptgnn_amd_row_epilogue_f32(const float *x, int64_t ld_x, int64_t rows, int32_t dim, int32_t flags,
+                                          const float *ln_gamma, const float *ln_beta, float ln_eps, float *y,
+                                          int64_t ld_y, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  if (int rc = check_common("row_epilogue", x, ld_x, rows, dim, flags, ln_gamma)) return rc;
+  PTGNN_REQUIRE(!(flags & PTGNN_AMD_EPI_LAYERNORM) || ln_beta != nullptr, PTGNN_AMD_EINVAL, "row_epilogue: LayerNorm needs beta");
+  PTGNN_REQUIRE(rows == 0 || (y != nullptr && ld_y >= dim), PTGNN_AMD_EINVAL, "row_epilogue: bad output matrix");
+  if (rows == 0) return PTGNN_AMD_OK;
+  RowArgs p{};
+  p.x = x; p.ld_x = ld_x; p.out = y; p.ld_out = ld_y; p.gamma = ln_gamma; p.beta = ln_beta; p.eps = ln_eps;
+  p.rows = rows; p.M = dim; p.flags = flags;
+  const bool vec4 = dim % 4 == 0 && ld_x % 4 == 0 && ld_y % 4 == 0 && aligned16(x) && aligned16(y);
+  return dispatch(vec4, dim, [&](auto VEC, auto LPR, auto CH) -> int {
+    constexpr int G = kBlock / decltype(LPR)::value;
+    k_row_epilogue<decltype(VEC)::value, decltype(LPR)::value, decltype(CH)::value>
+        <<<(unsigned)((rows + G - 1) / G), kBlock, 0, st>>>(p);
+    PTGNN_LAUNCH_CHECK();
+    return (int)PTGNN_AMD_OK;
+  });
+}
+
+extern "C" size_t ptgnn_amd_row_epilogue_workspace_bytes(int64_t rows, int32_t dim) {
+  if (rows <= 0 || dim <= 0) return 0;
+  return (size_t)2048 * 2 * (size_t)dim * sizeof(float) + 256;
+}
+
+extern "C" int ptgnn_amd_row_epilogue_backward_f32(const float *x, int64_t ld_x, const float *grad_y, int64_t ld_gy,
+                                                   int64_t rows, int32_t dim, int32_t flags, const float *ln_gamma,
+                                                   float ln_eps, float *grad_x, int64_t ld_gx, float *grad_gamma,
+                                                   float *grad_beta, void *workspace, size_t workspace_bytes,
+                                                   void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  if (int rc = check_common("row_epilogue_backward", x, ld_x, rows, dim, flags, ln_gamma)) return rc;
+  const bool ln = (flags & PTGNN_AMD_EPI_LAYERNORM) != 0;
+  PTGNN_REQUIRE(rows == 0 || (grad_y && ld_gy >= dim && grad_x && ld_gx >= dim), PTGNN_AMD_EINVAL,
+                "row_epilogue_backward: bad gradient matrices");
+  PTGNN_REQUIRE(!ln || (grad_gamma && grad_beta), PTGNN_AMD_EINVAL, "row_epilogue_backward: LayerNorm needs grad_gamma / grad_beta");
+  if (rows == 0) {
+    if (ln) {
+      PTGNN_HIP(hipMemsetAsync(grad_gamma, 0, sizeof(float) * dim, st));
+      PTGNN_HIP(hipMemsetAsync(grad_beta, 0, sizeof(float) * dim, st));
+    }
+    return PTGNN_AMD_OK;
+  }
+  PTGNN_REQUIRE(!ln || (workspace && workspace_bytes >= ptgnn_amd_row_epilogue_workspace_bytes(rows, dim)),
+                PTGNN_AMD_EWORKSPACE, "row_epilogue_backward: workspace %zu < %zu", workspace_bytes,
+                ptgnn_amd_row_epilogue_workspace_bytes(rows, dim));
+  RowArgs p{};
+  p.x = x; p.ld_x = ld_x; p.dy = grad_y; p.ld_dy = ld_gy; p.out = grad_x; p.ld_out = ld_gx; p.gamma = ln_gamma;
+  p.eps = ln_eps; p.rows = rows; p.M = dim; p.flags = flags;
+  p.partial = ln ? (float *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255) : nullptr;
+  const bool vec4 = dim % 4 == 0 && ld_x % 4 == 0 && ld_gy % 4 == 0 && ld_gx % 4 == 0 && aligned16(x) &&
+                    aligned16(grad_y) && aligned16(grad_x);
+  int nblocks = 0;
+  const int rc = dispatch(vec4, dim, [&](auto VEC, auto LPR, auto CH) -> int {
+    constexpr int G = kBlock / decltype(LPR)::value;
+    nblocks = backward_blocks(rows, G);
+    k_row_epilogue_backward<decltype(VEC)::value, decltype(LPR)::value, decltype(CH)::value>
+        <<<(unsigned)nblocks, kBlock, 0, st>>>(p);
+    PTGNN_LAUNCH_CHECK();
+    return (int)PTGNN_AMD_OK;
+  });
+  if (rc != PTGNN_AMD_OK || !ln) return rc;
+  k_partial_rows_sum<<<(unsigned)((2 * dim + 63) / 64), kBlock, 0, st>>>(p.partial, nblocks, 2 * dim, grad_gamma,
+                                                                        grad_beta, dim);
+  PTGNN_LAUNCH_CHECK();
+  return PTGNN_AMD_OK;
+}

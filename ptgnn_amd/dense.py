@@ -108,3 +108,33 @@ def gru_cell(cell: torch.nn.GRUCell, a: torch.Tensor, h: torch.Tensor) -> torch.
         raise _lib.PtgnnAmdError("dense.gru_cell: training needs state and message widths that are multiples of 4 "
                                  f"(got {a.shape[1]}, {h.shape[1]})")
     return _GruCell.apply(a, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+
+
+class _RowEpilogue(torch.autograd.Function):
+    """y = LayerNorm(GELU(x)) row-wise on the HIP kernels (csrc/row_epilogue.hip); saves only x."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, flags):
+        x = x.contiguous()
+        ctx.save_for_backward(x, gamma)
+        ctx.eps, ctx.flags = eps, flags
+        return ops.row_epilogue(x, flags, gamma, beta, eps)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma = ctx.saved_tensors
+        gx, gg, gb = ops.row_epilogue_backward(x, gy.contiguous(), ctx.flags, gamma, ctx.eps)
+        return gx, gg, gb, None, None
+
+
+def row_epilogue(x: torch.Tensor, gelu: bool, ln: Optional[torch.nn.LayerNorm]) -> torch.Tensor:
+    """Differentiable GELU -> LayerNorm of mlpmessagepassing.py:114-116 (either may be absent, not both).  Needs
+    fp32 CUDA rows of width <= 512 and an affine LayerNorm with bias -- the caller checks, this raises."""
+    flags = (ops.EPI_GELU if gelu else 0) | (ops.EPI_LAYERNORM if ln is not None else 0)
+    if flags == 0:
+        return x
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] > 512:
+        raise _lib.PtgnnAmdError("row_epilogue: expected a float32 CUDA matrix with rows of at most 512 columns")
+    if ln is not None:
+        return _RowEpilogue.apply(x, ln.weight, ln.bias, float(ln.eps), flags)
+    return _RowEpilogue.apply(x, None, None, 1e-5, flags)

@@ -592,10 +592,20 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
     def _update(self, agg: torch.Tensor, fused_epilogue_done: bool) -> torch.Tensor:
         x = agg
         if not fused_epilogue_done:
-            if self.__message_activation is not None:
-                x = self.__message_activation(x)
-            if self._ln is not None:
-                x = self._ln(x)
+            act = self.__message_activation
+            stock_act = act is None or (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none")
+            stock_ln = self._ln is None or (self._ln.elementwise_affine and self._ln.bias is not None
+                                            and tuple(self._ln.normalized_shape) == (x.shape[-1],))
+            if (stock_act and stock_ln and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+                    and x.shape[1] <= 512 and (act is not None or self._ln is not None)):
+                # training: the same GELU -> LayerNorm arithmetic as the fused inference epilogue, as one HIP
+                # autograd node (forward + backward kernels of csrc/row_epilogue.hip)
+                x = dense.row_epilogue(x, act is not None, self._ln)
+            else:
+                if act is not None:
+                    x = act(x)
+                if self._ln is not None:
+                    x = self._ln(x)
         if self._dense is not None:
             if _no_grad_needed(x, *self._dense.parameters()):
                 tanh = isinstance(self._dense_act, nn.Tanh)

@@ -733,6 +733,54 @@ def segment_spread(grad: torch.Tensor, arg: Optional[torch.Tensor], plan: GraphP
     return out
 
 
+def row_epilogue(x: torch.Tensor, flags: int, ln_weight: Optional[torch.Tensor] = None,
+                 ln_bias: Optional[torch.Tensor] = None, ln_eps: float = 1e-5) -> torch.Tensor:
+    """y = LayerNorm(GELU(x)) over the rows of x (`flags`: EPI_GELU | EPI_LAYERNORM) -- the training-time twin of
+    the fused aggregation epilogue (mlpmessagepassing.py:114-116)."""
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    x = _rowmajor(x)
+    n, d = x.shape
+    y = torch.empty(n, d, dtype=torch.float32, device=x.device)
+    if flags & EPI_LAYERNORM:
+        ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+    with _timed("row_epilogue", bytes=8.0 * n * d):
+        rc = lib.ptgnn_amd_row_epilogue_f32(x.data_ptr(), _ld(x), n, d, flags,
+                                            ln_weight.data_ptr() if flags & EPI_LAYERNORM else None,
+                                            ln_bias.data_ptr() if flags & EPI_LAYERNORM else None, float(ln_eps),
+                                            y.data_ptr(), d, _stream(y))
+    _lib.check(rc, "ptgnn_amd_row_epilogue_f32")
+    return y
+
+
+def row_epilogue_backward(x: torch.Tensor, grad_y: torch.Tensor, flags: int, ln_weight: Optional[torch.Tensor] = None,
+                          ln_eps: float = 1e-5):
+    """(grad_x, grad_gamma, grad_beta) of `row_epilogue`; the last two are None without LayerNorm."""
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    _require_cuda_f32("grad_y", grad_y)
+    x, grad_y = _rowmajor(x), _rowmajor(grad_y)
+    n, d = x.shape
+    gx = torch.empty(n, d, dtype=torch.float32, device=x.device)
+    ln = bool(flags & EPI_LAYERNORM)
+    gg = gb = ws = None
+    ws_bytes = 0
+    if ln:
+        ln_weight = ln_weight.contiguous()
+        gg = torch.empty(d, dtype=torch.float32, device=x.device)
+        gb = torch.empty(d, dtype=torch.float32, device=x.device)
+        ws_bytes = int(lib.ptgnn_amd_row_epilogue_workspace_bytes(n, d))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+    with _timed("row_epilogue_backward", bytes=12.0 * n * d):
+        rc = lib.ptgnn_amd_row_epilogue_backward_f32(x.data_ptr(), _ld(x), grad_y.data_ptr(), _ld(grad_y), n, d, flags,
+                                                     ln_weight.data_ptr() if ln else None, float(ln_eps),
+                                                     gx.data_ptr(), d, gg.data_ptr() if ln else None,
+                                                     gb.data_ptr() if ln else None,
+                                                     ws.data_ptr() if ln else None, ws_bytes, _stream(gx))
+    _lib.check(rc, "ptgnn_amd_row_epilogue_backward_f32")
+    return gx, gg, gb
+
+
 def gru_cell(a: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh) -> torch.Tensor:
     lib = _lib.load()
     _require_cuda_f32("a", a)

@@ -1836,3 +1836,63 @@ def test_integration_md_ctypes_stub_runs_as_printed(reduce_id, reduce):
         np.testing.assert_array_equal(got.cpu().numpy(), want.numpy())
     else:
         assert float((got.cpu() - want).abs().max()) <= TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# row epilogue (GELU -> LayerNorm) as a differentiable HIP pair: the training-time twin of the fused
+# aggregation epilogue (mlpmessagepassing.py:114-116)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim", [64, 128, 48, 50, 256, 512, 300, 4])
+@pytest.mark.parametrize("flags", ["gelu", "ln", "gelu_ln"])
+def test_row_epilogue_forward_and_backward_match_torch_cpu(dim, flags):
+    from ptgnn_amd import dense
+    g = torch.Generator().manual_seed(dim * 7 + len(flags))
+    n = 3001
+    x = torch.randn(n, dim, generator=g) * 1.5
+    gy = torch.randn(n, dim, generator=g)
+    ln_ref = torch.nn.LayerNorm(dim) if "ln" in flags else None
+    if ln_ref is not None:
+        with torch.no_grad():
+            ln_ref.weight.copy_(torch.randn(dim, generator=g))
+            ln_ref.bias.copy_(torch.randn(dim, generator=g))
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.gelu(xr) if "gelu" in flags else xr
+    if ln_ref is not None:
+        yr = ln_ref(yr)
+    yr.backward(gy)
+    ln = None
+    if ln_ref is not None:
+        ln = torch.nn.LayerNorm(dim).cuda()
+        ln.load_state_dict(ln_ref.state_dict())
+    xg = x.cuda().requires_grad_(True)
+    y = dense.row_epilogue(xg, "gelu" in flags, ln)
+    y.backward(gy.cuda())
+    assert float((y.detach().cpu() - yr.detach()).abs().max()) <= TOL
+    pairs = [(xg.grad.cpu(), xr.grad)]
+    if ln is not None:
+        pairs += [(ln.weight.grad.cpu(), ln_ref.weight.grad), (ln.bias.grad.cpu(), ln_ref.bias.grad)]
+    for a, b in pairs:       # gradients: the tolerance of the other backward tests (2e-5 x scale)
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_row_epilogue_equals_the_fused_inference_epilogue_bitwise_and_handles_edge_shapes():
+    from ptgnn_amd import dense, ops
+    g = torch.Generator().manual_seed(3)
+    n, dim = 2000, 128
+    x = torch.randn(n, dim, generator=g).cuda()
+    ln = torch.nn.LayerNorm(dim).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(dim, generator=g))
+        ln.bias.copy_(torch.randn(dim, generator=g))
+        plan = ops.plan_from_sorted_index(torch.arange(n, device="cuda"), n)      # one slot per row: sum == x
+        fused = ops.gather_reduce(x, plan, dim, "sum", epilogue=ops.EPI_GELU | ops.EPI_LAYERNORM,
+                                  ln_weight=ln.weight, ln_bias=ln.bias, ln_eps=ln.eps, type_bits=0)
+        node = dense.row_epilogue(x, True, ln)
+    assert torch.equal(fused, node)
+    # no rows: empty output, zero parameter gradients
+    x0 = torch.zeros(0, dim, device="cuda", requires_grad=True)
+    y0 = dense.row_epilogue(x0, True, ln)
+    y0.sum().backward()
+    assert y0.shape == (0, dim) and float(ln.weight.grad.abs().max()) == 0.0
+    with pytest.raises(Exception):
+        dense.row_epilogue(torch.zeros(4, 600, device="cuda"), True, None)        # wider than the kernels tile
