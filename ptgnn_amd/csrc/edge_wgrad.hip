@@ -15,7 +15,11 @@
 //
 // LDS layout is reduction-major ("[edge][m]" and "[edge][k]"): both operands are read from HBM as
 // contiguous rows (d_msg rows, gathered X rows), stored with ds_write_b128 as they are, and the MFMA
-// operand reads walk consecutive floats of one LDS row -- no transposes anywhere.
+// operand reads walk consecutive floats of one LDS row -- no transposes anywhere.  A wave's two MFMA row blocks
+// interleave (block i holds rows 2 l + i of its 64), so one ds_read_b64 feeds both blocks of an operand.
+// Partial tiles are stored in FRAGMENT order (each lane's accumulator quads as contiguous float4s: 16 coalesced
+// dwordx4 stores per wave instead of 64 strided dword stores); k_wgrad_reduce reads them in the same order and
+// un-permutes on its (much rarer) stores.
 #include "dense_common.h"
 
 namespace ptgnn_amd {
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
 #define WG_STORE(S, R, VA, VB)                                                               \
   do {                                                                                       \
     const int64_t e_ = e_begin + (int64_t)(S) * STEP + erow + (R) * 8;                       \
-    const bool valid_ = e_ < e_end; /* rows past the chunk must add nothing */              \
+    /* rows past the chunk must add nothing; only the last stage of a chunk can hold any (uniform test) */ \
+    const bool valid_ = (S) + 1 < nsteps || e_ < e_end;                                      \
     float4 b_ = VB;                                                                          \
     if constexpr (DROP) b_ = dropout_apply4(drop, gm_row0 + e_, kc, b_);                     \
     /* componentwise: `cond ? float4 : float4` becomes a pointer select through scratch */   \
@@ -156,15 +161,13 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
         colsum += cs0 + cs1;
       }
     }
-    const float *ap = As + hi * WG_LD + wm * 64 + li;
-    const float *bp = Bs + hi * WG_LD + wn * 64 + li;
+    const float *ap = As + hi * WG_LD + wm * 64 + 2 * li;
+    const float *bp = Bs + hi * WG_LD + wn * 64 + 2 * li;
 #pragma unroll
     for (int ks = 0; ks < STEP / 2; ++ks) {
-      float a[2], b[2];
-      a[0] = ap[ks * 2 * WG_LD];
-      a[1] = ap[ks * 2 * WG_LD + 32];
-      b[0] = bp[ks * 2 * WG_LD];
-      b[1] = bp[ks * 2 * WG_LD + 32];
+      const float2 a2 = *reinterpret_cast<const float2 *>(ap + ks * 2 * WG_LD);
+      const float2 b2 = *reinterpret_cast<const float2 *>(bp + ks * 2 * WG_LD);
+      const float a[2] = {a2.x, a2.y}, b[2] = {b2.x, b2.y};
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -183,17 +186,27 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
     if (kt == 0 && threadIdx.x < 128)
       colsum_partial[((int64_t)(chunk_base + chunk) * mtiles + mt) * 128 + threadIdx.x] = colsum;
   }
-  // partial tile: [128 m][128 k] floats; C fragment (i, j): row = (r & 3) + 8 (r >> 2) + 4 hi, col = li
-  float *const out = partial + ((int64_t)(chunk_base + chunk) * tiles_per_chunk + rem) * kTile;
+  // partial tile in fragment order: float4 f = ((wave * 4 + i * 2 + j) * 4 + q) * 64 + lane holds accumulator
+  // registers 4 q .. 4 q + 3 of block (i, j), i.e. tile rows wm * 64 + 2 * (8 q + 4 hi + {0, 1, 2, 3}) + i at
+  // tile column wn * 64 + 2 * li + j (see frag_coords)
+  float4 *const out = reinterpret_cast<float4 *>(partial + ((int64_t)(chunk_base + chunk) * tiles_per_chunk + rem) * kTile);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        out[m * 128 + wn * 64 + j * 32 + li] = acc[i][j][r];
-      }
+      for (int q = 0; q < 4; ++q)
+        out[((wave * 4 + i * 2 + j) * 4 + q) * 64 + lane] =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+}
+
+// float4 f of a fragment-ordered partial tile -> tile row of its first component (the four components are rows
+// m0, m0 + 2, m0 + 4, m0 + 6) and its tile column
+__device__ __forceinline__ void frag_coords(int f, int &m0, int &k) {
+  const int lane = f & 63, q = (f >> 6) & 3, blk = (f >> 8) & 3, wave = f >> 10;
+  const int i = blk >> 1, j = blk & 1, wm = wave >> 1, wn = wave & 1;
+  m0 = wm * 64 + 2 * (8 * q + 4 * (lane >> 5)) + i;
+  k = wn * 64 + 2 * (lane & 31) + j;
 }
 
 // grad_w[t][m][k .. k+3] = sum of the type's partial tiles.  Eight lanes share one output float4: lane
@@ -203,17 +216,20 @@ constexpr int kSplit = 8;
 __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradTable tab, const float *__restrict__ partial,
                                                       int chunk_base, int mtiles, int ktiles, int M,
                                                       int K, float *__restrict__ grad_w, int type_base) {
-  const int kq = K / 4;
-  const int64_t per_type = (int64_t)M * kq;
+  const int tiles_per_chunk = mtiles * ktiles;
+  const int64_t per_type = (int64_t)tiles_per_chunk * (kTile / 4);     // float4s of one type's tiles
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t i = gid / kSplit;
   const int sub = (int)(gid % kSplit);
   if (i >= per_type * tab.num_types) return;      // whole 8-lane groups leave together
   const int t = (int)(i / per_type);
   const int rem = (int)(i % per_type);
-  const int m = rem / kq, k = (rem % kq) * 4;
-  const int tiles_per_chunk = mtiles * ktiles;
-  const int64_t off = (int64_t)((m >> 7) * ktiles + (k >> 7)) * kTile + (m & 127) * 128 + (k & 127);
+  const int tile = rem / (kTile / 4), f = rem % (kTile / 4);
+  int m0, k;
+  frag_coords(f, m0, k);
+  m0 += (tile / ktiles) * 128;
+  k += (tile % ktiles) * 128;
+  const int64_t off = (int64_t)tile * kTile + (int64_t)f * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int c = tab.chunk_off[t] + sub; c < tab.chunk_off[t + 1]; c += kSplit) {
     const float4 p = *reinterpret_cast<const float4 *>(
@@ -225,7 +241,13 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradTable tab, const floa
     s.x += __shfl_xor(s.x, d); s.y += __shfl_xor(s.y, d);
     s.z += __shfl_xor(s.z, d); s.w += __shfl_xor(s.w, d);
   }
-  if (sub == 0) *reinterpret_cast<float4 *>(grad_w + ((int64_t)(type_base + t) * M + m) * K + k) = s;
+  if (sub == 0 && k < K) {
+    float *g = grad_w + ((int64_t)(type_base + t) * M + m0) * K + k;
+    if (m0 < M) g[0] = s.x;
+    if (m0 + 2 < M) g[2 * (int64_t)K] = s.y;
+    if (m0 + 4 < M) g[4 * (int64_t)K] = s.z;
+    if (m0 + 6 < M) g[6 * (int64_t)K] = s.w;
+  }
 }
 
 // grad_b[m] = sum over chunks of the column-sum partials (dense form: one "type")
@@ -343,7 +365,7 @@ static int weight_grad_launch(const float *x, int64_t ld_x, int64_t num_rows, in
     } else if (grad_b) {
       PTGNN_HIP(hipMemsetAsync(grad_b, 0, sizeof(float) * msg_dim, st));
     }
-    const int64_t outs = (int64_t)tab.num_types * msg_dim * (K / 4) * kSplit;
+    const int64_t outs = (int64_t)tab.num_types * mtiles * ktiles * (kTile / 4) * kSplit;
     k_wgrad_reduce<<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(
         tab, (const float *)workspace, (int)chunk_base, mtiles, ktiles, msg_dim, K, grad_w, t0);
     PTGNN_LAUNCH_CHECK();
