@@ -12,7 +12,8 @@ Primary workload: the batch BASELINE.json quotes its metric on -- the Graph2Clas
 configs[2] (48 graphs, ~116k nodes, 8 raw -> 17 edge types, Typilus GGNN stack: 8 GGNN layers,
 hidden 128, max aggregation, fp32, forward).  `value` = E / t_layer (edges per second per message-passing
 layer, E counted after reverse + self augmentation).  At N=1 the same run also reports configs[1]
-(synthetic 200k-node / 1.1M-edge graph, one MLP-MP layer) under "config2", the per-GPU shard of configs[4]
+(synthetic 200k-node / 1.1M-edge graph, one MLP-MP layer) under "config2", configs[3] (VarMisuse batch, T = 21,
+8 MLP-MP layers hidden 64) on one GPU under "config4", the per-GPU shard of configs[4]
 (power-law, 1.25M nodes / 12.5M edges, H=256) under "config5_shard", the same primary workload in the opt-in
 "f32 via 3xbf16 split" GEMM mode under "split_bf16", the training step of the Graph2Class stack under
 "graph2class_train", and the CPU restatement under "cpu_baseline".  The GPU output of the primary workload and
@@ -20,8 +21,8 @@ of config 2 is compared with the CPU oracle's at FULL size ("parity"); a miss fa
 
 N>1: the path partitions over whole graphs (a minibatch is a disjoint union; the reference's own
 multi-GPU mode hands whole graphs to ranks), so every rank runs the single-GPU step on ITS OWN
-Graph2Class batch: no data-path collective, weak scaling.  `--workload cfg2 --sharded-variants` times the
-dst-range-sharded code path (ptgnn_amd.sharded: halo all-to-all over RCCL) as secondary entries.
+Graph2Class batch: no data-path collective, weak scaling.  After it, by default, the dst-range-sharded cut-edge
+workloads run (ptgnn_amd.sharded: halo all-to-all over RCCL; "cut_edges_variant": the cfg5 shard and the cfg4 stack).
 
 Prints ONE JSON line on rank 0.
 """
@@ -591,19 +592,71 @@ def sharded_cfg5(dev, rank, world, k=5):
             "all_to_all_ms": round(t_x * 1e3, 3), "no_cut": bool(shard.no_cut)}
 
 
-def sharded_cfg4(dev, rank, world, k=5):
-    """configs[3]: the VarMisuse batch (40 graphs x ~2000 nodes, T0 = 10 -> T = 21) through the 8-layer MLP-MP
-    stack of varmisuse/train.py:42-74 (hidden 64, max), destination ranges balanced by in-edge mass over `world`
-    GPUs (the cuts go through graphs), every layer through `forward_sharded` (edge form over the [own | halo]
-    table) with one RCCL all-to-all of halo rows per layer."""
-    from ptgnn_amd import layers as L, ops, sharded, workloads
-    H, T = 64, 21
+def cfg4_batch():
+    """configs[3]: the VarMisuse batch (40 graphs x ~2000 nodes, T0 = 10) with reverse and self edges: T = 21."""
+    from ptgnn_amd import workloads
     mb = workloads.batched_graphs(40, 2000, 10, 2.4, seed=21)
     n, n2g = mb["num_nodes"], mb["node_to_graph_idx"]
     adj = list(mb["adjacency_lists"])
     adj = adj + [(d_, s_) for s_, d_ in adj]
     ar = torch.arange(n, dtype=torch.int64)
     adj.append((ar, ar))
+    return mb, adj, n, n2g
+
+
+def cfg4_modules(dev, H=64, T=21):
+    """The 8-layer MLP-MP stack of varmisuse/train.py:42-74 (hidden 64, max, dropout 0.1, concat / mean residuals)."""
+    from ptgnn_amd import layers as L
+    torch.manual_seed(4)
+    mk = lambda: L.MlpMessagePassingLayer(H, H, H, T, "max", dropout_rate=0.1)          # noqa: E731
+    mk2 = lambda: L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, "max", dropout_rate=0.1)  # noqa: E731
+    r1, r2, r3 = L.ConcatResidualLayer(H), L.MeanResidualLayer(H), L.ConcatResidualLayer(H)
+    mods = [r1.pass_through_dummy_layer(), mk(), mk(), mk(), r1, mk2(), r2.pass_through_dummy_layer(), mk(), mk(), r2,
+            r3.pass_through_dummy_layer(), mk(), r3, mk2()]
+    return [m.to(dev).eval() for m in mods]
+
+
+def config4(dev, k=20):
+    """configs[3] on ONE GPU, unsharded: the stack above over the whole batch through the layers' ordinary forward
+    (the 4-GPU dst-range-sharded form is `cut_edges_variant.cfg4_stack` at N > 1)."""
+    from ptgnn_amd import layers as L, ops, workloads
+    mb, adj, n, n2g = cfg4_batch()
+    adj = [(s_.to(dev), d_.to(dev)) for s_, d_ in adj]
+    n2g = n2g.to(dev)
+    mods = cfg4_modules(dev)
+    x0 = workloads.node_states(n, 64, seed=6).to(dev)
+    feats = [None] * len(adj)
+
+    def step():
+        ops.clear_plan_cache()
+        x = x0
+        with torch.no_grad(), L.forward_scope():
+            for m in mods:
+                x = m(x, adj, n2g, {}, {}, feats)
+        return x
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    e = sum(int(a[0].shape[0]) for a in adj)
+    return {"workload": f"cfg4: VarMisuse batch N={n}, T=21, E={e} (incl. reverse+self), 8 MLP-MP layers hidden 64 "
+                        "(+ concat / mean residuals), max, one GPU, unsharded",
+            "ms_per_forward": round(dt * 1e3, 4), "edges_per_sec_per_layer": round(e / (dt / 8), 1),
+            "nodes_per_sec_per_layer": round(n / (dt / 8), 1), "edges_per_sec_readme_convention": round(e / dt, 1)}
+
+
+def sharded_cfg4(dev, rank, world, k=5):
+    """configs[3]: the VarMisuse batch (40 graphs x ~2000 nodes, T0 = 10 -> T = 21) through the 8-layer MLP-MP
+    stack of varmisuse/train.py:42-74 (hidden 64, max), destination ranges balanced by in-edge mass over `world`
+    GPUs (the cuts go through graphs), every layer through `forward_sharded` (edge form over the [own | halo]
+    table) with one RCCL all-to-all of halo rows per layer."""
+    from ptgnn_amd import ops, sharded, workloads
+    H = 64
+    mb, adj, n, n2g = cfg4_batch()
     indeg = torch.zeros(n, dtype=torch.int64)
     for _, d_ in adj:
         indeg += torch.bincount(d_, minlength=n)
@@ -611,13 +664,7 @@ def sharded_cfg4(dev, rank, world, k=5):
     lo, hi = ranges[rank]
     mine = [(s_[(d_ >= lo) & (d_ < hi)].to(dev), d_[(d_ >= lo) & (d_ < hi)].to(dev)) for s_, d_ in adj]
     e_mine = sum(int(a[0].shape[0]) for a in mine)
-    torch.manual_seed(4)
-    mk = lambda: L.MlpMessagePassingLayer(H, H, H, T, "max", dropout_rate=0.1)          # noqa: E731
-    mk2 = lambda: L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, "max", dropout_rate=0.1)  # noqa: E731
-    r1, r2, r3 = L.ConcatResidualLayer(H), L.MeanResidualLayer(H), L.ConcatResidualLayer(H)
-    mods = [r1.pass_through_dummy_layer(), mk(), mk(), mk(), r1, mk2(), r2.pass_through_dummy_layer(), mk(), mk(), r2,
-            r3.pass_through_dummy_layer(), mk(), r3, mk2()]
-    mods = [m.to(dev).eval() for m in mods]
+    mods = cfg4_modules(dev)
     x = workloads.node_states(n, H, seed=6)[lo:hi].contiguous().to(dev)
     n2g_local = n2g[lo:hi].contiguous().to(dev)
     holder = {}
@@ -776,6 +823,11 @@ def main():
                     result["config5_shard"] = config5_shard(dev)
                 except Exception as exc:  # noqa: BLE001  (secondary numbers must never cost the primary line)
                     result["config5_shard"] = {"error": f"{type(exc).__name__}: {exc}"}
+                try:
+                    _log("secondary: config 4 stack (one GPU, unsharded)")
+                    result["config4"] = config4(dev)
+                except Exception as exc:  # noqa: BLE001
+                    result["config4"] = {"error": f"{type(exc).__name__}: {exc}"}
                 torch.cuda.empty_cache()
             else:
                 st3 = make_cfg3(dev)
