@@ -416,9 +416,12 @@ _PLAN_CACHE_SIZE = 4
 HUB_THRESHOLD = 4096
 
 # The plan (sort) is latency-bound integer work and the first dense block of a layer (pre-transform /
-# per-edge GEMM) does not read it, so the build runs on a side HIP stream under that GEMM; the
-# aggregation kernel waits on the plan's event.
-OVERLAP_PLAN_BUILD = False   # measured r01: no gain -- the GEMM already fills every CU, both just slow down
+# per-edge GEMM) does not read it, so the build CAN run on a side HIP stream under that GEMM, the
+# aggregation kernel waiting on the plan's event (PTGNN_AMD_OVERLAP_PLAN=1).
+# Off: measured again in round 2 with the streaming GEMMs (one 8-wave workgroup per CU, so the plan kernels do fit
+# beside them): cfg2 0.411 -> 0.456 ms per step, cfg3 4.34 -> 4.39 ms -- the co-resident plan workgroups take LDS
+# bandwidth and issue slots from the MFMA kernel for longer than the plan build lasts on an idle chip.
+OVERLAP_PLAN_BUILD = os.environ.get("PTGNN_AMD_OVERLAP_PLAN", "0") not in ("", "0")
 _SIDE_STREAMS = {}
 
 
