@@ -370,6 +370,8 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
                                      bad["dev"].data_ptr() if bad is not None else None,
                                      control.data_ptr(),
                                      ws.data_ptr(), ws_bytes, _stream(rowptr))
+    if rc != 0:
+        _PLAN_CONTROL.clear()       # a build that stopped half-way may have left its control block non-zero
     _lib.check(rc, "ptgnn_amd_csr_build")
     if bad is not None:
         if capturing:
