@@ -213,27 +213,34 @@ __global__ __launch_bounds__(kBlock) void k_row_epilogue_backward(RowArgs p) {
   }
 }
 
-// out[j] = sum over partial rows (fixed order: 4 interleaved slices, then the slices); j < 2 M
-__global__ __launch_bounds__(kBlock) void k_partial_rows_sum(const float *__restrict__ partial, int nrows, int width,
-                                                             float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                             int M) {
-  __shared__ float s[4][64];
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+// out[j] = sum over partial rows, j < 2 M: 64 columns x 16 row slices per workgroup; a slice adds its rows in
+// ascending order (8 independent loads per step), the 16 slice sums meet in LDS in a fixed order (deterministic)
+constexpr int kSumSlices = 16;
+__global__ __launch_bounds__(64 * kSumSlices) void k_partial_rows_sum(const float *__restrict__ partial, int nrows,
+                                                                      int width, float *__restrict__ dgamma,
+                                                                      float *__restrict__ dbeta, int M) {
+  __shared__ float s[kSumSlices][64];
+  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
   float acc = 0.f;
-  if (j < width)
-    for (int r = slice; r < nrows; r += 4) acc += partial[(int64_t)r * width + j];
-  s[slice][threadIdx.x & 63] = acc;
+  if (j < width) {
+#pragma unroll 8
+    for (int r = slice; r < nrows; r += kSumSlices) acc += partial[(int64_t)r * width + j];
+  }
+  s[slice][c] = acc;
   __syncthreads();
   if (slice == 0 && j < width) {
-    const float t = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < kSumSlices; ++q) t += s[q][c];
     if (j < M) dgamma[j] = t; else dbeta[j - M] = t;
   }
 }
 
 int backward_blocks(int64_t rows, int groups_per_block) {
-  // enough workgroups to fill the chip several times over, few enough partial rows to sum cheaply
+  // two workgroups per CU keep the loads of this HBM-bound pass in flight; every workgroup costs one partial row
   int64_t b = (rows + groups_per_block - 1) / groups_per_block;
-  if (b > 2048) b = 2048;
+  if (b > 512) b = 512;
   return (int)(b < 1 ? 1 : b);
 }
 
@@ -287,7 +294,7 @@ extern "C" int ptgnn_amd_row_epilogue_f32(const float *x, int64_t ld_x, int64_t 
 
 extern "C" size_t ptgnn_amd_row_epilogue_workspace_bytes(int64_t rows, int32_t dim) {
   if (rows <= 0 || dim <= 0) return 0;
-  return (size_t)2048 * 2 * (size_t)dim * sizeof(float) + 256;
+  return (size_t)512 * 2 * (size_t)dim * sizeof(float) + 256;
 }
 
 extern "C" int ptgnn_amd_row_epilogue_backward_f32(const float *x, int64_t ld_x, const float *grad_y, int64_t ld_gy,
@@ -327,7 +334,7 @@ extern "C" int ptgnn_amd_row_epilogue_backward_f32(const float *x, int64_t ld_x,
     return (int)PTGNN_AMD_OK;
   });
   if (rc != PTGNN_AMD_OK || !ln) return rc;
-  k_partial_rows_sum<<<(unsigned)((2 * dim + 63) / 64), kBlock, 0, st>>>(p.partial, nblocks, 2 * dim, grad_gamma,
+  k_partial_rows_sum<<<(unsigned)((2 * dim + 63) / 64), 64 * kSumSlices, 0, st>>>(p.partial, nblocks, 2 * dim, grad_gamma,
                                                                         grad_beta, dim);
   PTGNN_LAUNCH_CHECK();
   return PTGNN_AMD_OK;
