@@ -7,8 +7,9 @@
 //     wave-instruction (16 B/lane, the coalescing sweet spot), 64/LPR rows per wave;
 //   * the in-edges of a row are contiguous in `col` (CSR) and folded IN ORDER, so fp32 sums are
 //     deterministic and follow the reference's message order; no atomics;
-//   * the edge loop is unrolled x4 with all 4 row loads issued before the first use, to keep
-//     >= 4 KiB per wave in flight against ~1-2 us gather latency;
+//   * the edge loop runs in groups of 8 slots (4 with a destination term) with all row loads of a group
+//     issued before the first use and the next group's `col` entries fetched behind them: 8 KiB per wave
+//     in flight, one round trip per group;
 //   * consecutive row tiles run on the same XCD (xcd_swizzle) so one graph of a disjoint-union
 //     batch keeps its node states in a single 4 MiB L2;
 //   * HUB rows (in-degree > hub_threshold, power-law graphs): one lane group folding 10^5..10^6
@@ -241,6 +242,63 @@ struct RowOp {
     }
   }
 
+  // The same fold as reduce() in groups of U slots, every group ONE round trip: the group's U `col` entries
+  // were fetched while the previous group's rows were in flight (the first group's together, up front), and a
+  // short row or a tail is a clamped group (duplicates of the row's last slot: idempotent for max / min, zeroed
+  // for the sums) instead of a second, smaller round trip.  Slots fold in CSR order: bit-identical to reduce()
+  // (checked on the GPU over widths / reduces / args / epilogues / hub and tail cases,
+  // scripts/experiments/gr_walk_ab.py).  U = 8 keeps the kernel at 63-70 VGPRs (7-8 waves per SIMD) with twice
+  // the bytes in flight per wave: cfg3 97 -> 89 us, cfg5 shard 4.20 -> 3.39 ms (a 4000-edge row was ~1000 serial
+  // col -> row round trips; now ~500 single ones).
+  template <int U>
+  __device__ __forceinline__ void reduce_pf(int64_t row, int beg, int end, int stride) {
+    if (beg >= end) return;
+    const float *dst_base = HAS_DST ? a.ydst + row * a.ld_yd : nullptr;
+    const int last = beg + ((end - 1 - beg) / stride) * stride;
+    int32_t pk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = beg + u * stride;
+      pk[u] = a.col[idx < last ? idx : last];
+    }
+    for (int i = beg; i < end; i += U * stride) {
+      float m[U][CH][VEC];
+      float d[U][CH][VEC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t s = pk[u] >> a.type_bits;
+        const int t = pk[u] & tmask;
+        const int idx = i + u * stride;
+        load_row(a.ysrc + s * a.ld_y + (int64_t)t * M, m[u]);
+        apply_mask(m[u], s, idx < last ? idx : last);
+        if (HAS_DST) load_row(dst_base + (int64_t)t * M, d[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {   // the next group's col entries ride behind this group's rows
+        const int idx = i + (U + u) * stride;
+        pk[u] = a.col[idx < last ? idx : last];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = i + u * stride;
+        const bool valid = idx < end;
+        if (HAS_DST) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) m[u][c][v] += d[u][c][v];
+        }
+        if (REDUCE != PTGNN_AMD_MAX && REDUCE != PTGNN_AMD_MIN) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) m[u][c][v] = valid ? m[u][c][v] : 0.f;
+        }
+        fold(m[u], valid ? idx : last);
+      }
+    }
+  }
+
   __device__ __forceinline__ void store(float *orow, int32_t *arow) const {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -332,7 +390,11 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
   // column block (only > 0 when msg_dim exceeds LPR*VEC*CH; epilogues are then disabled by host)
   RowOp<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED> op(a, threadIdx.x % LPR,
                                                          blockIdx.y * (LPR * VEC * CH));
-  op.reduce(row, beg, end, 1);
+  // plain rows (no destination term: its second row set per slot would cost the occupancy the wider group buys)
+  // fold in prefetched groups of 8 (4 when a lane owns two column chunks)
+  constexpr int UP = (VEC == 4 && !MASKED && !HAS_DST) ? (CH == 1 ? 8 : 4) : 0;
+  if constexpr (UP == 0) op.reduce(row, beg, end, 1);
+  else op.template reduce_pf<UP>(row, beg, end, 1);
   op.finish_and_store(row, end - beg);
 }
 

@@ -415,7 +415,7 @@ _PLAN_CACHE: List[GraphPlan] = []
 _PLAN_CACHE_SIZE = 4
 
 # Rows longer than this are reduced chunk-parallel by the hub kernels (see gather_reduce.hip).
-HUB_THRESHOLD = 4096
+HUB_THRESHOLD = 2048
 
 # The plan (sort) is latency-bound integer work and the first dense block of a layer (pre-transform /
 # per-edge GEMM) does not read it, so the build CAN run on a side HIP stream under that GEMM, the
