@@ -250,11 +250,15 @@ struct RowOp {
   // scripts/experiments/gr_walk_ab.py).  U = 8 keeps the kernel at 63-70 VGPRs (7-8 waves per SIMD) with twice
   // the bytes in flight per wave: cfg3 97 -> 89 us, cfg5 shard 4.20 -> 3.39 ms (a 4000-edge row was ~1000 serial
   // col -> row round trips; now ~500 single ones).
-  template <int U>
+  // DST_ONCE (one edge type: the destination term is the same row for every slot): it is loaded once per row
+  // instead of once per slot; every slot still folds (message + destination term), same bits.
+  template <int U, bool DST_ONCE = false>
   __device__ __forceinline__ void reduce_pf(int64_t row, int beg, int end, int stride) {
     if (beg >= end) return;
     const float *dst_base = HAS_DST ? a.ydst + row * a.ld_yd : nullptr;
     const int last = beg + ((end - 1 - beg) / stride) * stride;
+    float d1[CH][VEC];
+    if constexpr (HAS_DST && DST_ONCE) load_row(dst_base, d1);
     int32_t pk[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -263,7 +267,7 @@ struct RowOp {
     }
     for (int i = beg; i < end; i += U * stride) {
       float m[U][CH][VEC];
-      float d[U][CH][VEC];
+      float d[(HAS_DST && !DST_ONCE) ? U : 1][CH][VEC];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t s = pk[u] >> a.type_bits;
@@ -271,7 +275,7 @@ struct RowOp {
         const int idx = i + u * stride;
         load_row(a.ysrc + s * a.ld_y + (int64_t)t * M, m[u]);
         apply_mask(m[u], s, idx < last ? idx : last);
-        if (HAS_DST) load_row(dst_base + (int64_t)t * M, d[u]);
+        if constexpr (HAS_DST && !DST_ONCE) load_row(dst_base + (int64_t)t * M, d[u]);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {   // the next group's col entries ride behind this group's rows
@@ -282,11 +286,11 @@ struct RowOp {
       for (int u = 0; u < U; ++u) {
         const int idx = i + u * stride;
         const bool valid = idx < end;
-        if (HAS_DST) {
+        if constexpr (HAS_DST) {
 #pragma unroll
           for (int c = 0; c < CH; ++c)
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) m[u][c][v] += d[u][c][v];
+            for (int v = 0; v < VEC; ++v) m[u][c][v] += DST_ONCE ? d1[c][v] : d[DST_ONCE ? 0 : u][c][v];
         }
         if (REDUCE != PTGNN_AMD_MAX && REDUCE != PTGNN_AMD_MIN) {
 #pragma unroll
@@ -378,7 +382,7 @@ struct RowOp {
 // ------------------------------------------------------------------------------------------------
 // main kernel: one row per lane group
 // ------------------------------------------------------------------------------------------------
-template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED>
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED, bool DST1 = false>
 __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
   constexpr int ROWS_PER_BLOCK = 256 / LPR;
   const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -390,11 +394,13 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
   // column block (only > 0 when msg_dim exceeds LPR*VEC*CH; epilogues are then disabled by host)
   RowOp<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED> op(a, threadIdx.x % LPR,
                                                          blockIdx.y * (LPR * VEC * CH));
-  // plain rows (no destination term: its second row set per slot would cost the occupancy the wider group buys)
-  // fold in prefetched groups of 8 (4 when a lane owns two column chunks)
-  constexpr int UP = (VEC == 4 && !MASKED && !HAS_DST) ? (CH == 1 ? 8 : 4) : 0;
+  // plain rows fold in prefetched groups of 8 (4 when a lane owns two column chunks); so do rows with a
+  // destination term when there is ONE edge type (DST1: the term is loaded once per row).  A per-slot destination
+  // term (several edge types) stays on groups of 4: its second row set per slot would cost the occupancy the
+  // wider group buys.
+  constexpr int UP = (VEC == 4 && !MASKED && (!HAS_DST || DST1)) ? (CH == 1 ? 8 : 4) : 0;
   if constexpr (UP == 0) op.reduce(row, beg, end, 1);
-  else op.template reduce_pf<UP>(row, beg, end, 1);
+  else op.template reduce_pf<UP, HAS_DST && DST1>(row, beg, end, 1);
   op.finish_and_store(row, end - beg);
 }
 
@@ -482,7 +488,14 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
   Args a = a0;
   a.num_tiles = (a.num_nodes + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   dim3 grid((unsigned)xcd_padded_blocks(a.num_tiles), (unsigned)col_blocks);
-  k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED><<<grid, 256, 0, stream>>>(a);
+  bool one_type = false;
+  if constexpr (VEC == 4 && HAS_DST && !MASKED) one_type = a.type_bits == 0;
+  if constexpr (VEC == 4 && HAS_DST && !MASKED) {
+    if (one_type) k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED, true><<<grid, 256, 0, stream>>>(a);
+    else k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED><<<grid, 256, 0, stream>>>(a);
+  } else {
+    k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED><<<grid, 256, 0, stream>>>(a);
+  }
   PTGNN_LAUNCH_CHECK();
   if (a.hub_threshold > 0) {
     // the list length lives on the device: a fixed grid strides over it (zero entries => instant exit)
