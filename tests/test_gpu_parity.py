@@ -125,7 +125,7 @@ def test_scatter_matches_oracle(reduce, dim):
     src = torch.randn(E, dim, generator=g)
     idx = torch.randint(0, N - 1, (E,), generator=g)
     idx[idx == 13] = 14                       # empty segments: 13 and N-1
-    idx[:900] = 5                             # one long segment (crosses the x4 unroll many times)
+    idx[:900] = 5                             # one long segment (many full groups of the fold loop + a tail)
     want = scatter_ref.scatter(src, idx, dim=0, dim_size=N, reduce=reduce)
     got = scatter(src.cuda(), idx.cuda(), dim=0, dim_size=N, reduce=reduce).cpu()
     assert got.dtype == torch.float32 and got.shape == want.shape
@@ -135,6 +135,45 @@ def test_scatter_matches_oracle(reduce, dim):
         # same fold order as the reference's CPU scatter_add_ / order-independent max,min
         np.testing.assert_array_equal(got.numpy(), want.numpy())
     assert float(got[13].abs().sum()) == 0.0 and float(got[N - 1].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("num_types", [1, 3])
+@pytest.mark.parametrize("dim", [32, 64, 128, 256, 512])
+def test_fused_table_form_equals_segment_reduce_of_materialised_messages(num_types, dim):
+    """Bit for bit: gather + destination term + reduce in one kernel (groups of 8 slots; groups of 4 with a per-slot
+    destination term; the term loaded once per row when there is one edge type) == the segment reduce of the
+    materialised messages y[src, t] + yd[dst, t] (same adds, same CSR fold order).  Degrees 0 .. ~300 plus one hub
+    row, so every group / tail / clamp case of the fold loop occurs."""
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(num_types * 1000 + dim)
+    N, T, M = 3001, num_types, dim
+    adj = []
+    for t in range(T):
+        e = 24000 // T
+        src = torch.randint(0, N, (e,), generator=g)
+        dst = torch.randint(0, N, (e,), generator=g)
+        dst[: e // 8] = torch.randint(0, 40, (e // 8,), generator=g)      # 40 rows of ~75 .. 300 in-edges
+        dst[e // 8: e // 8 + (ops.HUB_THRESHOLD + 200) // T + 1] = 77      # one hub row
+        dst[dst == 1500] = 1501                                            # an empty row
+        adj.append((src.cuda(), dst.cuda()))
+    plan = ops.build_plan(adj, N)
+    deg = plan.rowptr[1:] - plan.rowptr[:-1]
+    assert int(deg.max()) > ops.HUB_THRESHOLD and int(deg[1500]) == 0
+    plain_rows = (deg <= ops.HUB_THRESHOLD)          # hub rows fold chunk-wise: sums are not bit-comparable
+    y = torch.randn(N, T * M, generator=g).cuda()
+    yd = torch.randn(N, T * M, generator=g).cuda()
+    msgs = torch.cat([y[s][:, t * M:(t + 1) * M] + yd[d][:, t * M:(t + 1) * M] for t, (s, d) in enumerate(adj)])
+    plain = torch.cat([y[s][:, t * M:(t + 1) * M] for t, (s, d) in enumerate(adj)])
+    for reduce in ("sum", "mean", "max", "min"):
+        for with_dst in (True, False):
+            want = ops.segment_reduce(msgs if with_dst else plain, plan, reduce)
+            got = ops.gather_reduce(y, plan, M, reduce, ydst=yd if with_dst else None)
+            rows = slice(None) if reduce in ("max", "min") else plain_rows
+            assert torch.equal(want[rows], got[rows]), (reduce, with_dst)
+            if reduce in ("max", "min"):
+                w_arg = ops.segment_reduce(msgs if with_dst else plain, plan, reduce, return_arg=True)
+                g_arg = ops.gather_reduce(y, plan, M, reduce, ydst=yd if with_dst else None, return_arg=True)
+                assert torch.equal(w_arg[0], g_arg[0]) and torch.equal(w_arg[1], g_arg[1]), (reduce, with_dst, "arg")
 
 
 def test_scatter_known_answers_and_1d():
