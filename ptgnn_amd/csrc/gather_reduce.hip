@@ -430,7 +430,10 @@ __global__ __launch_bounds__(256) void k_hub_chunks(Args a) {
     // partial slot of this (chunk, row): 0 if the hub owns the chunk's first slot, else 1
     const int which = rbeg <= cbeg ? 0 : 1;
     Op op(a, g, cbase);
-    op.reduce(row, sbeg + grp, send, G);
+    // the chunk's slots are interleaved over the lane groups (stride G); same prefetched groups of 8 as the main kernel
+    constexpr int UP = (VEC == 4 && !MASKED && !HAS_DST && CH == 1) ? 8 : 0;
+    if constexpr (UP == 0) op.reduce(row, sbeg + grp, send, G);
+    else op.template reduce_pf<UP>(row, sbeg + grp, send, G);
     __syncthreads();  // the previous entry's readers are done with the staging arrays
 #pragma unroll
     for (int c = 0; c < CH; ++c)
@@ -467,13 +470,22 @@ __global__ __launch_bounds__(256) void k_hub_chunks(Args a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1 lines before reading partials
     if (g == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-clean
     Op fin(a, g, cbase);
-    for (int64_t c = c_first; c <= c_last; ++c) {
-      const int w2 = (c > c_first || rbeg == (int)(c_first * kHubChunk)) ? 0 : 1;
-      float m[CH][VEC];
-      int ma[CH][VEC];
-      fin.load_partial(a.hub_part + (2 * c + w2) * (int64_t)a.msg_dim,
-                       HAS_ARG ? a.hub_arg + (2 * c + w2) * (int64_t)a.msg_dim : nullptr, m, ma);
-      fin.fold_partial(m, ma);
+    // chunk partials fold in chunk order, fetched FB at a time (a 150 k-edge hub has ~150 of them: loaded one by
+    // one, this fold was most of the hub launch on the cfg5 shard)
+    constexpr int FB = (HAS_ARG || CH > 1) ? 4 : 8;
+    for (int64_t c0 = c_first; c0 <= c_last; c0 += FB) {
+      float m[FB][CH][VEC];
+      int ma[FB][CH][VEC];
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int64_t c = c0 + u <= c_last ? c0 + u : c_last;
+        const int w2 = (c > c_first || rbeg == (int)(c_first * kHubChunk)) ? 0 : 1;
+        fin.load_partial(a.hub_part + (2 * c + w2) * (int64_t)a.msg_dim,
+                         HAS_ARG ? a.hub_arg + (2 * c + w2) * (int64_t)a.msg_dim : nullptr, m[u], ma[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < FB; ++u)
+        if (c0 + u <= c_last) fin.fold_partial(m[u], ma[u]);
     }
     fin.finish_and_store(row, rend - rbeg);
   }
