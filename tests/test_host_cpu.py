@@ -236,3 +236,30 @@ def test_training_path_selection_rules():
     assert not L._prefer_edge_path(1_100_000, 200_000, 1, 128, 128)     # config 2: per-node table
     x, w = torch.zeros(4, 8), torch.zeros(12, 8)
     assert not dense._kernel_dims_ok(x, w)                              # CPU tensors never take the HIP nodes
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """The newest committed N = 1 bench line (profiles/r*_bench_n1.json) carries every field the driver and the
+    judge read, with self-consistent numbers: value = E / (ms_per_step / layers), roofline.frac = achieved / peak
+    <= 1, a cpu_baseline of kind "port", parity inside its tolerance."""
+    import glob
+    import json
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")))
+    if not lines:
+        pytest.skip("no committed bench line")
+    d = json.load(open(lines[-1]))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    cfg = d["config"]
+    per_layer_s = d["ms_per_step"] * 1e-3 / cfg["mp_layers_per_step"]
+    assert abs(d["value"] - cfg["edges_per_gpu"] / per_layer_s) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] <= 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["parity"]["max_abs"] <= d["parity"]["tol"] == 1e-5
