@@ -500,14 +500,12 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
   Args a = a0;
   a.num_tiles = (a.num_nodes + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   dim3 grid((unsigned)xcd_padded_blocks(a.num_tiles), (unsigned)col_blocks);
-  bool one_type = false;
-  if constexpr (VEC == 4 && HAS_DST && !MASKED) one_type = a.type_bits == 0;
-  if constexpr (VEC == 4 && HAS_DST && !MASKED) {
-    if (one_type) k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED, true><<<grid, 256, 0, stream>>>(a);
-    else k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED><<<grid, 256, 0, stream>>>(a);
-  } else {
+  // one edge type (type_bits == 0): the destination term of a row is one row -> the DST1 variant loads it once
+  constexpr bool kDst1Variant = VEC == 4 && HAS_DST && !MASKED;
+  if (kDst1Variant && a.type_bits == 0)
+    k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED, kDst1Variant><<<grid, 256, 0, stream>>>(a);
+  else
     k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED><<<grid, 256, 0, stream>>>(a);
-  }
   PTGNN_LAUNCH_CHECK();
   if (a.hub_threshold > 0) {
     // the list length lives on the device: a fixed grid strides over it (zero entries => instant exit)
