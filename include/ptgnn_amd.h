@@ -90,6 +90,11 @@ int ptgnn_amd_get_gemm_mode(void);
  * ---------------------------------------------------------------------------------------- */
 size_t ptgnn_amd_csr_workspace_bytes(int64_t num_edges, int64_t num_nodes);
 size_t ptgnn_amd_csr_control_bytes(void);
+/* Test / A-B knob of the plan build (process-wide; results never depend on it): 0 = pick the record format by
+ * size (default), 1 = force the 12-byte records + wide buckets of the large-graph path, 2 = additionally force
+ * one LSD pre-pass (the > 21 row-bit path) -- so the parity tests can drive every path at sizes the numpy
+ * argsort oracle finishes in seconds. */
+int ptgnn_amd_set_plan_path(int path);
 int ptgnn_amd_type_bits(int32_t num_types);
 int ptgnn_amd_csr_build(const int64_t *const *src_per_type, /* host [num_types] of device ptrs */
                         const int64_t *const *dst_per_type, /* host [num_types] of device ptrs */

@@ -22,6 +22,7 @@ SIGNATURES = {
     "ptgnn_amd_get_gemm_mode": (_c.c_int, []),
     "ptgnn_amd_csr_workspace_bytes": (_c.c_size_t, [_i64, _i64]),
     "ptgnn_amd_csr_control_bytes": (_c.c_size_t, []),
+    "ptgnn_amd_set_plan_path": (_c.c_int, [_c.c_int]),
     "ptgnn_amd_type_bits": (_c.c_int, [_i32]),
     "ptgnn_amd_csr_build": (_c.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _c.c_int, _vp, _vp, _vp, _vp,
                                        _i32, _vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),

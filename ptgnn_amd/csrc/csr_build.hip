@@ -1,24 +1,38 @@
 // Graph plan construction: per-edge-type int64 adjacency lists -> one destination-sorted CSR.
 // See include/ptgnn_amd.h (ptgnn_amd_csr_build) for the contract and the reference lines replaced.
 //
-// Pipeline (all on `stream`, no host sync):
-//   1. k_pack   : walk the T lists (pointer table in the kernel argument segment), narrow to
-//                 int32, emit key = row (dst), payload = packed (src << type_bits | type) and the
-//                 edge position in the type-major concatenation.
-//   2. stable LSD radix sort of (key, position) over ceil(log2(rows)) bits, <= 9 bits per pass
-//      (18-bit node ids = 2 passes).  Hand-written for the sizes that matter here: rocPRIM's onesweep
-//      sort runs 1.1 M pairs as ~140 long-running workgroups (29 us per pass on MI355X, latency-bound
-//      with half the CUs idle); these kernels use one workgroup per 1024 pairs (one pair per lane):
-//        k_radix_hist    per-workgroup digit histogram            -> hist[digit][workgroup]
-//        exclusive scan  of the digit-major histogram (rocPRIM device scan: plumbing, 1 small launch)
-//        k_radix_scatter stable rank = earlier waves' count (LDS) + same-digit lanes below (ballots)
-//      PTGNN_AMD_SORT=rocprim selects the library sort instead (A/B + fallback).
-//   3. k_finish : payload gather into CSR order + rowptr from key boundaries.
-// HBM-bound integer work: 8 B/edge read once, O(passes * 16 B/edge) inside the sort.
+// The plan is a STABLE sort of the edges by plan row (the order of a numpy stable argsort: tests compare bit
+// for bit), built MSD-first by hand-written kernels only -- no vendor sort, no vendor scan:
+//
+//   k_split_count    per tile of the edge list: LDS histogram of the HIGH row bits (reads only the key column of
+//                    the int64 lists), stored as the tile's row of the aggregate table; digit totals by one
+//                    global atomic per (tile, digit) into the control block
+//   k_split_scatter  one pass over the lists: stable scatter of compact records into <= 512 buckets of
+//                    consecutive rows.  Cross-tile prefix of a digit = column sum of the aggregate rows of all
+//                    earlier tiles (complete: previous launch) -- no flags, no inter-workgroup ordering
+//   k_plan_buckets   one workgroup per bucket: stable counting sort by the LOW row bits -> rowptr, col, perm and
+//                    the hub list; the last workgroup puts the control block back to its zero-at-rest state
+//
+// Ranking ("many keys per thread, ranks in registers"): a wave owns a CONTIGUOUS run of records and walks it in
+// rounds of 64; the rank of a record among the equal digits of its round is a ballot match, the count of its
+// wave's earlier rounds sits in a WAVE-PRIVATE LDS counter row -- no workgroup barrier per round (round 2 ranked
+// every 1024 records with three barriers and a 16-wave prefix; that LDS-latency chain bounded the build).  Two
+// barriers per tile turn the wave rows into global positions.  Ranks stay in registers between the two.
+//
+// Sizes:
+//   * row ids <= 18 bits and <= 4 M edges (every minibatch): 8-byte records (low row bits | position, payload),
+//     buckets of <= 512 rows;
+//   * anything larger (cfg5 shard: 1.25 M rows / 12.5 M edges; backward plans over rows = src * T + type):
+//     12-byte records, buckets of up to 4096 rows whose wave-private counters are packed 16-bit pairs
+//     (144 KB of LDS per workgroup -- CDNA4's 160 KB is what makes the two-level form reach 21 bits);
+//   * more than 21 row bits: the lowest bits are peeled off first by LSD pre-passes of the same two kernels
+//     (stable, so the MSD levels that follow keep their order), and rowptr comes from the sorted keys.
+// HBM-bound integer work; the lists are read 1.5 times (8 + 16 B/edge), records written and read once.
 #include <stdlib.h>
 #include <string.h>
 
-#include <rocprim/rocprim.hpp>
+#include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -109,165 +123,6 @@ __device__ __forceinline__ EdgeRec edge_record(const TypeTable &tab, int64_t e, 
   return r;
 }
 
-__global__ __launch_bounds__(256) void k_pack(TypeTable tab, int32_t type_bits, int mode, int total_types,
-                                              uint32_t *__restrict__ keys,
-                                              int32_t *__restrict__ pos,
-                                              int32_t *__restrict__ packed, int64_t pos_base, RangeGuard guard) {
-  const int64_t total = tab.offset[tab.num_types];
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const EdgeRec r = edge_record(tab, e, type_bits, mode, total_types, guard, true, TypeSpan{0, tab.num_types});
-    const int64_t g = pos_base + e;
-    pos[g] = (int32_t)g;
-    keys[g] = r.key;
-    packed[g] = r.packed;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_finish(const uint32_t *__restrict__ keys_sorted,
-                                                const int32_t *__restrict__ pos_sorted,
-                                                const int32_t *__restrict__ packed,
-                                                int64_t num_edges, int64_t num_nodes,
-                                                int32_t *__restrict__ rowptr,
-                                                int32_t *__restrict__ col,
-                                                int32_t *__restrict__ perm) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (num_edges == 0) {
-    for (int64_t v = i; v <= num_nodes; v += (int64_t)gridDim.x * blockDim.x) rowptr[v] = 0;
-    return;
-  }
-  if (i >= num_edges) return;
-  const int32_t p = pos_sorted[i];
-  col[i] = packed[p];
-  if (perm) perm[i] = p;
-  const int64_t k = keys_sorted[i];
-  const int64_t kprev = (i == 0) ? -1 : (int64_t)keys_sorted[i - 1];
-  for (int64_t v = kprev + 1; v <= k; ++v) rowptr[v] = (int32_t)i;  // rows (kprev, k] start here
-  if (i == num_edges - 1)
-    for (int64_t v = k + 1; v <= num_nodes; ++v) rowptr[v] = (int32_t)num_edges;
-}
-
-// ---- stable LSD radix sort of (key, value) pairs, one pair per lane, 1024 pairs per workgroup ------
-constexpr int kSortBlock = 1024;
-constexpr int kMaxBins = 512;
-
-__global__ __launch_bounds__(kSortBlock) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n,
-                                                           int shift, int bits,
-                                                           int32_t *__restrict__ hist, int64_t nblocks) {
-  __shared__ int lh[kMaxBins];
-  const int bins = 1 << bits;
-  for (int j = threadIdx.x; j < bins; j += kSortBlock) lh[j] = 0;
-  __syncthreads();
-  const int64_t i = blockIdx.x * (int64_t)kSortBlock + threadIdx.x;
-  if (i < n) atomicAdd(&lh[(keys[i] >> shift) & (bins - 1)], 1);
-  __syncthreads();
-  for (int j = threadIdx.x; j < bins; j += kSortBlock) hist[(int64_t)j * nblocks + blockIdx.x] = lh[j];
-}
-
-__global__ __launch_bounds__(kSortBlock) void k_radix_scatter(
-    const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
-    uint32_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, int64_t n, int shift, int bits,
-    const int32_t *__restrict__ offs /* scanned hist */, int64_t nblocks) {
-  __shared__ int wave_cnt[(kSortBlock / 64) * kMaxBins];
-  const int bins = 1 << bits;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int j = threadIdx.x; j < (kSortBlock / 64) * bins; j += kSortBlock) wave_cnt[j] = 0;
-  const int64_t i = blockIdx.x * (int64_t)kSortBlock + threadIdx.x;
-  const bool valid = i < n;
-  const uint32_t key = valid ? keys_in[i] : 0u;
-  const int32_t val = valid ? vals_in[i] : 0;
-  const int digit = (int)((key >> shift) & (uint32_t)(bins - 1));
-  // lanes of this wave that hold the same digit (ballots are wave-wide, 64 bits)
-  unsigned long long same = __ballot(valid);
-  for (int b = 0; b < bits; ++b) {
-    const bool bit = (digit >> b) & 1;
-    const unsigned long long bal = __ballot(bit);
-    same &= bit ? bal : ~bal;
-  }
-  const int rank = __popcll(same & ((1ull << lane) - 1ull));
-  __syncthreads();                                     // wave_cnt is zeroed
-  if (valid && rank == 0) wave_cnt[wave * bins + digit] = __popcll(same);
-  __syncthreads();
-  for (int d = threadIdx.x; d < bins; d += kSortBlock) {   // exclusive prefix over the 16 waves
-    int run = 0;
-    for (int w = 0; w < kSortBlock / 64; ++w) {
-      const int t = wave_cnt[w * bins + d];
-      wave_cnt[w * bins + d] = run;
-      run += t;
-    }
-  }
-  __syncthreads();
-  if (valid) {
-    const int64_t pos = (int64_t)offs[(int64_t)digit * nblocks + blockIdx.x] + wave_cnt[wave * bins + digit] + rank;
-    keys_out[pos] = key;
-    vals_out[pos] = val;
-  }
-}
-
-// ---- two-level plan build for minibatch-sized graphs (rows <= 2^18, <= 64 edge types, <= 4 M edges) --
-// The LSD sort above needs 2 x (histogram, scan, scatter) + pack + finish + hub list = 11 dependent
-// launches whose 4-byte scatters land two-at-a-time in random cache lines.  Rows are node ids, i.e.
-// roughly uniformly populated, so the plan is built MSD-first in THREE launches:
-//   k_plan_count    per 4096-edge tile: LDS histogram of the HIGH row bits (reads only the key column of the
-//                   int64 lists), stored as the tile's row of the aggregate table; digit totals by one global
-//                   atomic per (tile, digit) into the control block (4 replicas against same-address contention)
-//   k_plan_scatter  one pass over the lists: stable scatter of 8-byte records (low row bits | position,
-//                   payload) into <= 512 buckets of 2^low_bits consecutive rows.  The cross-tile prefix of every
-//                   digit is the column sum of the aggregate rows of all earlier tiles (complete: previous
-//                   launch): all 1024 threads, dwordx4, 32 rows per step, plain cached loads -- no flags, no
-//                   inter-workgroup communication or ordering.  Quadratic in the tile count, which the 4 M-edge
-//                   ceiling of this path bounds at 1024 (72 MB of L2 reads at 1.1 M edges).  A decoupled
-//                   look-back over (flag | value) status words was measured against it: its agent-scope loads go
-//                   to the memory side on this multi-L2 part (~1 us per dependent step) and it was never faster
-//                   (625 k edges / 153 tiles: 18.0 vs 15.7 us per launch; 1.1 M edges / 269 tiles: 28.2 vs 28.5)
-//   k_plan_buckets  one workgroup per bucket: histogram of the LOW bits = the in-degrees -> rowptr and
-//                   the hub list directly; stable counting sort of the bucket into col / perm; the last
-//                   workgroup to have read the control block zeroes it again
-// Keys are never materialised, the second level works inside a few-KiB window of the output, and the edge
-// lists are read 1.5 times (8 + 16 B/edge) against 2 x 16 B/edge + a scan launch for the histogram/scan/scatter
-// form this replaces.  Stability of both levels = the order of a numpy stable argsort (tests: bit-exact).
-//
-// Control block (PlanControl, ptgnn_amd_csr_control_bytes()): digit totals + one counter, ZERO AT REST -- the
-// caller zero-fills it once, hands it to every build on ONE stream, and finds it zero-filled again after each
-// build.  A null control pointer makes the library carve one out of the workspace and zero it with a memset
-// node per build.
-constexpr int kMsdBlock = 1024;
-constexpr int kTileRounds = 4;
-constexpr int kTileEdges = kMsdBlock * kTileRounds;   // edges per tile of k_plan_count / k_plan_scatter
-constexpr int kPosBits = 22;                          // record.x = low row bits << 22 | position (E <= 4 M)
-
-constexpr int kTotalReplicas = 4;
-struct PlanControl {
-  int32_t totals[kTotalReplicas][kMaxBins];   // digit totals, replica = tile % 4
-  int32_t done;                               // k_plan_buckets workgroups that have finished reading `totals`
-  int32_t pad[3];
-};
-
-__device__ __forceinline__ int digit_total(const PlanControl *ctl, int d) {
-  int v = 0;
-#pragma unroll
-  for (int r = 0; r < kTotalReplicas; ++r) v += ctl->totals[r][d];
-  return v;
-}
-
-// exclusive scan of v over threads 0 .. 511 of a 1024-thread block (tmp: 8 ints of LDS); returns the
-// exclusive prefix
-__device__ __forceinline__ int block_scan_512(int v, int *tmp) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
-  if (wave < 8 && lane == 63) tmp[wave] = inc;
-  __syncthreads();
-  int prior = 0;
-  if (wave < 8)
-    for (int w = 0; w < wave; ++w) prior += tmp[w];
-  return prior + inc - v;
-}
-
 // plan row of edge e (the sort key), reading only the column that holds it; same clamping as edge_record
 __device__ __forceinline__ uint32_t edge_key(const TypeTable &tab, int64_t e, int mode, int total_types,
                                              const RangeGuard &guard, TypeSpan span) {
@@ -283,227 +138,435 @@ __device__ __forceinline__ uint32_t edge_key(const TypeTable &tab, int64_t e, in
   return (key < 0 || key >= guard.num_rows) ? 0u : (uint32_t)key;
 }
 
-__global__ __launch_bounds__(kMsdBlock) void k_plan_count(TypeTable tab, int mode, int total_types, int64_t n,
-                                                          int low_bits, int bins, PlanControl *ctl,
-                                                          int32_t *__restrict__ agg, int32_t *hub_count,
-                                                          RangeGuard guard) {
-  __shared__ int lh[kMaxBins];
-  for (int j = threadIdx.x; j < bins; j += kMsdBlock) lh[j] = 0;
-  if (hub_count && blockIdx.x == 0 && threadIdx.x == 0) *hub_count = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * kTileEdges;
-  const TypeSpan span = tile_types(tab, base, (base + kTileEdges < n ? base + kTileEdges : n) - 1);
-#pragma unroll
-  for (int r = 0; r < kTileRounds; ++r) {
-    const int64_t e = base + r * kMsdBlock + threadIdx.x;
-    if (e < n) atomicAdd(&lh[edge_key(tab, e, mode, total_types, guard, span) >> low_bits], 1);
-  }
-  __syncthreads();
-  const int bp = (bins + 3) & ~3;                     // row stride of the aggregate table (dwordx4 reads)
-  for (int j = threadIdx.x; j < bp; j += kMsdBlock) {
-    const int c = j < bins ? lh[j] : 0;
-    agg[(int64_t)blockIdx.x * bp + j] = c;
-    if (c) atomicAdd(&ctl->totals[blockIdx.x % kTotalReplicas][j], c);
+// (key, position, payload) of every edge as three arrays: the output of an LSD pre-pass, and of k_pack for
+// batches with more than kMaxTypes edge types
+struct Soa {
+  uint32_t *key;
+  int32_t *pos;
+  int32_t *packed;
+};
+
+__global__ __launch_bounds__(256) void k_pack(TypeTable tab, int32_t type_bits, int mode, int total_types,
+                                              Soa out, int64_t pos_base, RangeGuard guard) {
+  const int64_t total = tab.offset[tab.num_types];
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const EdgeRec r = edge_record(tab, e, type_bits, mode, total_types, guard, true, TypeSpan{0, tab.num_types});
+    const int64_t g = pos_base + e;
+    out.pos[g] = (int32_t)g;
+    out.key[g] = r.key;
+    out.packed[g] = r.packed;
   }
 }
 
-// stable rank of this lane's digit inside a 1024-thread block: (earlier waves' count, rank in wave)
-// via wave ballots + a [16][bins] LDS table; returns the block-local exclusive rank contribution
-// wave_cnt[wave][digit] + rank (valid lanes only) and leaves per-digit block totals in `run_out`
-// for threads < bins.
-__device__ __forceinline__ int block_stable_rank(bool valid, int digit, int bits, int bins, int *wave_cnt,
-                                                 int *run_out) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int j = threadIdx.x; j < (kMsdBlock / 64) * bins; j += kMsdBlock) wave_cnt[j] = 0;
+// ---- the split kernels (one stable partition pass over the edge list by one digit of the key) --------------
+constexpr int kMaxBins = 512;
+constexpr int kSplitWaves = 8;
+constexpr int kSplitThreads = kSplitWaves * 64;
+constexpr int kSplitRounds = 8;                                    // records per lane per sub-tile
+constexpr int kWaveRun = 64 * kSplitRounds;                        // consecutive records one wave ranks
+constexpr int kSubTile = kSplitThreads * kSplitRounds;             // 4096 records
+constexpr int kMaxTiles = 512;      // the cross-tile prefix is quadratic in the tile count: large inputs take
+                                    // several sub-tiles per workgroup instead of more tiles
+constexpr int kPosBits = 22;        // 8-byte record: x = low row bits << 22 | position (E <= 4 M)
+constexpr int kSmallLowBits = 9;    // 8-byte records: buckets of <= 512 rows
+constexpr int kBigLowBits = 12;     // 12-byte records: buckets of <= 4096 rows
+constexpr int kMaxPasses = 3;       // <= 2 LSD pre-passes + the MSD level
+
+constexpr int kTotalReplicas = 4;
+struct PlanControl {
+  int32_t totals[kMaxPasses][kTotalReplicas][kMaxBins];   // digit totals of each pass, replica = tile % 4
+  int32_t done;                                           // k_plan_buckets workgroups that have read `totals`
+  int32_t pad[3];
+};
+
+__device__ __forceinline__ int digit_total(const int32_t *totals, int d) {
+  int v = 0;
+#pragma unroll
+  for (int r = 0; r < kTotalReplicas; ++r) v += totals[r * kMaxBins + d];
+  return v;
+}
+
+// exclusive scan of v over ALL threads of the block (NW waves; tmp: NW ints of LDS); returns the exclusive prefix
+template <int NW>
+__device__ __forceinline__ int block_scan(int v, int *tmp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();                 // tmp may still be read by the previous scan's consumers
+  if (lane == 63) tmp[wave] = inc;
+  __syncthreads();
+  int prior = 0;
+  for (int w = 0; w < wave; ++w) prior += tmp[w];
+  return prior + inc - v;
+}
+
+// lanes of this wave that hold the same digit (valid lanes only), as a 64-bit mask
+__device__ __forceinline__ unsigned long long match_digit(bool valid, int digit, int bits) {
   unsigned long long same = __ballot(valid);
   for (int b = 0; b < bits; ++b) {
     const bool bit = (digit >> b) & 1;
     const unsigned long long bal = __ballot(bit);
     same &= bit ? bal : ~bal;
   }
-  const int rank = __popcll(same & ((1ull << lane) - 1ull));
-  __syncthreads();
-  if (valid && rank == 0) wave_cnt[wave * bins + digit] = __popcll(same);
-  __syncthreads();
-  int run = 0;
-  if (threadIdx.x < bins) {     // bins <= 512 < block: one digit per thread
-    // all 16 counts first (independent LDS reads in flight together), then the prefix: written as a
-    // read-modify-write loop the accesses form a 16-deep dependent chain of LDS round trips
-    constexpr int W = kMsdBlock / 64;
-    int c[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) c[w] = wave_cnt[w * bins + threadIdx.x];
-#pragma unroll
-    for (int w = 0; w < W; ++w) {
-      wave_cnt[w * bins + threadIdx.x] = run;
-      run += c[w];
-    }
-  }
-  *run_out = run;
-  __syncthreads();
-  return valid ? wave_cnt[wave * bins + digit] + rank : 0;
+  return same;
 }
 
-// 8 waves per SIMD = two 16-wave workgroups per CU (<= 64 VGPRs): with one, the tiles beyond 256 run as a second
-// round and double the kernel time at cfg2's 269 tiles
-__global__ __launch_bounds__(kMsdBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_plan_scatter(TypeTable tab, int32_t type_bits, int mode,
-                                                            int total_types, int64_t n, int low_bits,
-                                                            int high_bits, int bins, const PlanControl *ctl,
-                                                            const int32_t *__restrict__ agg,
-                                                            int2 *__restrict__ recs, RangeGuard guard) {
-  __shared__ __attribute__((aligned(16))) int wave_cnt[(kMsdBlock / 64) * kMaxBins];
-  __shared__ int base[kMaxBins];
-  __shared__ int tile_excl[kMaxBins];
-  __shared__ int round_base[kTileRounds][kMaxBins];
-  __shared__ int tmp[8];
-  const int tile = blockIdx.x;
-  {   // where each bucket starts in the record array: prefix of the digit totals (complete: previous launch)
-    const int v = threadIdx.x < bins ? digit_total(ctl, threadIdx.x) : 0;
-    const int ex = block_scan_512(v, tmp);
-    if (threadIdx.x < bins) base[threadIdx.x] = ex;
-  }
-  const uint32_t low_mask = (1u << low_bits) - 1u;
-  EdgeRec rec[kTileRounds];
-  const TypeSpan span = tile_types(tab, (int64_t)tile * kTileEdges,
-                                   ((int64_t)(tile + 1) * kTileEdges < n ? (int64_t)(tile + 1) * kTileEdges : n) - 1);
+template <bool LISTS>
+__global__ __launch_bounds__(kSplitThreads) void k_split_count(TypeTable tab, Soa in, int mode, int total_types,
+                                                               int64_t n, int shift, uint32_t mask, int bins,
+                                                               int subs, int32_t *__restrict__ totals,
+                                                               int32_t *__restrict__ agg, int32_t *hub_count,
+                                                               RangeGuard guard) {
+  __shared__ int lh[kMaxBins];
+  for (int j = threadIdx.x; j < bins; j += kSplitThreads) lh[j] = 0;
+  if (hub_count && blockIdx.x == 0 && threadIdx.x == 0) *hub_count = 0;
+  __syncthreads();
+  for (int s = 0; s < subs; ++s) {
+    const int64_t base = ((int64_t)blockIdx.x * subs + s) * kSubTile;
+    if (base >= n) break;
+    TypeSpan span{0, 1};
+    if constexpr (LISTS) span = tile_types(tab, base, (base + kSubTile < n ? base + kSubTile : n) - 1);
 #pragma unroll
-  for (int r = 0; r < kTileRounds; ++r) {            // issued first: in flight under the prefix sums
-    const int64_t e = (int64_t)tile * kTileEdges + r * kMsdBlock + threadIdx.x;
-    rec[r] = EdgeRec{0u, 0};
-    if (e < n) rec[r] = edge_record(tab, e, type_bits, mode, total_types, guard, true, span);
+    for (int r = 0; r < kSplitRounds; ++r) {
+      const int64_t e = base + r * kSplitThreads + threadIdx.x;
+      if (e < n) {
+        uint32_t key;
+        if constexpr (LISTS) key = edge_key(tab, e, mode, total_types, guard, span);
+        else key = in.key[e];
+        atomicAdd(&lh[(key >> shift) & mask], 1);
+      }
+    }
+  }
+  __syncthreads();
+  const int bp = (bins + 3) & ~3;                     // row stride of the aggregate table (dwordx4 reads)
+  for (int j = threadIdx.x; j < bp; j += kSplitThreads) {
+    const int c = j < bins ? lh[j] : 0;
+    agg[(int64_t)blockIdx.x * bp + j] = c;
+    if (c) atomicAdd(&totals[(blockIdx.x % kTotalReplicas) * kMaxBins + j], c);
+  }
+}
+
+// where the scattered records go
+constexpr int DST_SOA = 0;    // pre-pass: (key, position, payload) arrays
+constexpr int DST_REC2 = 1;   // int2 (low row bits << 22 | position, payload)
+constexpr int DST_REC3 = 2;   // int2 (key, payload) + int position
+
+struct SplitOut {
+  Soa soa;
+  int2 *recs;
+  int32_t *rpos;
+  uint32_t low_mask;
+};
+
+template <bool LISTS, int DST>
+__global__ __launch_bounds__(kSplitThreads) void k_split_scatter(TypeTable tab, Soa in, int32_t type_bits, int mode,
+                                                                 int total_types, int64_t n, int shift,
+                                                                 uint32_t mask, int dbits, int bins, int subs,
+                                                                 const int32_t *__restrict__ totals,
+                                                                 const int32_t *__restrict__ agg, SplitOut out,
+                                                                 RangeGuard guard) {
+  __shared__ __attribute__((aligned(16))) int wcnt[kSplitWaves * kMaxBins];
+  __shared__ int cursor[kMaxBins];
+  __shared__ int tmp[kSplitWaves];
+  const int tile = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int *const wrow = wcnt + wave * kMaxBins;
+  {   // where each bucket starts in the output: prefix of the digit totals (complete: previous launch)
+    const int v = (int)threadIdx.x < bins ? digit_total(totals, threadIdx.x) : 0;
+    const int ex = block_scan<kSplitWaves>(v, tmp);
+    if ((int)threadIdx.x < bins) cursor[threadIdx.x] = ex;
   }
   {
     // exclusive cross-tile prefix of every digit = column sums of the aggregate rows of tiles 0 .. tile-1:
-    // thread (g, q) adds rows g, g+8, ... for digits 4q .. 4q+3; the 8 partials meet in LDS (the rank table's
+    // thread (g, q) adds rows g, g+4, ... for digits 4q .. 4q+3; the 4 partials meet in LDS (the rank table's
     // storage, not yet in use)
     const int bp = (bins + 3) & ~3;
     const int q = threadIdx.x & 127, g = threadIdx.x >> 7;
     int4 acc = make_int4(0, 0, 0, 0);
     if (4 * q < bp) {
 #pragma unroll 4
-      for (int r = g; r < tile; r += 8) {
+      for (int r = g; r < tile; r += 4) {
         const int4 v = *reinterpret_cast<const int4 *>(agg + (int64_t)r * bp + 4 * q);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
-      *reinterpret_cast<int4 *>(wave_cnt + g * kMaxBins + 4 * q) = acc;
+      *reinterpret_cast<int4 *>(wcnt + g * kMaxBins + 4 * q) = acc;
     }
     __syncthreads();
-    if (threadIdx.x < bins) {
-      int e8 = 0;
+    if ((int)threadIdx.x < bins) {
+      int e4 = 0;
 #pragma unroll
-      for (int gg = 0; gg < 8; ++gg) e8 += wave_cnt[gg * kMaxBins + threadIdx.x];
-      tile_excl[threadIdx.x] = e8;
+      for (int gg = 0; gg < 4; ++gg) e4 += wcnt[gg * kMaxBins + threadIdx.x];
+      cursor[threadIdx.x] += e4;
     }
-    __syncthreads();                                 // the rank rounds clear wave_cnt next
+    __syncthreads();                                 // the rank rounds clear wcnt next
   }
-  int local[kTileRounds];
-  int mine = 0;                                      // threads < bins: this tile's count of digit threadIdx.x
+  for (int s = 0; s < subs; ++s) {
+    const int64_t sbase = ((int64_t)tile * subs + s) * kSubTile;
+    if (sbase >= n) break;                            // workgroup-uniform
+    TypeSpan span{0, 1};
+    if constexpr (LISTS) span = tile_types(tab, sbase, (sbase + kSubTile < n ? sbase + kSubTile : n) - 1);
+    // wave w owns records [sbase + w * 512, + 512): round r = its r-th group of 64 consecutive records
+    const int64_t wbase = sbase + (int64_t)wave * kWaveRun + lane;
+    EdgeRec rec[kSplitRounds];
+    int32_t opos[kSplitRounds];
 #pragma unroll
-  for (int r = 0; r < kTileRounds; ++r) {
-    const int64_t e = (int64_t)tile * kTileEdges + r * kMsdBlock + threadIdx.x;
-    int run;
-    local[r] = block_stable_rank(e < n, (int)(rec[r].key >> low_bits), high_bits, bins, wave_cnt, &run);
-    if (threadIdx.x < bins) {
-      round_base[r][threadIdx.x] = mine;
-      mine += run;
+    for (int r = 0; r < kSplitRounds; ++r) {          // all loads of the sub-tile in flight together
+      const int64_t e = wbase + r * 64;
+      rec[r] = EdgeRec{0u, 0};
+      opos[r] = (int32_t)e;
+      if (e < n) {
+        if constexpr (LISTS) {
+          rec[r] = edge_record(tab, e, type_bits, mode, total_types, guard, true, span);
+        } else {
+          rec[r].key = in.key[e];
+          rec[r].packed = in.packed[e];
+          opos[r] = in.pos[e];
+        }
+      }
     }
-    __syncthreads();                                 // wave_cnt is cleared again by the next round
-  }
+    for (int j = lane; j < bins; j += 64) wrow[j] = 0;
+    __builtin_amdgcn_wave_barrier();                  // DS ops of one wave execute in order; this pins the compiler
+    int rk[kSplitRounds];
 #pragma unroll
-  for (int r = 0; r < kTileRounds; ++r) {
-    const int64_t e = (int64_t)tile * kTileEdges + r * kMsdBlock + threadIdx.x;
-    if (e < n) {
-      const int digit = (int)(rec[r].key >> low_bits);
-      const int64_t pos = (int64_t)base[digit] + tile_excl[digit] + round_base[r][digit] + local[r];
-      recs[pos] = make_int2((int)(((rec[r].key & low_mask) << kPosBits) | (uint32_t)e), rec[r].packed);
+    for (int r = 0; r < kSplitRounds; ++r) {
+      const bool valid = wbase + r * 64 < n;
+      const int digit = (int)((rec[r].key >> shift) & mask);
+      const unsigned long long same = match_digit(valid, digit, dbits);
+      const int below = __popcll(same & ((1ull << lane) - 1ull));
+      const int prior = valid ? wrow[digit] : 0;      // this wave's earlier rounds
+      __builtin_amdgcn_wave_barrier();
+      if (valid && below == 0) wrow[digit] = prior + __popcll(same);
+      __builtin_amdgcn_wave_barrier();
+      rk[r] = prior + below;
     }
+    __syncthreads();
+    if ((int)threadIdx.x < bins) {   // wave rows -> global positions; all counts first (independent LDS reads)
+      int c[kSplitWaves];
+#pragma unroll
+      for (int w = 0; w < kSplitWaves; ++w) c[w] = wcnt[w * kMaxBins + threadIdx.x];
+      int run = cursor[threadIdx.x];
+#pragma unroll
+      for (int w = 0; w < kSplitWaves; ++w) {
+        wcnt[w * kMaxBins + threadIdx.x] = run;
+        run += c[w];
+      }
+      cursor[threadIdx.x] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSplitRounds; ++r) {
+      if (wbase + r * 64 < n) {
+        const int digit = (int)((rec[r].key >> shift) & mask);
+        const int64_t pos = (int64_t)wrow[digit] + rk[r];
+        if constexpr (DST == DST_SOA) {
+          out.soa.key[pos] = rec[r].key;
+          out.soa.pos[pos] = opos[r];
+          out.soa.packed[pos] = rec[r].packed;
+        } else if constexpr (DST == DST_REC2) {
+          out.recs[pos] = make_int2((int)(((rec[r].key & out.low_mask) << kPosBits) | (uint32_t)opos[r]),
+                                    rec[r].packed);
+        } else {
+          out.recs[pos] = make_int2((int)rec[r].key, rec[r].packed);
+          out.rpos[pos] = opos[r];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // this wave's reads of its row precede the next sub-tile's clear
   }
 }
 
-__global__ __launch_bounds__(kMsdBlock) void k_plan_buckets(
-    const int2 *__restrict__ recs, PlanControl *ctl, int bins, int low_bits,
-    int64_t num_rows, int64_t num_edges, int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
-    int32_t *__restrict__ perm, int32_t hub_threshold, int32_t hub_chunk, int32_t *__restrict__ hub_entries,
-    int32_t *__restrict__ hub_count) {
-  __shared__ int wave_cnt[(kMsdBlock / 64) * kMaxBins];
-  __shared__ int offs[kMaxBins];
-  __shared__ int tmp[8];
+// ---- second level: one workgroup per bucket -----------------------------------------------------------------
+// Stable counting sort of the bucket's records by the low row bits.  Records are ranked in super-chunks of
+// NW x 512; inside one, wave w owns a contiguous run, counts it into its private counter row (packed 16-bit
+// pairs: a run holds <= 512 records and a super-chunk <= 8192 at NW = 16, so neither the counts nor their
+// prefix over the waves can carry into the neighbour), one pass over the rows turns them into offsets, and the
+// wave ranks its run round by round against them.  BIG: 12-byte records, digit = (key >> pshift) & mask.
+constexpr int kBucketRounds = 8;
+
+template <int NW, bool BIG>
+__global__ __launch_bounds__(NW * 64) void k_plan_buckets(
+    const int2 *__restrict__ recs, const int32_t *__restrict__ rpos, PlanControl *ctl, int pass, int bins,
+    int low_bits, int pshift, int64_t num_rows, int64_t num_edges, int32_t *__restrict__ rowptr,
+    int32_t *__restrict__ col, int32_t *__restrict__ perm, uint32_t *__restrict__ keys_out, int32_t hub_threshold,
+    int32_t hub_chunk, int32_t *__restrict__ hub_entries, int32_t *__restrict__ hub_count) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+  constexpr int NT = NW * 64;
+  constexpr int SC = NT * kBucketRounds;             // records per super-chunk
+  constexpr int WPT = (1 << (kBigLowBits - 1)) / 512;  // counter words a thread may own (2048 words / 512 threads)
+  __shared__ int tmp[NW];
   __shared__ int bucket_start_s, bucket_size_s, last_s;
+  const int lbins = 1 << low_bits, lmask = lbins - 1;
+  const int words = (lbins + 1) >> 1;
+  uint32_t *const offs = dyn;                         // [lbins] degrees -> row starts -> + records placed so far
+  uint32_t *const wcnt = dyn + lbins;                 // [NW][words] packed wave counters
   const int b = blockIdx.x;
-  const int lbins = 1 << low_bits, mask = lbins - 1;
-  {   // where this bucket starts in the record array: prefix of the digit totals
-    const int v = threadIdx.x < bins ? digit_total(ctl, threadIdx.x) : 0;
-    const int ex = block_scan_512(v, tmp);
-    if (threadIdx.x == b) { bucket_start_s = ex; bucket_size_s = v; }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t *const wrow = wcnt + wave * words;
+  const int32_t *totals = &ctl->totals[pass][0][0];
+  {   // where this bucket starts in the record array: prefix of the digit totals (bins <= 512 <= NT)
+    const int v = (int)threadIdx.x < bins ? digit_total(totals, threadIdx.x) : 0;
+    const int ex = block_scan<NW>(v, tmp);
+    if ((int)threadIdx.x == b) { bucket_start_s = ex; bucket_size_s = v; }
   }
-  for (int j = threadIdx.x; j < lbins; j += kMsdBlock) offs[j] = 0;
+  for (int j = threadIdx.x; j < lbins; j += NT) offs[j] = 0;
   __syncthreads();
   // every thread of this workgroup has its totals in registers: the last workgroup to get here puts the
   // control block back to its zero-at-rest state
   if (threadIdx.x == 0) last_s = atomicAdd(&ctl->done, 1) == (int)gridDim.x - 1;
   const int s = bucket_start_s, e = s + bucket_size_s;
-  // the first 4096 records of the bucket (all of it, as a rule) stay in registers for both passes: one memory
-  // round trip with four loads in flight instead of two passes of dependent ones
-  constexpr int KC = kTileRounds;
-  int2 rc[KC];
+  auto digit_of = [&](int2 r) -> int {
+    return BIG ? (int)(((uint32_t)r.x >> pshift) & (uint32_t)lmask) : (int)(((uint32_t)r.x >> kPosBits) & (uint32_t)lmask);
+  };
+
+  // records of one super-chunk, wave-striped: wave w owns [cb + w * run, + run), run a multiple of 64
+  int2 rc[kBucketRounds];
+  int32_t rp[BIG ? kBucketRounds : 1];
+  int run = 0;
+  auto load_chunk = [&](int cb) {
+    const int left = e - cb < SC ? e - cb : SC;
+    run = (((left + NW - 1) / NW) + 63) & ~63;
 #pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    const int i = s + k * kMsdBlock + threadIdx.x;
-    rc[k] = i < e ? recs[i] : make_int2(0, 0);
-  }
+    for (int k = 0; k < kBucketRounds; ++k) {
+      const int i = cb + wave * run + k * 64 + lane;
+      const bool valid = k * 64 < run && i < e;
+      rc[k] = valid ? recs[i] : make_int2(0, 0);
+      if constexpr (BIG) rp[k] = valid ? rpos[i] : 0;
+    }
+  };
+  auto valid_at = [&](int cb, int k) -> bool { return k * 64 < run && cb + wave * run + k * 64 + lane < e; };
+
+  // in-degrees of the bucket's rows: the first super-chunk from registers (it is ranked from them below), the
+  // rest of a long bucket in a strided pass
+  load_chunk(s);
 #pragma unroll
-  for (int k = 0; k < KC; ++k)
-    if (s + k * kMsdBlock + (int)threadIdx.x < e) atomicAdd(&offs[(rc[k].x >> kPosBits) & mask], 1);
-  for (int i = s + KC * kMsdBlock + threadIdx.x; i < e; i += kMsdBlock)
-    atomicAdd(&offs[(recs[i].x >> kPosBits) & mask], 1);
+  for (int k = 0; k < kBucketRounds; ++k)
+    if (valid_at(s, k)) atomicAdd(&offs[digit_of(rc[k])], 1u);
+  for (int i = s + SC + threadIdx.x; i < e; i += NT) atomicAdd(&offs[digit_of(recs[i])], 1u);
   __syncthreads();
   if (last_s) {
-    for (int j = threadIdx.x; j < kTotalReplicas * kMaxBins; j += kMsdBlock) (&ctl->totals[0][0])[j] = 0;
+    for (int j = threadIdx.x; j < kMaxPasses * kTotalReplicas * kMaxBins; j += NT) (&ctl->totals[0][0][0])[j] = 0;
     if (threadIdx.x == 0) ctl->done = 0;
   }
-  {   // in-degrees -> rowptr (+ hub rows); offs becomes the running write cursor of each row
-    const int deg = threadIdx.x < lbins ? offs[threadIdx.x] : 0;
+  {   // degrees -> row starts (+ rowptr, hub rows); thread t owns the consecutive digits [t * per, (t+1) * per)
+    const int per = (lbins + NT - 1) / NT;
+    const int d0 = threadIdx.x * per;
+    uint32_t deg[(1 << kBigLowBits) / 512];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < (1 << kBigLowBits) / 512; ++k) {
+      deg[k] = (k < per && d0 + k < lbins) ? offs[d0 + k] : 0u;
+      sum += (int)deg[k];
+    }
+    int ex = block_scan<NW>(sum, tmp);       // synchronises: every degree has been read
+#pragma unroll
+    for (int k = 0; k < (1 << kBigLowBits) / 512; ++k) {
+      if (k < per && d0 + k < lbins) {
+        offs[d0 + k] = (uint32_t)ex;
+        if (keys_out == nullptr) {
+          const int64_t row = ((int64_t)b << low_bits) + d0 + k;
+          if (row < num_rows) {
+            rowptr[row] = s + ex;
+            if (row == num_rows - 1) rowptr[num_rows] = (int32_t)num_edges;
+            if (hub_entries && hub_threshold > 0 && (int)deg[k] > hub_threshold) {
+              const int beg = s + ex, end = beg + (int)deg[k];
+              const int c0 = beg / hub_chunk, c1 = (end - 1) / hub_chunk;
+              const int at = atomicAdd(hub_count, c1 - c0 + 1);
+              for (int c = c0; c <= c1; ++c) {
+                hub_entries[2 * (at + c - c0)] = c;
+                hub_entries[2 * (at + c - c0) + 1] = (int32_t)row;
+              }
+            }
+          }
+        }
+        ex += (int)deg[k];
+      }
+    }
+  }
+  uint32_t pend[WPT];   // packed totals of the previous super-chunk, owned per counter word
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) pend[k] = 0u;
+  for (int cb = s; cb < e; cb += SC) {
+    if (cb > s) load_chunk(cb);
+    for (int j = lane; j < words; j += 64) wrow[j] = 0u;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < kBucketRounds; ++k) {
+      if (valid_at(cb, k)) {
+        const int d = digit_of(rc[k]);
+        atomicAdd(&wrow[d >> 1], 1u << ((d & 1) * 16));
+      }
+    }
     __syncthreads();
-    const int ex = block_scan_512(deg, tmp);
-    const int64_t row = ((int64_t)b << low_bits) + threadIdx.x;
-    if (threadIdx.x < lbins) {
-      offs[threadIdx.x] = ex;
-      if (row < num_rows) {
-        rowptr[row] = s + ex;
-        if (row == num_rows - 1) rowptr[num_rows] = (int32_t)num_edges;
-        if (hub_entries && hub_threshold > 0 && deg > hub_threshold) {
-          const int beg = s + ex, end = beg + deg;
-          const int c0 = beg / hub_chunk, c1 = (end - 1) / hub_chunk;
-          const int at = atomicAdd(hub_count, c1 - c0 + 1);
-          for (int c = c0; c <= c1; ++c) {
-            hub_entries[2 * (at + c - c0)] = c;
-            hub_entries[2 * (at + c - c0) + 1] = (int32_t)row;
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {   // counter word t + k * NT: both halves prefix at once over the waves
+      const int word = threadIdx.x + k * NT;
+      if (word < words) {
+        if (pend[k]) {                 // rows advance by what the previous super-chunk placed
+          offs[2 * word] += pend[k] & 0xffffu;
+          if (2 * word + 1 < lbins) offs[2 * word + 1] += pend[k] >> 16;
+        }
+        uint32_t c[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) c[w] = wcnt[w * words + word];
+        uint32_t acc = 0u;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          wcnt[w * words + word] = acc;
+          acc += c[w];
+        }
+        pend[k] = acc;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kBucketRounds; ++k) {
+      if (k * 64 < run) {              // wave-uniform
+        const bool valid = valid_at(cb, k);
+        const int d = digit_of(rc[k]);
+        const unsigned long long same = match_digit(valid, d, low_bits);
+        const int below = __popcll(same & ((1ull << lane) - 1ull));
+        const int sh = (d & 1) * 16;
+        const uint32_t cur = valid ? (wrow[d >> 1] >> sh) & 0xffffu : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && below == 0) atomicAdd(&wrow[d >> 1], (uint32_t)__popcll(same) << sh);
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+          const int pos = s + (int)offs[d] + (int)cur + below;
+          col[pos] = rc[k].y;
+          if constexpr (BIG) {
+            if (perm) perm[pos] = rp[k];
+            if (keys_out) keys_out[pos] = (uint32_t)rc[k].x;
+          } else {
+            if (perm) perm[pos] = rc[k].x & ((1 << kPosBits) - 1);
           }
         }
       }
     }
+    // no barrier: the next super-chunk clears and counts wave-private rows only, and `offs` moves in its prefix
+    // step, behind the barrier every wave reaches after this ranking step
   }
-  __syncthreads();
-  auto place = [&](bool valid, int2 r) {   // one 1024-record chunk, in record order
-    const int digit = (r.x >> kPosBits) & mask;
-    int run;
-    const int local = block_stable_rank(valid, digit, low_bits, lbins, wave_cnt, &run);   // syncs inside
-    if (valid) {
-      const int pos = s + offs[digit] + local;
-      col[pos] = r.y;
-      if (perm) perm[pos] = r.x & ((1 << kPosBits) - 1);
-    }
-    __syncthreads();
-    if (threadIdx.x < lbins) offs[threadIdx.x] += run;
-    // the next chunk's block_stable_rank synchronises before offs is read again
-  };
-#pragma unroll
-  for (int k = 0; k < KC; ++k)
-    if (s + k * kMsdBlock < e) place(s + k * kMsdBlock + (int)threadIdx.x < e, rc[k]);   // workgroup-uniform test
-  for (int cb = s + KC * kMsdBlock; cb < e; cb += kMsdBlock) {
-    const int i = cb + threadIdx.x;
-    place(i < e, i < e ? recs[i] : make_int2(0, 0));
-  }
+}
+
+// rowptr from the sorted keys (plans with LSD pre-passes, whose buckets hold several rows per low digit)
+__global__ __launch_bounds__(256) void k_rowptr_from_keys(const uint32_t *__restrict__ keys_sorted, int64_t num_edges,
+                                                          int64_t num_rows, int32_t *__restrict__ rowptr) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= num_edges) return;
+  const int64_t k = keys_sorted[i];
+  const int64_t kprev = (i == 0) ? -1 : (int64_t)keys_sorted[i - 1];
+  for (int64_t v = kprev + 1; v <= k; ++v) rowptr[v] = (int32_t)i;  // rows (kprev, k] start here
+  if (i == num_edges - 1)
+    for (int64_t v = k + 1; v <= num_rows; ++v) rowptr[v] = (int32_t)num_edges;
+}
+
+__global__ __launch_bounds__(256) void k_zero_rowptr(int32_t *__restrict__ rowptr, int64_t num_rows) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v <= num_rows; v += (int64_t)gridDim.x * blockDim.x)
+    rowptr[v] = 0;
 }
 
 // (chunk, row) pairs of every row longer than `threshold`, appended in arbitrary order (consumers
@@ -552,73 +615,99 @@ __global__ __launch_bounds__(256) void k_validate(const int64_t *__restrict__ id
   if (local) atomicAdd(bad, local);
 }
 
+// ---- host side ----------------------------------------------------------------------------------------------
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-struct WsLayout {
-  size_t keys_in, keys_out, pos_in, pos_out, packed, sort_tmp, sort_tmp_bytes, hist, hist_scan, control, total;
-};
-
-// The one-pair-per-lane kernels win up to a few million edges (minibatch sizes: 0.11 vs 0.15 ms at
-// 1.1 M, 0.085 vs 0.16 ms at 0.6 M edges); beyond that rocPRIM's many-items-per-thread onesweep
-// coalesces its scatters better (0.67 vs 0.80 ms at 12.5 M).  PTGNN_AMD_SORT=rocprim|custom forces one.
-bool use_rocprim_sort(int64_t num_edges) {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("PTGNN_AMD_SORT");
-    v = !e ? 0 : (strcmp(e, "rocprim") == 0 ? 1 : (strcmp(e, "custom") == 0 || strcmp(e, "lsd") == 0 ? 2 : 0));
-  }
-  if (v == 1) return true;
-  if (v == 2 || v == 3) return false;
-  return num_edges > ((int64_t)4 << 20);
-}
-
-// two-level build: needs every row id in 18 bits (high digit <= 9 bits over <= 9-bit buckets) and one
-// type table; PTGNN_AMD_SORT=lsd forces the flat LSD sort for A/B runs
-bool use_msd_build(int64_t num_edges, int64_t num_rows, int num_types) {
-  const char *e = getenv("PTGNN_AMD_SORT");
-  if (e && strcmp(e, "msd") != 0) return false;
-  return num_edges > 0 && num_edges <= ((int64_t)4 << 20) && num_rows <= ((int64_t)1 << 18) &&
-         num_types <= kMaxTypes;
-}
-
-int end_bit_for(int64_t num_nodes) {
+int end_bit_for(int64_t num_rows) {
   int b = 1;
-  while (((int64_t)1 << b) < num_nodes) ++b;
+  while (((int64_t)1 << b) < num_rows) ++b;
   return b;
 }
 
-hipError_t sort_tmp_bytes(int64_t num_edges, int64_t num_nodes, size_t *bytes) {
-  *bytes = 0;
-  if (num_edges == 0) return hipSuccess;
-  size_t a = 0, b = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, a, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                           (int32_t *)nullptr, (int32_t *)nullptr, (size_t)num_edges, 0,
-                                           end_bit_for(num_nodes), (hipStream_t)0);
-  if (e != hipSuccess) return e;
-  const size_t nh = (size_t)kMaxBins * (size_t)((num_edges + kSortBlock - 1) / kSortBlock);
-  e = rocprim::exclusive_scan(nullptr, b, (int32_t *)nullptr, (int32_t *)nullptr, 0, nh,
-                              rocprim::plus<int32_t>(), (hipStream_t)0);
-  *bytes = a > b ? a : b;
-  return e;
+int g_force_path = 0;   // ptgnn_amd_set_plan_path: 0 auto, 1 force 12-byte records, 2 force an LSD pre-pass
+
+// How a build of (edges, rows) is split into passes.
+struct PlanPath {
+  int bits;           // row id bits
+  int low_bits;       // second level: rows per bucket = 2^low_bits
+  int pre_bits;       // bits peeled off by LSD pre-passes (0 as a rule)
+  int npre;           // number of pre-passes
+  int pre[2];         // bits of each pre-pass, lowest first
+  bool big;           // 12-byte records
+  int bins;           // first-level buckets
+  int subs;           // sub-tiles per workgroup of the split kernels
+  int64_t ntiles;
+  int bucket_waves;   // 8 or 16
+  size_t bucket_lds;  // dynamic LDS of k_plan_buckets
+};
+
+PlanPath choose_path(int64_t num_edges, int64_t num_rows) {
+  PlanPath P{};
+  P.bits = end_bit_for(num_rows);
+  const bool small = g_force_path == 0 && num_edges <= ((int64_t)1 << kPosBits) && P.bits <= 2 * kSmallLowBits;
+  P.big = !small;
+  const int lmax = small ? kSmallLowBits : kBigLowBits;
+  // buckets of ~4096 edges on average keep every CU busy in the second level
+  int l = 0;
+  while (l < lmax && l < P.bits && (((int64_t)2 << l) * num_edges <= (int64_t)4096 * num_rows)) ++l;
+  if (l < 3) l = P.bits < 3 ? P.bits : 3;
+  int p = 0;
+  if (P.bits - l > 9) l = P.bits - 9 < lmax ? P.bits - 9 : lmax;
+  if (P.bits - l > 9) p = P.bits - l - 9;
+  if (g_force_path == 2 && P.bits >= 3 && p < 2) {
+    p = 2;
+    if (l > P.bits - p) l = P.bits - p;
+  }
+  P.low_bits = l;
+  P.pre_bits = p;
+  P.npre = (p + 8) / 9;
+  P.pre[0] = P.npre == 2 ? (p + 1) / 2 : p;
+  P.pre[1] = p - P.pre[0];
+  P.bins = (int)((num_rows + (((int64_t)1 << (l + p)) - 1)) >> (l + p));
+  if (P.bins < 1) P.bins = 1;
+  P.subs = (int)((num_edges + (int64_t)kSubTile * kMaxTiles - 1) / ((int64_t)kSubTile * kMaxTiles));
+  if (P.subs < 1) P.subs = 1;
+  P.ntiles = (num_edges + (int64_t)kSubTile * P.subs - 1) / ((int64_t)kSubTile * P.subs);
+  P.bucket_waves = 16;
+  const size_t lbins = (size_t)1 << l;
+  P.bucket_lds = 4 * lbins + (size_t)P.bucket_waves * 4 * ((lbins + 1) / 2);
+  return P;
 }
 
-bool layout(int64_t num_edges, int64_t num_nodes, WsLayout *L) {
-  size_t tmp = 0;
-  if (sort_tmp_bytes(num_edges, num_nodes, &tmp) != hipSuccess) return false;
+struct WsLayout {
+  size_t soa_a, soa_b, recs, rpos, agg, control, total;
+};
+
+void layout(int64_t num_edges, const PlanPath &P, WsLayout *L) {
   const size_t e4 = align_up((size_t)num_edges * 4, 256);
   size_t o = 0;
-  L->keys_in = o;  o += e4;
-  L->keys_out = o; o += e4;
-  L->pos_in = o;   o += e4;
-  L->pos_out = o;  o += e4;
-  L->packed = o;   o += e4;
-  L->sort_tmp = o; o += align_up(tmp, 256);
-  L->sort_tmp_bytes = tmp;
-  const size_t nh = align_up((size_t)kMaxBins * (size_t)((num_edges + kSortBlock - 1) / kSortBlock) * 4, 256);
-  L->hist = o;      o += nh;
-  L->hist_scan = o; o += nh;
-  L->control = o;   o += align_up(sizeof(PlanControl), 256);   // only used when the caller passes no control block
+  L->soa_a = o; o += 3 * e4;                       // k_pack (> 64 edge types) / first pre-pass output
+  L->soa_b = o; o += P.npre > 0 ? 3 * e4 : 0;      // second hop of the pre-pass ping-pong
+  L->recs = o;  o += 2 * e4;
+  L->rpos = o;  o += P.big ? e4 : 0;
+  L->agg = o;   o += align_up((size_t)(P.ntiles > 0 ? P.ntiles : 1) * kMaxBins * 4, 256);
+  L->control = o; o += align_up(sizeof(PlanControl), 256);   // only used when the caller passes no control block
   L->total = o + 256;
+}
+
+// Raise a kernel's dynamic-LDS limit once per (device, kernel): the attribute call is not legal while a stream is
+// being captured into a hipGraph, and the warm-up launch outside the capture has made it.
+template <typename Kern>
+bool set_lds(Kern kern, size_t bytes) {
+  static std::mutex mu;
+  static std::unordered_map<uint64_t, size_t> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const void *fn = reinterpret_cast<const void *>(kern);
+  const uint64_t key = (uint64_t)(uintptr_t)fn * 64u + (uint64_t)dev;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find(key);
+  if (it != done.end() && it->second >= bytes) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  done[key] = bytes;
   return true;
 }
 
@@ -635,10 +724,16 @@ extern "C" int ptgnn_amd_type_bits(int32_t num_types) {
 
 extern "C" size_t ptgnn_amd_csr_control_bytes(void) { return sizeof(PlanControl); }
 
+extern "C" int ptgnn_amd_set_plan_path(int path) {
+  PTGNN_REQUIRE(path >= 0 && path <= 2, PTGNN_AMD_EINVAL, "set_plan_path: 0 auto, 1 wide records, 2 LSD pre-pass");
+  g_force_path = path;
+  return PTGNN_AMD_OK;
+}
+
 extern "C" size_t ptgnn_amd_csr_workspace_bytes(int64_t num_edges, int64_t num_nodes) {
   if (num_edges < 0 || num_nodes < 0) return 0;
   WsLayout L;
-  if (!layout(num_edges, num_nodes, &L)) return 0;
+  layout(num_edges, choose_path(num_edges, num_nodes), &L);
   return L.total;
 }
 
@@ -667,140 +762,186 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
   const int type_bits = ptgnn_amd_type_bits(num_types);
   // mode 2: `num_nodes` is the number of plan rows = source rows * num_types (caller passes it so)
   const int64_t src_rows = num_src_rows > num_nodes ? num_src_rows : num_nodes;
-  PTGNN_REQUIRE(num_edges < ((int64_t)1 << 31) &&
+  PTGNN_REQUIRE(num_edges < ((int64_t)1 << 31) && num_nodes < ((int64_t)1 << 31) &&
                     (src_rows << (swap_src_dst == 2 ? 0 : type_bits)) < ((int64_t)1 << 31),
                 PTGNN_AMD_EUNSUPPORTED,
-                "csr_build: num_edges=%lld / source rows=%lld x 2^%d exceed the int32 plan format",
-                (long long)num_edges, (long long)src_rows, type_bits);
+                "csr_build: num_edges=%lld / rows=%lld / source rows=%lld x 2^%d exceed the int32 plan format",
+                (long long)num_edges, (long long)num_nodes, (long long)src_rows, type_bits);
   PTGNN_REQUIRE(num_edges == 0 || col != nullptr, PTGNN_AMD_EINVAL, "csr_build: col is null");
   const RangeGuard guard{num_nodes, swap_src_dst == 0 ? src_rows : 0, bad_index_count};
+  const RangeGuard no_guard{num_nodes, 0, nullptr};
+  const bool hubs = hub_entries && hub_count && hub_threshold > 0;
+
+  if (num_edges == 0) {
+    const int64_t zb = (num_nodes + 256) / 256;
+    k_zero_rowptr<<<(unsigned)(zb < 1024 ? zb : 1024), 256, 0, stream>>>(rowptr, num_nodes);
+    PTGNN_LAUNCH_CHECK();
+    if (hubs) PTGNN_HIP(hipMemsetAsync(hub_count, 0, sizeof(int32_t), stream));
+    if (max_degree) PTGNN_HIP(hipMemsetAsync(max_degree, 0, sizeof(int32_t), stream));
+    return PTGNN_AMD_OK;
+  }
+
+  const PlanPath P = choose_path(num_edges, num_nodes);
   WsLayout L;
-  PTGNN_REQUIRE(layout(num_edges, num_nodes, &L), PTGNN_AMD_EHIP, "csr_build: sort size query failed");
-  PTGNN_REQUIRE(workspace_bytes >= L.total && (workspace || L.total == 0), PTGNN_AMD_EWORKSPACE,
+  layout(num_edges, P, &L);
+  PTGNN_REQUIRE(workspace_bytes >= L.total && workspace, PTGNN_AMD_EWORKSPACE,
                 "csr_build: workspace %zu < required %zu", workspace_bytes, L.total);
   char *ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  uint32_t *keys_in = (uint32_t *)(ws + L.keys_in), *keys_out = (uint32_t *)(ws + L.keys_out);
-  int32_t *pos_in = (int32_t *)(ws + L.pos_in), *pos_out = (int32_t *)(ws + L.pos_out);
-  int32_t *packed = (int32_t *)(ws + L.packed);
+  const size_t e4 = align_up((size_t)num_edges * 4, 256);
+  auto soa_at = [&](size_t off) {
+    Soa s;
+    s.key = (uint32_t *)(ws + off);
+    s.pos = (int32_t *)(ws + off + e4);
+    s.packed = (int32_t *)(ws + off + 2 * e4);
+    return s;
+  };
+  const Soa soa[2] = {soa_at(L.soa_a), soa_at(L.soa_b)};
+  int32_t *agg = (int32_t *)(ws + L.agg);
+  PlanControl *ctl = (PlanControl *)control;
+  if (ctl == nullptr) {         // no caller-owned control block: one inside the workspace, zeroed per build
+    ctl = (PlanControl *)(ws + L.control);
+    PTGNN_HIP(hipMemsetAsync(ctl, 0, sizeof(PlanControl), stream));
+  }
 
-  if (use_msd_build(num_edges, num_nodes, num_types)) {
-    TypeTable tab;
+  TypeTable tab{};
+  bool from_lists = num_types <= kMaxTypes;
+  int cur = -1;     // index of the Soa that holds the current records (-1: the lists)
+  if (from_lists) {
     tab.num_types = num_types;
-    tab.type_base = 0;
-    tab.offset[0] = 0;
     for (int t = 0; t < num_types; ++t) {
       tab.src[t] = src_per_type[t];
       tab.dst[t] = dst_per_type[t];
       tab.offset[t + 1] = tab.offset[t] + edges_per_type[t];
     }
-    const int total_bits = end_bit_for(num_nodes);
-    // buckets of ~4096 edges on average keep every CU busy in the second level; <= 9 bits per level
-    int low_bits = 0;
-    while (low_bits < 9 && low_bits < total_bits &&
-           (((int64_t)2 << low_bits) * num_edges <= (int64_t)4096 * num_nodes)) ++low_bits;
-    if (low_bits < 3) low_bits = total_bits < 3 ? total_bits : 3;
-    if (total_bits - low_bits > 9) low_bits = total_bits - 9;
-    const int high_bits = total_bits - low_bits;
-    const int bins = (int)((num_nodes + ((int64_t)1 << low_bits) - 1) >> low_bits);
-    const int64_t ntiles = (num_edges + kTileEdges - 1) / kTileEdges;
-    int32_t *agg = (int32_t *)(ws + L.hist);        // [ntiles][bins rounded up to 4] per-tile digit counts
-    int2 *recs = (int2 *)ws;      // 8 B/edge over the (unused) key/pos/payload buffers of the LSD path
-    PlanControl *ctl = (PlanControl *)control;
-    if (ctl == nullptr) {         // no caller-owned control block: one inside the workspace, zeroed per build
-      ctl = (PlanControl *)(ws + L.control);
-      PTGNN_HIP(hipMemsetAsync(ctl, 0, sizeof(PlanControl), stream));
-    }
-    const bool hubs = hub_entries && hub_count && hub_threshold > 0;
-    k_plan_count<<<(unsigned)ntiles, kMsdBlock, 0, stream>>>(tab, swap_src_dst, num_types, num_edges, low_bits, bins,
-                                                            ctl, agg, hubs ? hub_count : nullptr, guard);
-    PTGNN_LAUNCH_CHECK();
-    k_plan_scatter<<<(unsigned)ntiles, kMsdBlock, 0, stream>>>(tab, type_bits, swap_src_dst, num_types, num_edges,
-                                                              low_bits, high_bits, bins, ctl, agg, recs, guard);
-    PTGNN_LAUNCH_CHECK();
-    k_plan_buckets<<<(unsigned)bins, kMsdBlock, 0, stream>>>(recs, ctl, bins, low_bits, num_nodes, num_edges,
-                                                             rowptr, col, perm, hubs ? hub_threshold : 0, 1024,
-                                                             hub_entries, hub_count);
-    PTGNN_LAUNCH_CHECK();
-    if (max_degree) {
-      PTGNN_HIP(hipMemsetAsync(max_degree, 0, sizeof(int32_t), stream));
-      const int64_t mb = (num_nodes + 255) / 256;
-      k_max_degree<<<(unsigned)(mb < 1024 ? mb : 1024), 256, 0, stream>>>(rowptr, num_nodes, max_degree);
-      PTGNN_LAUNCH_CHECK();
-    }
-    return PTGNN_AMD_OK;
-  }
-  if (num_edges > 0) {
+  } else {
+    // more edge types than one kernel-argument table holds: narrow the lists into (key, position, payload)
+    // arrays chunk by chunk; the passes below then read those
     int64_t base = 0;
     for (int t0 = 0; t0 < num_types; t0 += kMaxTypes) {
-      TypeTable tab;
-      tab.num_types = (num_types - t0 < kMaxTypes) ? (num_types - t0) : kMaxTypes;
-      tab.type_base = t0;
-      tab.offset[0] = 0;
-      for (int t = 0; t < tab.num_types; ++t) {
-        tab.src[t] = src_per_type[t0 + t];
-        tab.dst[t] = dst_per_type[t0 + t];
-        tab.offset[t + 1] = tab.offset[t] + edges_per_type[t0 + t];
+      TypeTable tt;
+      tt.num_types = (num_types - t0 < kMaxTypes) ? (num_types - t0) : kMaxTypes;
+      tt.type_base = t0;
+      tt.offset[0] = 0;
+      for (int t = 0; t < tt.num_types; ++t) {
+        tt.src[t] = src_per_type[t0 + t];
+        tt.dst[t] = dst_per_type[t0 + t];
+        tt.offset[t + 1] = tt.offset[t] + edges_per_type[t0 + t];
       }
-      const int64_t chunk = tab.offset[tab.num_types];
+      const int64_t chunk = tt.offset[tt.num_types];
       if (chunk > 0) {
         const int64_t blocks = (chunk + 255) / 256;
-        k_pack<<<(unsigned)(blocks < 4096 ? blocks : 4096), 256, 0, stream>>>(
-            tab, type_bits, swap_src_dst, num_types, keys_in, pos_in, packed, base, guard);
+        k_pack<<<(unsigned)(blocks < 4096 ? blocks : 4096), 256, 0, stream>>>(tt, type_bits, swap_src_dst, num_types,
+                                                                              soa[0], base, guard);
         PTGNN_LAUNCH_CHECK();
       }
       base += chunk;
     }
-    size_t tmp = L.sort_tmp_bytes;
-    if (use_rocprim_sort(num_edges)) {
-      PTGNN_HIP(rocprim::radix_sort_pairs(ws + L.sort_tmp, tmp, keys_in, keys_out, pos_in, pos_out,
-                                          (size_t)num_edges, 0, end_bit_for(num_nodes), stream));
-    } else {
-      const int total_bits = end_bit_for(num_nodes);
-      const int passes = (total_bits + 8) / 9;
-      const int bits = (total_bits + passes - 1) / passes;          // <= 9
-      const int64_t nblocks = (num_edges + kSortBlock - 1) / kSortBlock;
-      int32_t *hist = (int32_t *)(ws + L.hist), *hscan = (int32_t *)(ws + L.hist_scan);
-      uint32_t *ka = keys_in, *kb = keys_out;
-      int32_t *va = pos_in, *vb = pos_out;
-      for (int p = 0; p < passes; ++p) {
-        const int shift = p * bits;
-        k_radix_hist<<<(unsigned)nblocks, kSortBlock, 0, stream>>>(ka, num_edges, shift, bits, hist, nblocks);
-        PTGNN_LAUNCH_CHECK();
-        size_t stmp = L.sort_tmp_bytes;
-        PTGNN_HIP(rocprim::exclusive_scan(ws + L.sort_tmp, stmp, hist, hscan, 0,
-                                          (size_t)((int64_t)(1 << bits) * nblocks),
-                                          rocprim::plus<int32_t>(), stream));
-        k_radix_scatter<<<(unsigned)nblocks, kSortBlock, 0, stream>>>(ka, va, kb, vb, num_edges, shift, bits,
-                                                                      hscan, nblocks);
-        PTGNN_LAUNCH_CHECK();
-        uint32_t *tk = ka; ka = kb; kb = tk;
-        int32_t *tv = va; va = vb; vb = tv;
-      }
-      keys_out = ka;   // the sorted pairs live in whichever buffer the last pass wrote
-      pos_out = va;
-    }
+    cur = 0;
   }
-  const int64_t work = num_edges > 0 ? num_edges : 1;
-  const int64_t blocks = num_edges > 0 ? (work + 255) / 256 : 64;
-  k_finish<<<(unsigned)blocks, 256, 0, stream>>>(keys_out, pos_out, packed, num_edges, num_nodes,
-                                                 rowptr, col, perm);
-  PTGNN_LAUNCH_CHECK();
-  if (hub_entries && hub_count && hub_threshold > 0) {
-    PTGNN_HIP(hipMemsetAsync(hub_count, 0, sizeof(int32_t), stream));
-    if (num_edges > hub_threshold && num_nodes > 0) {
-      const int64_t hb = (num_nodes + 255) / 256;
-      k_hub_list<<<(unsigned)(hb < 2048 ? hb : 2048), 256, 0, stream>>>(rowptr, num_nodes, hub_threshold,
-                                                                        1024, hub_entries, hub_count);
+  // soa_b only exists in the workspace when the path has pre-passes; a packed source with pre-passes ping-pongs
+  // a -> b (-> a), a list source writes its first pre-pass into a
+  const unsigned grid = (unsigned)P.ntiles;
+  int pass = 0;
+  int shift = 0;
+  bool first_count = true;
+  for (int i = 0; i < P.npre; ++i) {
+    const int bits_i = P.pre[i];
+    const uint32_t mask = (1u << bits_i) - 1u;
+    const int nb = 1 << bits_i;
+    int32_t *totals = &ctl->totals[pass][0][0];
+    const int dstidx = cur == 0 ? 1 : 0;
+    SplitOut out{};
+    out.soa = soa[dstidx];
+    if (cur < 0) {
+      k_split_count<true><<<grid, kSplitThreads, 0, stream>>>(tab, Soa{}, swap_src_dst, num_types, num_edges, shift,
+                                                             mask, nb, P.subs, totals, agg,
+                                                             first_count && hubs ? hub_count : nullptr, guard);
       PTGNN_LAUNCH_CHECK();
+      k_split_scatter<true, DST_SOA><<<grid, kSplitThreads, 0, stream>>>(tab, Soa{}, type_bits, swap_src_dst, num_types,
+                                                                        num_edges, shift, mask, bits_i, nb, P.subs,
+                                                                        totals, agg, out, guard);
+    } else {
+      k_split_count<false><<<grid, kSplitThreads, 0, stream>>>(tab, soa[cur], swap_src_dst, num_types, num_edges, shift,
+                                                              mask, nb, P.subs, totals, agg,
+                                                              first_count && hubs ? hub_count : nullptr, no_guard);
+      PTGNN_LAUNCH_CHECK();
+      k_split_scatter<false, DST_SOA><<<grid, kSplitThreads, 0, stream>>>(tab, soa[cur], type_bits, swap_src_dst,
+                                                                         num_types, num_edges, shift, mask, bits_i, nb,
+                                                                         P.subs, totals, agg, out, no_guard);
+    }
+    PTGNN_LAUNCH_CHECK();
+    first_count = false;
+    cur = dstidx;
+    shift += bits_i;
+    ++pass;
+  }
+  // first MSD level: digit = key >> (pre_bits + low_bits)
+  {
+    const int lshift = P.pre_bits + P.low_bits;
+    int dbits = 0;
+    while ((1 << dbits) < P.bins) ++dbits;
+    int32_t *totals = &ctl->totals[pass][0][0];
+    SplitOut out{};
+    out.recs = (int2 *)(ws + L.recs);
+    out.rpos = (int32_t *)(ws + L.rpos);
+    out.low_mask = (1u << P.low_bits) - 1u;
+    const int32_t *hc = first_count && hubs ? hub_count : nullptr;
+#define PTGNN_SPLIT(LISTS_, DST_, IN_, G_)                                                                            \
+  do {                                                                                                                \
+    k_split_count<LISTS_><<<grid, kSplitThreads, 0, stream>>>(tab, IN_, swap_src_dst, num_types, num_edges, lshift,   \
+                                                             0xffffffffu, P.bins, P.subs, totals, agg,               \
+                                                             (int32_t *)hc, G_);                                     \
+    PTGNN_LAUNCH_CHECK();                                                                                             \
+    k_split_scatter<LISTS_, DST_><<<grid, kSplitThreads, 0, stream>>>(tab, IN_, type_bits, swap_src_dst, num_types,  \
+                                                                     num_edges, lshift, 0xffffffffu, dbits, P.bins,  \
+                                                                     P.subs, totals, agg, out, G_);                  \
+    PTGNN_LAUNCH_CHECK();                                                                                             \
+  } while (0)
+    if (cur < 0) {
+      if (P.big) PTGNN_SPLIT(true, DST_REC3, Soa{}, guard); else PTGNN_SPLIT(true, DST_REC2, Soa{}, guard);
+    } else {
+      if (P.big) PTGNN_SPLIT(false, DST_REC3, soa[cur], no_guard); else PTGNN_SPLIT(false, DST_REC2, soa[cur], no_guard);
+    }
+#undef PTGNN_SPLIT
+  }
+  // second level
+  {
+    // plans with pre-passes: rowptr comes from the sorted keys (written over the first Soa's key array: every
+    // reader of it has finished)
+    uint32_t *keys_out = P.npre > 0 ? soa[0].key : nullptr;
+    const int2 *recs = (const int2 *)(ws + L.recs);
+    const int32_t *rpos = (const int32_t *)(ws + L.rpos);
+    const unsigned bgrid = (unsigned)P.bins;
+    const int hub_thr = hubs && keys_out == nullptr ? hub_threshold : 0;
+    if (P.big) {
+      auto kern = k_plan_buckets<16, true>;
+      PTGNN_REQUIRE(set_lds(kern, P.bucket_lds), PTGNN_AMD_EHIP, "csr_build: %zu B of LDS refused", P.bucket_lds);
+      kern<<<bgrid, 16 * 64, P.bucket_lds, stream>>>(recs, rpos, ctl, pass, P.bins, P.low_bits, P.pre_bits, num_nodes,
+                                                    num_edges, rowptr, col, perm, keys_out, hub_thr, 1024, hub_entries,
+                                                    hub_count);
+    } else {
+      k_plan_buckets<16, false><<<bgrid, 16 * 64, P.bucket_lds, stream>>>(recs, nullptr, ctl, pass, P.bins, P.low_bits, 0,
+                                                                         num_nodes, num_edges, rowptr, col, perm,
+                                                                         nullptr, hub_thr, 1024, hub_entries, hub_count);
+    }
+    PTGNN_LAUNCH_CHECK();
+    if (keys_out) {
+      const int64_t blocks = (num_edges + 255) / 256;
+      k_rowptr_from_keys<<<(unsigned)blocks, 256, 0, stream>>>(keys_out, num_edges, num_nodes, rowptr);
+      PTGNN_LAUNCH_CHECK();
+      if (hubs && num_edges > hub_threshold) {
+        const int64_t hb = (num_nodes + 255) / 256;
+        k_hub_list<<<(unsigned)(hb < 2048 ? hb : 2048), 256, 0, stream>>>(rowptr, num_nodes, hub_threshold, 1024,
+                                                                          hub_entries, hub_count);
+        PTGNN_LAUNCH_CHECK();
+      }
     }
   }
   if (max_degree) {
     PTGNN_HIP(hipMemsetAsync(max_degree, 0, sizeof(int32_t), stream));
-    if (num_edges > 0 && num_nodes > 0) {
-      const int64_t mb = (num_nodes + 255) / 256;
-      k_max_degree<<<(unsigned)(mb < 1024 ? mb : 1024), 256, 0, stream>>>(rowptr, num_nodes, max_degree);
-      PTGNN_LAUNCH_CHECK();
-    }
+    const int64_t mb = (num_nodes + 255) / 256;
+    k_max_degree<<<(unsigned)(mb < 1024 ? mb : 1024), 256, 0, stream>>>(rowptr, num_nodes, max_degree);
+    PTGNN_LAUNCH_CHECK();
   }
   return PTGNN_AMD_OK;
 }
