@@ -330,8 +330,7 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
         gru = self.__state_update
         p = self.__dropout.p if self.training else 0.0
         ws = [l.weight for l in self.__edge_message_transformation_layers]
-        table_rows = shard.n_local + (shard.n_halo if T * M > H else 0)
-        edge_form = _prefer_edge_path(shard.num_edges, table_rows, T, H, M)
+        edge_form = _prefer_edge_path(*shard.form_sizes(T * M > H), T, H, M)   # one decision for the whole group
         if not self._fused_ok(node_states, feats):
             # training.  Edge form: differentiable halo exchange (backward = transposed all-to-all + HIP
             # segment-sum) -> grouped per-edge GEMM node with the hash dropout folded in -> HIP segment reduce
@@ -526,8 +525,7 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
                                      "transforms without edge features")
         use_dst = self.__use_target_state_as_message_input
         ws = [m.linears[0].weight for m in self.__edge_message_transformation_layers]
-        table_rows = shard.n_local + (shard.n_halo if T * M > H else 0)
-        edge_form = _prefer_edge_path(shard.num_edges, table_rows, T, H, M)
+        edge_form = _prefer_edge_path(*shard.form_sizes(T * M > H), T, H, M)   # one decision for the whole group
         if not self._fused_ok(node_states, feats):
             if edge_form and _edge_training_ok(H, M):
                 table = shard.exchange_autograd(node_states)

@@ -71,6 +71,35 @@ def balanced_node_ranges(in_degree: torch.Tensor, world: int) -> List[Tuple[int,
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
+def ranges_on_graph_boundaries(node_to_graph_idx: torch.Tensor, in_degree: torch.Tensor, world: int
+                               ) -> List[Tuple[int, int]]:
+    """Contiguous node ranges with ~equal in-edge mass whose cuts are SNAPPED TO GRAPH STARTS ("choose
+    boundaries on graph boundaries via node_to_graph_idx when possible").  A ptgnn minibatch is a disjoint union whose
+    graphs occupy contiguous id ranges (graphneuralnetwork.py:418-423, 440-443), so such a partition cuts no edge: the
+    per-layer halo exchange and its bookkeeping disappear (`ShardedGraph.build(..., assume_no_cut=True)`).  Every cut
+    goes to the graph start nearest (in mass) to the ideal split point; with fewer graphs than ranks the surplus
+    ranks get empty ranges.  `node_to_graph_idx` must be non-decreasing (the batcher's layout)."""
+    n = int(node_to_graph_idx.shape[0])
+    if n == 0:
+        return [(0, 0)] * world
+    g = node_to_graph_idx.to(torch.int64).cpu()
+    if bool((g[1:] < g[:-1]).any()):
+        raise ValueError("ranges_on_graph_boundaries: node_to_graph_idx must be sorted (graphs contiguous)")
+    w = (in_degree.to(torch.float64).cpu() + 1.0)
+    c = torch.cumsum(w, 0)
+    total = float(c[-1])
+    first = torch.ones(n, dtype=torch.bool)
+    first[1:] = g[1:] != g[:-1]
+    starts = torch.nonzero(first).flatten()                    # node id where each graph starts
+    mass_before = torch.cat([torch.zeros(1, dtype=torch.float64), c])[starts]   # edge mass in front of each graph
+    cuts = [0]
+    for p in range(1, world):
+        j = int(torch.argmin((mass_before - total * p / world).abs()))
+        cuts.append(max(int(starts[j]), cuts[-1]))
+    cuts.append(n)
+    return [(cuts[i], cuts[i + 1]) for i in range(world)]
+
+
 class ShardedGraph:
     """Per-rank view of a dst-range-sharded minibatch."""
 
@@ -88,6 +117,10 @@ class ShardedGraph:
         self._plan: Optional["ops.GraphPlan"] = None
         self.group = None
         self.no_cut = False    # True when NO rank has a remote source: the exchange is skipped entirely
+        # sums over ALL ranks of (edges, own rows, halo rows): what the layers' edge-form / table-form choice is made
+        # from.  The form fixes WHAT travels in the halo all-to-all (node states or message-table rows), so it must
+        # be one decision for the whole group, not one per rank from its own shard sizes
+        self.global_stats: Tuple[int, int, int] = (0, 0, 0)
         # global-exchange layers (globalgraphexchange.py): graph id of every OWN node (global graph ids) and the
         # number of graphs of the whole batch; set by the caller (`attach_graph_index`)
         self.node_to_graph_idx: Optional[torch.Tensor] = None
@@ -106,7 +139,7 @@ class ShardedGraph:
     @staticmethod
     def build(adjacency_lists: Adj, node_range: Tuple[int, int], group=None,
               build_plan: bool = True, all_ranges: Optional[Sequence[Tuple[int, int]]] = None,
-              overlap: Optional[bool] = None) -> "ShardedGraph":
+              overlap: Optional[bool] = None, assume_no_cut: bool = False) -> "ShardedGraph":
         """adjacency_lists: int64 (src, dst) per edge type in GLOBAL node ids, holding exactly the
         edges whose dst lies in this rank's `node_range`.  `all_ranges` (every rank's range, in rank
         order) skips the all-gather when the partition is static.  `overlap` (default: env
@@ -120,6 +153,29 @@ class ShardedGraph:
         g.lo, g.hi = int(node_range[0]), int(node_range[1])
         g.n_local = g.hi - g.lo
         dev = adjacency_lists[0][0].device
+        if assume_no_cut:
+            # The caller partitioned on graph boundaries (`ranges_on_graph_boundaries`): no edge crosses a rank, so
+            # there is nothing to detect, exchange or read back -- no collective, no host synchronisation, no pass
+            # over the global id space; the plan build's range guard still flags a source outside the own rows
+            # (ptgnn_amd.ops.check_indices), i.e. a broken promise cannot go unnoticed.  EVERY rank must pass it.
+            if all_ranges is not None:
+                g.set_bounds(all_ranges, dev)
+            g.no_cut = True
+            g.n_halo = 0
+            g.need_ids = torch.zeros(0, dtype=torch.int64, device=dev)
+            g.send_ids = g.need_ids
+            g.send_splits = [0] * g.world
+            g.recv_splits = [0] * g.world
+            if g.lo == 0:
+                g.local_adj = [(s_, d_) for s_, d_ in adjacency_lists]
+            else:            # two launches over the concatenated lists instead of two per edge type
+                src, dst, counts = _flatten(adjacency_lists)
+                g.local_adj = _unflatten(src - g.lo, dst - g.lo, counts)
+            g.global_stats = (0, 0, 0)      # no exchange: the form may differ per rank without harm
+            g._flat = g._slot = g._mark = None
+            if build_plan:
+                g.build_plan()
+            return g
         if all_ranges is None:   # every rank learns all range boundaries
             mine = _to_device_ints([g.lo, g.hi], dev)
             allr = [torch.empty_like(mine) for _ in range(g.world)]
@@ -136,14 +192,20 @@ class ShardedGraph:
         if src.numel():
             lo_s, hi_s = torch.aminmax(src)
             flag = ((lo_s < g.lo) | (hi_s >= g.hi)).to(torch.int64).reshape(1)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
         need_counts = g.index_locally(adjacency_lists, (src, dst, counts))   # device int64 [world], no host sync yet
+        # ONE small all-reduce: the cut flag and the group-wide (edges, own rows, halo rows) the layers choose their
+        # form from -- a per-rank choice would make ranks disagree on what the halo all-to-all carries
+        stats = torch.cat([flag, torch.tensor([int(src.numel()), g.n_local], dtype=torch.int64, device=dev),
+                           need_counts.sum().reshape(1)])
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
         got_counts = torch.empty_like(need_counts)
         dist.all_to_all_single(got_counts, need_counts, group=group)
-        # ONE host read-back per minibatch: the no-cut flag, the split sizes all_to_all_single wants as host ints
+        # ONE host read-back per minibatch: the flag + stats, the split sizes all_to_all_single wants as host ints
         # and (two-block mode) the per-type own-source edge counts
         extra = [g.own_source_counts()] if overlap else []
-        both = torch.cat([flag, need_counts, got_counts] + extra).tolist()
+        both = torch.cat([stats, need_counts, got_counts] + extra).tolist()
+        g.global_stats = (int(both[1]), int(both[2]), int(both[3]))
+        both = [both[0]] + both[4:]
         if int(both[0]) == 0:
             g.no_cut = True
             g.n_halo = 0
@@ -288,6 +350,8 @@ class ShardedGraph:
         """Start the halo all-to-all into table[n_local:] (table[:n_local] holds this rank's rows) and return the
         work handle; `wait()` on it orders the CURRENT stream behind the arrival -- kernels launched in between
         (the own-source block) run while the rows travel over xGMI."""
+        if self.no_cut:
+            return None
         own = table[: self.n_local]
         send = ops.gather_rows(own, self.send_ids) if own.is_cuda else own.index_select(0, self.send_ids)
         return dist.all_to_all_single(table[self.n_local:], send, self.recv_splits, self.send_splits,
@@ -307,6 +371,7 @@ class ShardedGraph:
         g.set_bounds(all_ranges, adjacency_lists[0][0].device)
         g.recv_splits = [int(v) for v in g.index_locally(adjacency_lists).tolist()]
         g.n_halo = sum(g.recv_splits)
+        g.global_stats = (sum(int(a[0].shape[0]) for a in adjacency_lists), g.n_local, g.n_halo)
         g.no_cut = False
         g.finish_local_index()
         g.send_splits = [0] * g.world
@@ -334,12 +399,22 @@ class ShardedGraph:
     def num_edges(self) -> int:
         return sum(int(a[0].shape[0]) for a in self.local_adj)
 
+    def form_sizes(self, rows_travel_as_states: bool) -> Tuple[int, int]:
+        """(edges, table rows) the edge-form / table-form choice of a layer is made from: group-wide sums when the
+        shard exchanges halo rows (one decision for all ranks), this rank's own sizes when nothing travels."""
+        if self.no_cut or self.global_stats[1] == 0:
+            return self.num_edges, self.n_local + (self.n_halo if rows_travel_as_states else 0)
+        e, own, halo = self.global_stats
+        return e, own + (halo if rows_travel_as_states else 0)
+
     # -- per-layer exchange -----------------------------------------------------------------------
     def new_table(self, dim: int, like: torch.Tensor) -> torch.Tensor:
         return torch.empty(self.n_local + self.n_halo, dim, dtype=like.dtype, device=like.device)
 
     def exchange_into(self, table: torch.Tensor) -> torch.Tensor:
         """table[:n_local] holds this rank's rows; fills table[n_local:] with the halo rows."""
+        if self.no_cut:      # agreed on by every rank at build time: nobody enters the collective
+            return table
         own = table[: self.n_local]
         if own.is_cuda:
             send = ops.gather_rows(own, self.send_ids)
@@ -350,6 +425,8 @@ class ShardedGraph:
         return table
 
     def exchange(self, rows_local: torch.Tensor) -> torch.Tensor:
+        if self.no_cut:      # the local table IS the own rows
+            return rows_local
         table = self.new_table(rows_local.shape[1], rows_local)
         table[: self.n_local].copy_(rows_local)
         return self.exchange_into(table)
@@ -358,6 +435,8 @@ class ShardedGraph:
         """Differentiable `exchange`: backward is the transposed exchange -- the halo rows'
         gradients travel back to their owners over the same all-to-all with the splits swapped and are
         segment-summed onto the owners' rows (a row sent to several peers collects all of them)."""
+        if self.no_cut:      # nothing travels in either direction
+            return rows_local
         return _HaloExchange.apply(rows_local, self)
 
     def _send_plan(self):

@@ -431,3 +431,80 @@ def test_two_block_split_async_exchange_and_combine_plan_over_gloo():
     for r in results:
         assert r[1] == "ok", r[1]
     assert all(r[2] > 0 for r in results)
+
+
+# ------------------------------------------------------------------------------------------------
+# graph-boundary partitions and the group-wide form decision
+# ------------------------------------------------------------------------------------------------
+def test_ranges_on_graph_boundaries_snap_to_graph_starts_and_cut_no_edge():
+    """cuts on graph boundaries (graphneuralnetwork.py:418-423 keeps a graph's ids contiguous) => a
+    disjoint-union batch has no cut edge; the cfg4-shaped batch is balanced within one graph's mass."""
+    from ptgnn_amd import sharded, workloads
+    mb = workloads.batched_graphs(40, 2000, 10, 2.4, seed=21)          # the cfg4 batch of bench.py
+    n, n2g = mb["num_nodes"], mb["node_to_graph_idx"]
+    adj = list(mb["adjacency_lists"])
+    adj = adj + [(d, s) for s, d in adj] + [(torch.arange(n), torch.arange(n))]
+    indeg = torch.zeros(n, dtype=torch.int64)
+    for _, d in adj:
+        indeg += torch.bincount(d, minlength=n)
+    for world in (2, 3, 4, 8):
+        ranges = sharded.ranges_on_graph_boundaries(n2g, indeg, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == n and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        for lo, hi in ranges[1:]:
+            assert lo == n or n2g[lo] != n2g[lo - 1], "a cut inside a graph"
+        for lo, hi in ranges:                                           # no edge crosses a rank
+            for s, d in adj:
+                m = (d >= lo) & (d < hi)
+                assert bool(((s[m] >= lo) & (s[m] < hi)).all())
+        mass = [float((indeg[lo:hi] + 1).sum()) for lo, hi in ranges]
+        biggest_graph = max(float((indeg[n2g == g] + 1).sum()) for g in range(int(n2g.max()) + 1))
+        assert max(mass) - min(mass) <= 2 * biggest_graph
+    # fewer graphs than ranks: surplus ranks own nothing, nothing breaks
+    few = sharded.ranges_on_graph_boundaries(torch.tensor([0, 0, 1, 1, 1]), torch.ones(5, dtype=torch.int64), 4)
+    assert few[0][0] == 0 and few[-1][1] == 5 and all(a[1] == b[0] for a, b in zip(few, few[1:]))
+    with pytest.raises(ValueError):
+        sharded.ranges_on_graph_boundaries(torch.tensor([1, 0]), torch.ones(2, dtype=torch.int64), 2)
+
+
+def _worker_form(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ptgnn_amd import layers as L, sharded
+        # unbalanced shards around the edge-path threshold: rank 0 owns few nodes with many in-edges, rank 1 many
+        # nodes with few -- a per-rank decision (the round-2 code) lands on different sides of E * 1.25 < N * T
+        n, T, H, M = 4000, 4, 64, 16                                    # T * M == H: the payload width cannot tell
+        ranges = [(0, 400), (400, n)]
+        lo, hi = ranges[rank]
+        g = torch.Generator().manual_seed(7 + rank)
+        per_type = 8000 if rank == 0 else 300
+        adj = [(torch.randint(0, n, (per_type,), generator=g), torch.randint(lo, hi, (per_type,), generator=g))
+               for _ in range(T)]
+        shard = sharded.ShardedGraph.build(adj, (lo, hi), all_ranges=ranges, build_plan=False)
+        own_view = L._prefer_edge_path(shard.num_edges, shard.n_local + shard.n_halo, T, H, M)
+        group_view = L._prefer_edge_path(*shard.form_sizes(True), T, H, M)
+        # a snapped partition: no collective, no read-back, local ids
+        adj2 = [(torch.randint(lo, hi, (50,), generator=g), torch.randint(lo, hi, (50,), generator=g))]
+        sh2 = sharded.ShardedGraph.build(adj2, (lo, hi), all_ranges=ranges, build_plan=False, assume_no_cut=True)
+        ok2 = (sh2.no_cut and sh2.n_halo == 0 and int(sh2.local_adj[0][0].min()) >= 0
+               and int(sh2.local_adj[0][0].max()) < hi - lo and sh2.exchange(torch.ones(hi - lo, 3)).shape[0] == hi - lo)
+        out_q.put((rank, own_view, group_view, shard.global_stats, ok2))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_layer_form_is_one_decision_for_the_group():
+    """edge form vs table form fixes what the halo all-to-all carries, so ranks must agree."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_form, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p_ in procs:
+        p_.join(timeout=60)
+    assert res[0][1] != res[1][1], "the test shards are meant to disagree when each rank decides alone"
+    assert res[0][2] == res[1][2], "group-wide sizes give one decision"
+    assert res[0][3] == res[1][3] and res[0][3][0] == 4 * 8000 + 4 * 300 and res[0][3][1] == 4000
+    assert res[0][4] and res[1][4]

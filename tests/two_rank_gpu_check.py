@@ -168,12 +168,52 @@ def case_training(rank, world):
         _ok(rank, f"{name} rel_err={worst:.2e}")
 
 
+def case_graph_boundaries(rank, world):
+    """The cfg4-shaped stack over a partition SNAPPED TO GRAPH STARTS (sharded.ranges_on_graph_boundaries): the
+    build finds no cut edge (one all-reduce), `assume_no_cut=True` skips even that (no collective, no read-back),
+    and both give the unsharded rows bit for bit -- no halo, no exchange, the single-GPU kernels per rank."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, ops, sharded, workloads
+    H = 64
+    L.EDGE_PATH_BIAS = 1.25
+    mb = workloads.batched_graphs(9, 500, 5, 2.4, seed=61)
+    n, n2g = mb["num_nodes"], mb["node_to_graph_idx"]
+    adj = O.augment_adjacency(mb["adjacency_lists"], n, True, True)
+    T = len(adj)
+    torch.manual_seed(62)
+    r1 = L.ConcatResidualLayer(H)
+    mods = [r1.pass_through_dummy_layer(), L.MlpMessagePassingLayer(H, H, H, T, "max"),
+            L.MlpMessagePassingLayer(H, H, H, T, "max"), r1, L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, "max")]
+    mods = [m.cuda().eval() for m in mods]
+    x = workloads.node_states(n, H, seed=63).cuda()
+    cadj = _cuda_adj(adj)
+    ops.clear_plan_cache()
+    with torch.no_grad(), L.forward_scope():
+        want = x
+        for m in mods:
+            want = m(want, cadj, n2g.cuda(), {}, {}, [None] * T)
+    indeg = torch.zeros(n, dtype=torch.int64)
+    for _, d in adj:
+        indeg += torch.bincount(d, minlength=n)
+    ranges = sharded.ranges_on_graph_boundaries(n2g, indeg, world)
+    lo, hi = ranges[rank]
+    for assume in (False, True):
+        shard = sharded.ShardedGraph.build(_mine(adj, lo, hi), (lo, hi), all_ranges=ranges, assume_no_cut=assume)
+        assert shard.no_cut and shard.n_halo == 0
+        shard.attach_graph_index(n2g[lo:hi].cuda(), mb["num_graphs"])
+        with torch.no_grad():
+            got = sharded.run_stack(mods, x[lo:hi].contiguous(), shard)
+        np.testing.assert_array_equal(got.cpu().numpy(), want[lo:hi].cpu().numpy())
+        _ok(rank, f"graph_boundary_partition{'_assumed' if assume else '_detected'}")
+    ops.check_indices(sync=True)     # the range guard saw no source outside the own rows
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        for case in (case_layers, case_stack, case_training):
+        for case in (case_layers, case_stack, case_training, case_graph_boundaries):
             case(rank, world)
             dist.barrier()
     finally:
