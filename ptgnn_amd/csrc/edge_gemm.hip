@@ -246,8 +246,8 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
   hipStream_t st = (hipStream_t)stream_;
   int64_t row_base = 0;
   // streaming core (stream_gemm.hip): inference / no-dropout shapes it tiles
-  const bool streaming = dropout_mode == 0 && stream_edge_supported(state_dim, msg_dim, use_dst) &&
-                         ld_x % 4 == 0 && aligned16(x);
+  bool streaming = dropout_mode == 0 && stream_edge_supported(state_dim, msg_dim, use_dst) &&
+                   ld_x % 4 == 0 && aligned16(x);
   for (int t0 = 0; streaming && t0 < num_types; t0 += kStreamMaxTypes) {
     StreamEdgeTable tab;
     tab.num_types = (num_types - t0 < kStreamMaxTypes) ? (num_types - t0) : kStreamMaxTypes;
@@ -269,8 +269,13 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
       PTGNN_REQUIRE(units < ((int64_t)1 << 30), PTGNN_AMD_EUNSUPPORTED, "edge_linear: too many units");
       tab.unit_off[t + 1] = (int32_t)units;
     }
-    PTGNN_REQUIRE(stream_edge(tab, x, ld_x, num_rows, state_dim, use_dst, msg_dim, act, msg, ld_msg, row_base, st) == 1,
-                  PTGNN_AMD_EHIP, "edge_linear: streaming launch failed");
+    if (stream_edge(tab, x, ld_x, num_rows, state_dim, use_dst, msg_dim, act, msg, ld_msg, row_base, st) != 1) {
+      // "not taken" (the dynamic-LDS attribute was refused, e.g. a first use inside a graph capture): like
+      // stream_linear / stream_gru, fall through to the tile kernel, which recomputes every type chunk
+      streaming = false;
+      row_base = 0;
+      break;
+    }
     PTGNN_LAUNCH_CHECK();
     row_base += tab.edge_off[tab.num_types];
   }

@@ -712,17 +712,20 @@ bool debug_on() {
   return v == 1;
 }
 
-// Raise a kernel's dynamic-LDS limit once per (kernel, size): the attribute call is not legal while a
+// Raise a kernel's dynamic-LDS limit once per (kernel, device, size): the attribute call is not legal while a
 // stream is being captured into a hipGraph, and the warm-up launch outside the capture has made it.
 template <typename Kern>
 bool set_lds(Kern kern, size_t bytes) {
   static std::mutex mu;
-  static std::unordered_map<const void *, size_t> done;
-  const void *key = reinterpret_cast<const void *>(kern);
+  static std::unordered_map<uint64_t, size_t> done;     // (kernel, device): the attribute is per device
+  const void *fn = reinterpret_cast<const void *>(kern);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t key = (uint64_t)(uintptr_t)fn * 64u + (uint64_t)dev;
   std::lock_guard<std::mutex> lock(mu);
   auto it = done.find(key);
   if (it != done.end() && it->second >= bytes) return true;
-  const hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     if (debug_on()) fprintf(stderr, "[ptgnn_amd] stream kernel: %zu B of LDS refused (%s) -> tile kernel\n", bytes, hipGetErrorString(e));

@@ -28,6 +28,25 @@ def _pad4(t: torch.Tensor) -> torch.Tensor:
     return t if extra == 0 and t.stride(0) % 4 == 0 else torch.nn.functional.pad(t, (0, extra)).contiguous()
 
 
+_WT_CACHE = {}   # id(weight) -> (weakref, version, transposed copy)
+
+
+def _transposed(weight: torch.Tensor) -> torch.Tensor:
+    """`weight.t().contiguous()` for the input-gradient GEMMs, kept per (tensor, version): a tied layer (the Typilus
+    stack applies one GGNN layer seven times) transposes its GRU / Linear weights once per backward pass instead of
+    once per use; an optimizer step bumps the version, so a stale copy can never be used."""
+    import weakref
+    key = id(weight)
+    hit = _WT_CACHE.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        return hit[2]
+    wt = weight.detach().t().contiguous()
+    if len(_WT_CACHE) > 64:
+        _WT_CACHE.clear()
+    _WT_CACHE[key] = (weakref.ref(weight), weight._version, wt)
+    return wt
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T (+ b);  d x = g W,  d W = g^T x (split-row kernel),  d b = column sums of g."""
 
@@ -43,7 +62,7 @@ class _Linear(torch.autograd.Function):
         g = g.contiguous()
         d_x = d_w = d_b = None
         if ctx.needs_input_grad[0]:
-            d_x = ops.linear(g, weight.detach().t().contiguous())
+            d_x = ops.linear(g, _transposed(weight))
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             n_out, k = weight.shape
@@ -83,8 +102,8 @@ class _GruCell(torch.autograd.Function):
         a, h, w_ih, w_hh, gates = ctx.saved_tensors
         d_gi, d_gh, d_h = ops.gru_gates_backward(g.contiguous(), gates, h)
         need = ctx.needs_input_grad
-        d_a = ops.linear(d_gi, w_ih.detach().t().contiguous()) if need[0] else None
-        d_hx = d_h + ops.linear(d_gh, w_hh.detach().t().contiguous()) if need[1] else None
+        d_a = ops.linear(d_gi, _transposed(w_ih)) if need[0] else None
+        d_hx = d_h + ops.linear(d_gh, _transposed(w_hh)) if need[1] else None
         d_wih = d_bih = d_whh = d_bhh = None
         if need[2] or need[4]:
             d_wih, d_bih = ops.linear_weight_grad(a, d_gi, want_bias=True)
@@ -98,16 +117,23 @@ def gru_cell(cell: torch.nn.GRUCell, a: torch.Tensor, h: torch.Tensor) -> torch.
     if not (_kernel_dims_ok(a, cell.weight_ih) and _kernel_dims_ok(h, cell.weight_hh)):
         raise _lib.PtgnnAmdError(f"dense.gru_cell needs 2-D float32 CUDA matrices (got {a.dtype} / {h.dtype} on "
                                  f"{a.device}); AMP dtypes are up-cast by the layers")
-    if not cell.bias:
-        raise _lib.PtgnnAmdError("dense.gru_cell: nn.GRUCell(bias=False) is not a reference configuration")
-    needs_grad = torch.is_grad_enabled() and any(
-        t.requires_grad for t in (a, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh))
-    if not needs_grad:
+    params = [cell.weight_ih, cell.weight_hh] + ([cell.bias_ih, cell.bias_hh] if cell.bias else [])
+    needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in [a, h] + params)
+    if cell.bias and not needs_grad:
         return ops.gru_cell(a, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
-    if h.shape[1] % 4 != 0 or a.shape[1] % 4 != 0:
-        raise _lib.PtgnnAmdError("dense.gru_cell: training needs state and message widths that are multiples of 4 "
-                                 f"(got {a.shape[1]}, {h.shape[1]})")
-    return _GruCell.apply(a, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+    if cell.bias and h.shape[1] % 4 == 0 and a.shape[1] % 4 == 0:
+        return _GruCell.apply(a, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+    # Shapes the fused cell does not tile (nn.GRUCell(bias=False); training with a state / message width that is
+    # not a multiple of 4): the reference accepts them (gatedmessagepassing.py:25), so they run as the two gate
+    # GEMMs on the differentiable HIP Linear (any width) + torch's elementwise gate math -- same arithmetic, on
+    # the GPU, no vendor BLAS.
+    hd = h.shape[1]
+    gi = linear(a, cell.weight_ih, cell.bias_ih if cell.bias else None)
+    gh = linear(h, cell.weight_hh, cell.bias_hh if cell.bias else None)
+    r = torch.sigmoid(gi[:, :hd] + gh[:, :hd])
+    z = torch.sigmoid(gi[:, hd:2 * hd] + gh[:, hd:2 * hd])
+    n = torch.tanh(gi[:, 2 * hd:] + r * gh[:, 2 * hd:])
+    return (1.0 - z) * n + z * h
 
 
 class _RowEpilogue(torch.autograd.Function):

@@ -104,6 +104,13 @@ class GraphNeuralNetwork(ModuleWithMetrics):
         self.__num_graphs, self.__num_edges, self.__num_nodes = 0, 0, 0
 
     def _module_metrics(self) -> Dict[str, Any]:
+        # A natural synchronisation point (the trainer reads the metrics at the end of an epoch / evaluation,
+        # trainer.py:236): surface node ids that were out of range in ANY minibatch since the last check -- with
+        # the default PTGNN_AMD_VALIDATE=async a bad id in the last minibatch, or in an inference-only call, would
+        # otherwise never be reported (the reference device-asserts at once; "sync" reproduces that per build)
+        if torch.cuda.is_available():
+            from ptgnn_amd import ops
+            ops.check_indices(sync=True)
         return {"num_graphs": int(self.__num_graphs), "num_nodes": int(self.__num_nodes),
                 "num_edges": int(self.__num_edges)}
 

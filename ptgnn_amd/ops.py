@@ -283,9 +283,11 @@ def check_indices(device=None, sync: bool = False) -> None:
 
 def _post_plan_readback(st) -> None:
     if st["event"] is None:   # one read-back in flight at a time
-        st["host"].copy_(st["dev"], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        dev = st["dev"].device
+        with torch.cuda.device(dev):     # the copy and its event belong to the stream of the plan's device
+            st["host"].copy_(st["dev"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
         st["event"] = ev
 
 

@@ -195,8 +195,7 @@ class ShardedGraph:
         need_counts = g.index_locally(adjacency_lists, (src, dst, counts))   # device int64 [world], no host sync yet
         # ONE small all-reduce: the cut flag and the group-wide (edges, own rows, halo rows) the layers choose their
         # form from -- a per-rank choice would make ranks disagree on what the halo all-to-all carries
-        stats = torch.cat([flag, torch.tensor([int(src.numel()), g.n_local], dtype=torch.int64, device=dev),
-                           need_counts.sum().reshape(1)])
+        stats = torch.cat([flag, _to_device_ints([int(src.numel()), g.n_local], dev), need_counts.sum().reshape(1)])
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
         got_counts = torch.empty_like(need_counts)
         dist.all_to_all_single(got_counts, need_counts, group=group)

@@ -12,3 +12,5 @@ timeout 1500 python -m pytest tests -q -m gpu -x > $out/pytest.log 2>&1
 echo "pytest rc=$?" >> $out/pytest.log; tail -8 $out/pytest.log
 timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
 echo "bench rc=$?"; tail -3 $out/bench.err
+timeout 600 python bench.py --sharded-variants --no-cpu-baseline --no-secondary > $out/bench_sharded.json 2> $out/bench_sharded.err
+echo "bench sharded rc=$?"; tail -3 $out/bench_sharded.err

@@ -1910,9 +1910,27 @@ def test_odd_widths_and_general_path_run_on_the_hip_kernels(monkeypatch):
     assert float((w.grad.cpu().double() - gy.cpu().double().t() @ inp_c).abs().max()) <= 1e-4
     assert float((b.grad.cpu().double() - gy.cpu().double().sum(0)).abs().max()) <= 1e-4
     assert float((xi.grad.cpu().double() - (gy.cpu().double() @ w.detach().cpu().double())[:, :H]).abs().max()) <= 1e-4
-    with pytest.raises(Exception, match="multiples of 4"):
-        cell = torch.nn.GRUCell(M, H).cuda()
-        dense.gru_cell(cell, torch.randn(n, M, device="cuda", requires_grad=True), x.cuda())
+    # the GRU cell in TRAINING with odd widths, and nn.GRUCell(bias=False): the reference accepts both
+    # (gatedmessagepassing.py:25); here the two gate GEMMs run on the differentiable HIP Linear + torch's elementwise
+    # gate math -- outputs and gradients vs torch's own GRUCell in float64 on the CPU
+    for bias in (True, False):
+        torch.manual_seed(17)
+        cell = torch.nn.GRUCell(M, H, bias=bias)
+        ref = torch.nn.GRUCell(M, H, bias=bias).double()
+        ref.load_state_dict({k: v.double() for k, v in cell.state_dict().items()})
+        a0, h0 = torch.randn(n, M, generator=g), x.clone()
+        ar, hr = a0.double().requires_grad_(True), h0.double().requires_grad_(True)
+        gout = torch.randn(n, H, generator=g)
+        real_gru(ref, ar, hr).backward(gout.double())
+        cell = cell.cuda()
+        ac, hc = a0.cuda().requires_grad_(True), h0.cuda().requires_grad_(True)
+        out = dense.gru_cell(cell, ac, hc)
+        out.backward(gout.cuda())
+        with torch.no_grad():
+            assert float((out.cpu().double() - real_gru(ref, ar, hr)).abs().max()) <= TOL
+        assert float((ac.grad.cpu().double() - ar.grad).abs().max()) <= 1e-4
+        assert float((hc.grad.cpu().double() - hr.grad).abs().max()) <= 1e-4
+        assert float((cell.weight_ih.grad.cpu().double() - ref.weight_ih.grad).abs().max()) <= 1e-3
     assert calls == [], calls
 
 
