@@ -266,14 +266,15 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_count(TypeTable tab, So
 
 // Aggregate table: per-tile digit counts -> exclusive prefix over the tiles, in place (column-wise scan of
 // [ntiles][bp]).  Round 2 had every scatter workgroup add up the rows of all earlier tiles itself: quadratic in the
-// tile count, and up to nine dependent L2 round trips in the prologue of the late tiles.  One workgroup per 8
-// digits; thread (g, c) owns the rows [g R, (g+1) R) of column c.
-constexpr int kScanCols = 8;
+// tile count, and up to nine dependent L2 round trips in the prologue of the late tiles.  One workgroup per 2
+// digits (64-256 workgroups); thread (g, c) owns the rows [g R, (g+1) R) of column c.
+constexpr int kScanCols = 2;
 __global__ __launch_bounds__(1024) void k_tile_scan(int32_t *__restrict__ agg, int ntiles, int bp,
                                                     int32_t *__restrict__ totals /* [bp] column sums */) {
-  constexpr int G = 1024 / kScanCols;
-  __shared__ int part[G][kScanCols];
-  const int c = threadIdx.x % kScanCols, g = threadIdx.x / kScanCols;
+  constexpr int G = 1024 / kScanCols;             // row groups per column = 8 waves of consecutive threads
+  __shared__ int wtot[16];
+  const int c = threadIdx.x / G, g = threadIdx.x % G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * kScanCols + c;
   const int R = (ntiles + G - 1) / G;
   const int r0 = g * R, r1 = r0 + R < ntiles ? r0 + R : ntiles;
@@ -287,20 +288,21 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int32_t *__restrict__ agg, i
       for (int u = 0; u < 8; ++u) sum += v[u];
     }
   }
-  part[g][c] = sum;
-  __syncthreads();
-  if (g == 0) {   // 8 threads: serial exclusive prefix over the 128 row groups of their column
-    int run = 0;
-    for (int i = 0; i < G; ++i) {
-      const int t = part[i][c];
-      part[i][c] = run;
-      run += t;
-    }
-    if (col < bp) totals[col] = run;
+  // exclusive scan of the group sums along the column: within the wave by shuffles, across the column's 8 waves
+  // through LDS
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
   }
+  if (lane == 63) wtot[wave] = inc;
   __syncthreads();
+  constexpr int WPC = G / 64;                     // waves per column
+  int run = inc - sum;
+  for (int w = c * WPC; w < wave; ++w) run += wtot[w];
+  if (g == G - 1 && col < bp) totals[col] = run + sum;
   if (col < bp) {
-    int run = part[g][c];
     for (int r = r0; r < r1; r += 8) {
       int v[8];
 #pragma unroll

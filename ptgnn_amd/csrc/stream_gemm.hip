@@ -462,6 +462,52 @@ __device__ __forceinline__ float fast_sigmoid(float v) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 
+// Epilogue of one GRU unit (32 rows x 32 features), per row group of 8 rows: previous state in as one dwordx4 per
+// lane (8 rows x 128 B of the h tile), un-transposed through the wave's slab into the C layout; gate math per lane;
+// h' (and, in training, the gates) back through the slab as dwordx4 stores.  No mul+add contraction in the gate
+// math: a row's result must not depend on which slot of the lane it occupies (sharded == unsharded bit for bit).
+__device__ __forceinline__ void gru_epilogue(const GruArgs &p, const f32x16 (&acc)[4], float *tq, int64_t row0,
+                                             int j0, int lane, int li, int hi, float bir, float biz, float bin,
+                                             float bhr, float bhz, float bhn) {
+  const int trow = lane >> 3, tcol = (lane & 7) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int64_t hrow = row0 + 8 * q + trow;
+    const bool rvalid = hrow < p.n;
+    hrow = rvalid ? hrow : p.n - 1;
+    float hp[4];
+    tq_untranspose(tq, lane, li, hi, *reinterpret_cast<const float4 *>(p.h + hrow * p.ld_h + j0 + tcol), hp);
+    float res[4], rg[4], zg[4], ng[4], hn[4];
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * q + i;
+        rg[i] = fast_sigmoid((acc[0][r] + bir) + bhr);
+        zg[i] = fast_sigmoid((acc[1][r] + biz) + bhz);
+        hn[i] = acc[3][r] + bhn;
+        ng[i] = fast_tanh((acc[2][r] + bin) + rg[i] * hn[i]);
+        res[i] = (1.0f - zg[i]) * ng[i] + zg[i] * hp[i];
+      }
+    }
+    const float4 o = tq_transpose(tq, lane, li, hi, res[0], res[1], res[2], res[3]);
+    if (rvalid) *reinterpret_cast<float4 *>(p.out + hrow * p.ld_out + j0 + tcol) = o;
+    if (p.gates) {   // training: r, z, n, gh_n for the backward ([n, 4H], gate-major)
+      float *gp = p.gates + hrow * (int64_t)(4 * p.H) + j0 + tcol;
+      const float4 o_r = tq_transpose(tq, lane, li, hi, rg[0], rg[1], rg[2], rg[3]);
+      const float4 o_z = tq_transpose(tq, lane, li, hi, zg[0], zg[1], zg[2], zg[3]);
+      const float4 o_n = tq_transpose(tq, lane, li, hi, ng[0], ng[1], ng[2], ng[3]);
+      const float4 o_h = tq_transpose(tq, lane, li, hi, hn[0], hn[1], hn[2], hn[3]);
+      if (rvalid) {
+        *reinterpret_cast<float4 *>(gp) = o_r;
+        *reinterpret_cast<float4 *>(gp + p.H) = o_z;
+        *reinterpret_cast<float4 *>(gp + 2 * p.H) = o_n;
+        *reinterpret_cast<float4 *>(gp + 3 * p.H) = o_h;
+      }
+    }
+  }
+}
+
 template <bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -530,54 +576,139 @@ __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
     const int nn = claim_unit(counter);
     unit_fence();
     unit_kloop<3, 4, true, SPLIT>(acc, a0, a1, smem, sl, li, hi, rows, ch0, nch);
-    const int64_t row0 = (int64_t)(rb0 + cur) * 32;
-    // Epilogue per row group (8 rows): previous state in as one dwordx4 per lane (8 rows x 128 B of the h tile),
-    // un-transposed through the wave's slab into the C layout; gate math per lane; h' (and, in training, the
-    // gates) back through the slab as dwordx4 stores.  No mul+add contraction in the gate math: a row's result must
-    // not depend on which slot of the lane it occupies (sharded == unsharded bit for bit).
-    const int trow = lane >> 3, tcol = (lane & 7) * 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int64_t hrow = row0 + 8 * q + trow;
-      const bool rvalid = hrow < p.n;
-      hrow = rvalid ? hrow : p.n - 1;
-      float hp[4];
-      tq_untranspose(tq, lane, li, hi, *reinterpret_cast<const float4 *>(p.h + hrow * p.ld_h + j0 + tcol), hp);
-      float res[4], rg[4], zg[4], ng[4], hn[4];
-      {
-#pragma clang fp contract(off)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 4 * q + i;
-          rg[i] = fast_sigmoid((acc[0][r] + bir) + bhr);
-          zg[i] = fast_sigmoid((acc[1][r] + biz) + bhz);
-          hn[i] = acc[3][r] + bhn;
-          ng[i] = fast_tanh((acc[2][r] + bin) + rg[i] * hn[i]);
-          res[i] = (1.0f - zg[i]) * ng[i] + zg[i] * hp[i];
-        }
-      }
-      const float4 o = tq_transpose(tq, lane, li, hi, res[0], res[1], res[2], res[3]);
-      if (rvalid) *reinterpret_cast<float4 *>(p.out + hrow * p.ld_out + j0 + tcol) = o;
-      if (p.gates) {   // training: r, z, n, gh_n for the backward ([n, 4H], gate-major)
-        float *gp = p.gates + hrow * (int64_t)(4 * p.H) + j0 + tcol;
-        const float4 o_r = tq_transpose(tq, lane, li, hi, rg[0], rg[1], rg[2], rg[3]);
-        const float4 o_z = tq_transpose(tq, lane, li, hi, zg[0], zg[1], zg[2], zg[3]);
-        const float4 o_n = tq_transpose(tq, lane, li, hi, ng[0], ng[1], ng[2], ng[3]);
-        const float4 o_h = tq_transpose(tq, lane, li, hi, hn[0], hn[1], hn[2], hn[3]);
-        if (rvalid) {
-          *reinterpret_cast<float4 *>(gp) = o_r;
-          *reinterpret_cast<float4 *>(gp + p.H) = o_z;
-          *reinterpret_cast<float4 *>(gp + 2 * p.H) = o_n;
-          *reinterpret_cast<float4 *>(gp + 3 * p.H) = o_h;
-        }
-      }
-    }
+    gru_epilogue(p, acc, tq, (int64_t)(rb0 + cur) * 32, j0, lane, li, hi, bir, biz, bin, bhr, bhz, bhn);
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = zero16();
     cur = nxt;
     nxt = nn;
     rows.c0 = rows.n0; rows.c1 = rows.n1;
     const int64_t r1 = clampr(nxt);
+    rows.n0 = p.a + r1 * p.ld_a + lofs; rows.n1 = p.h + r1 * p.ld_h + lofs;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused GRU cell whose weight slab does NOT fit LDS (K = M + H > ~400: BASELINE config 5, H = M = 256): the
+// 3 x 32 gate rows of the feature tile stream through a double-buffered ring of 64-column panels instead (2 x 26 KB),
+// refilled by the workgroup itself under its own MFMAs; A still goes straight from global memory into the MFMA
+// operand registers.  The waves of a workgroup walk the panels in lockstep (one LDS barrier per 64 columns), so the
+// workgroup is 4 waves and two of them share a CU: while one sits in its epilogue or at a barrier the other's waves
+// keep the matrix pipes busy.  Chunks are consumed in the same order, with the same k permutation, as by
+// k_stream_gru and the tile kernel: the three produce identical bits.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kRingPanel = 64;                         // K columns per panel (two 32-wide chunks)
+constexpr int kRingLd = kRingPanel + 4;                // floats per panel row
+constexpr int kRingPanelFloats = 96 * kRingLd;
+constexpr int kRingWaves = 4;
+
+__global__ __launch_bounds__(kRingWaves * 64, 2) void k_stream_gru_ring(GruArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = kRingWaves * 64;
+  const int b = blockIdx.x, G = gridDim.x;
+  int slab, part;
+  if (G % (kNumXcd * p.ncs) == 0) {
+    const int xcd = b % kNumXcd, j = b / kNumXcd;
+    slab = j % p.ncs;
+    part = xcd + kNumXcd * (j / p.ncs);
+  } else {
+    slab = b / p.rps;
+    part = b % p.rps;
+  }
+  const int rb0 = part * p.run_len;
+  const int rb1 = rb0 + p.run_len < p.nrb ? rb0 + p.run_len : p.nrb;
+  if (rb0 >= rb1) return;
+  const int count = rb1 - rb0;
+  const int rounds = (count + kRingWaves - 1) / kRingWaves;
+
+  const int K = p.M + p.H;
+  const int npan = K / kRingPanel;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  float *const tq = smem + 2 * kRingPanelFloats + wave * kTqFloats;
+  const int j0 = slab * 32;
+  const int ch0 = p.M >> 5, nch = K >> 5;
+
+  // this thread's six float4 of a weight panel: element e = t + 256 q -> slab row e / 16 = (t >> 4) + 16 q, i.e.
+  // gate q >> 1, feature j0 + (t >> 4) + 16 (q & 1); columns 4 (t & 15).  One per-thread offset, the rest is uniform
+  // (kept as 32-bit offsets on purpose: twelve hoisted 64-bit row pointers spilled the kernel)
+  const int trow = threadIdx.x >> 4, tc4 = (threadIdx.x & 15) * 4;
+  const int base_ih = (j0 + trow) * p.M + tc4, base_hh = (j0 + trow) * p.H + tc4;
+  auto panel_src = [&](int pan, int q) -> const float * {
+    const int k0 = pan * kRingPanel;                  // M % 64 == 0: a panel lies in W_ih or in W_hh
+    const int rq = (q >> 1) * p.H + (q & 1) * 16;     // row offset of this float4 inside the [3H, .] matrix
+    return k0 < p.M ? p.w_ih + (base_ih + rq * p.M + k0) : p.w_hh + (base_hh + rq * p.H + (k0 - p.M));
+  };
+  auto panel_dst = [&](int buf, int q) -> float * {
+    return smem + buf * kRingPanelFloats + (trow + 16 * q) * kRingLd + tc4;
+  };
+  {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) *reinterpret_cast<float4 *>(panel_dst(0, q)) = *reinterpret_cast<const float4 *>(panel_src(0, q));
+  }
+  __syncthreads();
+
+  const int lofs = lane_piece_offset<false>(hi);
+  auto clampr = [&](int u) {
+    const int64_t row = (int64_t)(rb0 + (u < count ? u : count - 1)) * 32 + li;
+    return row < p.n ? row : p.n - 1;
+  };
+  ARows rows;
+  {
+    const int64_t r0 = clampr(wave), r1 = clampr(wave + kRingWaves);
+    rows.c0 = p.a + r0 * p.ld_a + lofs; rows.c1 = p.h + r0 * p.ld_h + lofs;
+    rows.n0 = p.a + r1 * p.ld_a + lofs; rows.n1 = p.h + r1 * p.ld_h + lofs;
+  }
+  float4 a0[4], a1[4];
+  prologue_loads<false>(a0, a1, rows, ch0, nch);
+  f32x16 acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc[n] = zero16();
+
+  const int j = j0 + li;
+  const float bir = p.b_ih[j], biz = p.b_ih[p.H + j], bin = p.b_ih[2 * p.H + j];
+  const float bhr = p.b_hh[j], bhz = p.b_hh[p.H + j], bhn = p.b_hh[2 * p.H + j];
+  const int cbs = 32 * kRingLd;
+
+  int P = 0;                                          // panels consumed so far: panel P sits in buffer P & 1
+  for (int i = 0; i < rounds; ++i) {
+    const int u = i * kRingWaves + wave;              // this wave's unit of the round (may be past the run: computed
+    unit_fence();                                     // on clamped rows, not stored -- every wave keeps the barriers)
+    // one panel = two chunks; the next panel's rows ride under its MFMAs in two halves (3 + 3 float4 per thread:
+    // registers), each written into the buffer every wave left at the last barrier once its chunk is done
+#define PTGNN_RING_PANEL(PH)                                                                                   \
+  do {                                                                                                         \
+    const float *bl = smem + (P & 1) * kRingPanelFloats + li * kRingLd + hi * 4;                               \
+    float *const nb = smem + ((P + 1) & 1) * kRingPanelFloats + trow * kRingLd + tc4;                          \
+    const int nextpan = pan + 1 < npan ? pan + 1 : 0;                                                          \
+    float4 w0 = *reinterpret_cast<const float4 *>(panel_src(nextpan, 0));                                      \
+    float4 w1 = *reinterpret_cast<const float4 *>(panel_src(nextpan, 1));                                      \
+    float4 w2 = *reinterpret_cast<const float4 *>(panel_src(nextpan, 2));                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    float4 bcur[3];                                                                                            \
+    _Pragma("unroll") for (int n = 0; n < 3; ++n) bcur[n] = *reinterpret_cast<const float4 *>(bl + n * cbs);   \
+    chunk_f32<3, 4, PH, true>(acc, a0, bcur, bl, cbs, 0, 32, rows, 2 * pan + 2, ch0, nch);                     \
+    *reinterpret_cast<float4 *>(nb) = w0;                                                                      \
+    *reinterpret_cast<float4 *>(nb + 16 * kRingLd) = w1;                                                       \
+    *reinterpret_cast<float4 *>(nb + 32 * kRingLd) = w2;                                                       \
+    w0 = *reinterpret_cast<const float4 *>(panel_src(nextpan, 3));                                             \
+    w1 = *reinterpret_cast<const float4 *>(panel_src(nextpan, 4));                                             \
+    w2 = *reinterpret_cast<const float4 *>(panel_src(nextpan, 5));                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    chunk_f32<3, 4, PH, true>(acc, a1, bcur, bl, cbs, 32, 0, rows, 2 * pan + 3, ch0, nch);                     \
+    *reinterpret_cast<float4 *>(nb + 48 * kRingLd) = w0;                                                       \
+    *reinterpret_cast<float4 *>(nb + 64 * kRingLd) = w1;                                                       \
+    *reinterpret_cast<float4 *>(nb + 80 * kRingLd) = w2;                                                       \
+    lds_barrier();   /* panel P + 1 is complete; everyone is done reading panel P */                           \
+  } while (0)
+    int pan = 0;
+    for (; pan < (ch0 >> 1); ++pan, ++P) PTGNN_RING_PANEL(0);
+    for (; pan < npan; ++pan, ++P) PTGNN_RING_PANEL(1);
+#undef PTGNN_RING_PANEL
+    if (u < count) gru_epilogue(p, acc, tq, (int64_t)(rb0 + u) * 32, j0, lane, li, hi, bir, biz, bin, bhr, bhz, bhn);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = zero16();
+    rows.c0 = rows.n0; rows.c1 = rows.n1;
+    const int64_t r1 = clampr(u + 2 * kRingWaves);
     rows.n0 = p.a + r1 * p.ld_a + lofs; rows.n1 = p.h + r1 * p.ld_h + lofs;
   }
 }
@@ -736,8 +867,8 @@ bool set_lds(Kern kern, size_t bytes) {
 }
 
 // runs per slab for the dense kernels: one 8-wave workgroup per CU
-void dense_runs(int nrb, int ncs, int &rps, int &run_len) {
-  const int max_wg = num_compute_units();
+void dense_runs(int nrb, int ncs, int &rps, int &run_len, int max_wg = 0) {
+  if (max_wg <= 0) max_wg = num_compute_units();
   rps = max_wg / ncs;
   if (rps < 1) rps = 1;
   if (rps >= kNumXcd && (rps / kNumXcd * kNumXcd) * ncs * 10 >= max_wg * 9) rps = rps / kNumXcd * kNumXcd;
@@ -827,12 +958,25 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
     slab = Slab<false>::bytes(K, 96);
   }
   const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
-  if (lds > (size_t)kLdsBudget) return 0;
   GruArgs p;
   p.a = a; p.ld_a = ld_a; p.h = h; p.ld_h = ld_h; p.w_ih = w_ih; p.w_hh = w_hh; p.b_ih = b_ih; p.b_hh = b_hh;
   p.n = n; p.M = m; p.H = hd; p.out = out; p.ld_out = ld_out; p.gates = gates;
   p.nrb = (int)((n + 31) / 32);
   p.ncs = hd / 32;
+  const char *ring_env = getenv("PTGNN_AMD_GRU_RING");                        // "1": A/B + parity tests at small K
+  const bool force_ring = ring_env && ring_env[0] == '1';
+  if ((lds > (size_t)kLdsBudget && !(ring_env && ring_env[0] == '0')) || (force_ring && !split)) {
+    // the slab does not fit (K > ~400): stream the weights through the panel ring (exact fp32, also in the split
+    // mode, whose three bf16 planes fit even less)
+    const size_t rlds = (size_t)(2 * kRingPanelFloats + kRingWaves * kTqFloats) * sizeof(float);
+    dense_runs(p.nrb, p.ncs, p.rps, p.run_len, 2 * num_compute_units());   // two 4-wave workgroups per CU
+    p.lds_floats = 0;
+    auto kern = k_stream_gru_ring;
+    if (!set_lds(kern, rlds)) return 0;
+    kern<<<(unsigned)(p.ncs * p.rps), kRingWaves * 64, rlds, st>>>(p);
+    return 1;
+  }
+  if (lds > (size_t)kLdsBudget) return 0;
   dense_runs(p.nrb, p.ncs, p.rps, p.run_len);
   p.lds_floats = (int)(slab / 4);
   const unsigned grid = (unsigned)(p.ncs * p.rps);

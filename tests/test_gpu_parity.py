@@ -370,6 +370,36 @@ def test_gru_cell_matches_oracle(n, m, h):
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("n,m,h", [(5000, 256, 256), (131, 256, 256), (4097, 384, 256), (3000, 128, 128), (900, 64, 192)])
+def test_gru_ring_kernel_is_bit_identical_to_the_other_gru_kernels(n, m, h, monkeypatch):
+    """The fused GRU cell whose weight slab does not fit LDS (K = M + H > ~400: BASELINE config 5, H = M = 256)
+    streams its weights through a two-panel ring (stream_gemm.hip k_stream_gru_ring).  It accumulates K in the
+    library's one fixed order, so it must reproduce the tile kernel -- and, at shapes both take, the slab-resident
+    streaming kernel -- bit for bit, with and without the training-time gate outputs; and sit within 1e-5 of
+    float64 (gatedmessagepassing.py:69)."""
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(n + m)
+    a, hh = torch.randn(n, m, generator=g), torch.randn(n, h, generator=g)
+    w_ih, w_hh = torch.randn(3 * h, m, generator=g) / m ** 0.5, torch.randn(3 * h, h, generator=g) / h ** 0.5
+    b_ih, b_hh = torch.randn(3 * h, generator=g) * 0.1, torch.randn(3 * h, generator=g) * 0.1
+    want64 = torch._VF.gru_cell(a.double(), hh.double(), w_ih.double(), w_hh.double(), b_ih.double(), b_hh.double())
+    args = [t.cuda() for t in (a, hh, w_ih, w_hh, b_ih, b_hh)]
+    monkeypatch.setenv("PTGNN_AMD_GRU_RING", "1")            # also where the resident slab would fit
+    ring = ops.gru_cell(*args)
+    ring_out, ring_gates = ops.gru_cell_train(*args)
+    monkeypatch.setenv("PTGNN_AMD_GRU_RING", "0")            # never the ring: resident slab, or the tile kernel
+    other = ops.gru_cell(*args)
+    other_out, other_gates = ops.gru_cell_train(*args)
+    prev = ops.set_gemm_mode("tile")
+    try:
+        tile = ops.gru_cell(*args)
+    finally:
+        ops.set_gemm_mode(prev)
+    assert torch.equal(ring, other) and torch.equal(ring, tile) and torch.equal(ring, ring_out)
+    assert torch.equal(ring_out, other_out) and torch.equal(ring_gates, other_gates)
+    assert float((ring.cpu().double() - want64).abs().max()) <= TOL
+
+
 def test_gather_rows():
     from ptgnn_amd import ops
     g = torch.Generator().manual_seed(1)
