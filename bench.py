@@ -377,7 +377,8 @@ def pmc_traffic(workload, kernel):
     return {"traffic": None}
 
 
-VARIANT_DEADLINE_S = 240   # wall-clock budget of the sharded cut-edge variants at N > 1
+# wall-clock budget of the sharded cut-edge variants at N > 1 (env override: the watchdog test uses a short one)
+VARIANT_DEADLINE_S = float(os.environ.get("PTGNN_AMD_BENCH_VARIANT_DEADLINE", "240"))
 PARITY_TOL = 1e-5   # BASELINE.json north_star: fp32 node states within 1e-5 of the reference CPU path
 
 
@@ -925,6 +926,10 @@ def main():
         watchdog = threading.Timer(VARIANT_DEADLINE_S, bail_out)
         watchdog.daemon = True
         watchdog.start()
+        fault = os.environ.get("PTGNN_AMD_BENCH_FAULT", "")      # test hook: "hang:<rank>" stalls that rank here
+        if fault == f"hang:{rank}":
+            _log(f"fault injection: rank {rank} stalls before the sharded variants")
+            threading.Event().wait()
         for key, fn in (("cfg5_shard", sharded_cfg5), ("cfg4_stack", sharded_cfg4)):
             try:
                 _log(f"sharded cut-edge variant {key}")

@@ -133,6 +133,26 @@ int ptgnn_amd_validate_indices(const int64_t *idx, int64_t n, int64_t num_nodes,
                                int32_t *bad_count, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Index bookkeeping of a destination-range shard (north star: "large batched graphs shard by destination-node
+ * range across up to 8 GPUs"; SURVEY.md 8e, 8f-3 "halo send lists").  The reference has no counterpart -- its only
+ * multi-GPU mode is whole-batch data parallelism (distributedtrainer.py:250-297); the tensors it starts from are
+ * the per-type int64 adjacency lists of finalize_minibatch (graphneuralnetwork.py:461-467), here in GLOBAL node ids
+ * and restricted to the edges whose destination this rank owns ([lo, hi)).
+ *   local_dst[e] = dst - lo;  local_src[e] = src - lo for an own source, else n_local + the source's slot in the
+ *   sorted list of DISTINCT remote sources `need_ids` (ascending global ids = grouped by owner, because the
+ *   ranges bounds[0] <= ... <= bounds[world] are ordered by rank); edges in the type-major order of the lists.
+ *   stats (device int64 [world + 2 + num_types], zeroed here): [0, world) halo rows per owner |
+ *   [world] edges with a remote source | [world + 1] halo rows in all | then own-source edges per edge type.
+ * need_capacity >= min(num_edges, total_nodes - (hi - lo)).  Nothing synchronises with the host.
+ * ---------------------------------------------------------------------------------------- */
+size_t ptgnn_amd_shard_index_workspace_bytes(int64_t total_nodes);
+int ptgnn_amd_shard_index(const int64_t *const *src_per_type, const int64_t *const *dst_per_type,
+                          const int64_t *edges_per_type, int32_t num_types, int64_t lo, int64_t hi,
+                          const int64_t *bounds /* device [world + 1] */, int32_t world, int64_t total_nodes,
+                          int64_t *local_src, int64_t *local_dst, int64_t *need_ids, int64_t need_capacity,
+                          int64_t *stats, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused gather -> (+ destination term) -> segment reduce -> (row epilogue).
  *
  *   out[v, :] = EPI( REDUCE_{i in rowptr[v]..rowptr[v+1]}  Ysrc[src_i, t_i*M : (t_i+1)*M]

@@ -393,6 +393,41 @@ def build_plan(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], num
     return plan
 
 
+def shard_index(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], lo: int, hi: int,
+                bounds: torch.Tensor, total_nodes: int):
+    """ptgnn_amd_shard_index: (local_src [E], local_dst [E], need_ids buffer, stats) of a dst-range shard whose
+    edges are given in global ids; see include/ptgnn_amd.h.  No host synchronisation."""
+    lib = _lib.load()
+    T = len(adjacency_lists)
+    srcs = [a[0].contiguous() for a in adjacency_lists]
+    dsts = [a[1].contiguous() for a in adjacency_lists]
+    for s_, d_ in zip(srcs, dsts):
+        if not (s_.is_cuda and d_.is_cuda and s_.dtype == torch.int64 and d_.dtype == torch.int64 and s_.shape == d_.shape):
+            raise _lib.PtgnnAmdError("shard_index: adjacency lists must be equal-length CUDA int64 tensors")
+    dev = srcs[0].device
+    counts = [int(s_.shape[0]) for s_ in srcs]
+    E = sum(counts)
+    world = int(bounds.shape[0]) - 1
+    local_src = torch.empty(max(E, 1), dtype=torch.int64, device=dev)
+    local_dst = torch.empty(max(E, 1), dtype=torch.int64, device=dev)
+    cap = max(0, min(E, total_nodes - (hi - lo)))
+    need = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+    stats = torch.empty(world + 2 + T, dtype=torch.int64, device=dev)
+    ws_bytes = int(lib.ptgnn_amd_shard_index_workspace_bytes(total_nodes))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    PtrArr, CntArr = ctypes.c_void_p * T, ctypes.c_int64 * T
+    sp = PtrArr(*[s_.data_ptr() if s_.numel() else None for s_ in srcs])
+    dp = PtrArr(*[d_.data_ptr() if d_.numel() else None for d_ in dsts])
+    cn = CntArr(*counts)
+    with _timed("shard_index", bytes=E * 32.0 + total_nodes / 4.0):
+        rc = lib.ptgnn_amd_shard_index(ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p),
+                                       ctypes.cast(cn, ctypes.c_void_p), T, int(lo), int(hi), bounds.data_ptr(), world,
+                                       int(total_nodes), local_src.data_ptr(), local_dst.data_ptr(), need.data_ptr(),
+                                       cap, stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream(local_src))
+    _lib.check(rc, "ptgnn_amd_shard_index")
+    return local_src[:E], local_dst[:E], counts, need, stats
+
+
 def plan_from_sorted_index(index: torch.Tensor, num_segments: int) -> GraphPlan:
     """Plan of a segment reduce whose index is already sorted (node_to_graph_idx of a disjoint-union
     batch): no sort -- rowptr is a searchsorted over the index, col/perm are the identity."""

@@ -187,21 +187,35 @@ class ShardedGraph:
         # partitioned on graph boundaries (graphneuralnetwork.py:418-423 keeps a graph's node ids
         # contiguous) has none: every rank then runs the single-GPU path with no data-path collective
         # and skips the halo bookkeeping altogether.
-        src, dst, counts = _flatten(adjacency_lists)
-        flag = torch.zeros(1, dtype=torch.int64, device=dev)
-        if src.numel():
-            lo_s, hi_s = torch.aminmax(src)
-            flag = ((lo_s < g.lo) | (hi_s >= g.hi)).to(torch.int64).reshape(1)
-        need_counts = g.index_locally(adjacency_lists, (src, dst, counts))   # device int64 [world], no host sync yet
+        hip = dev.type == "cuda"
+        if hip:
+            # the whole index pass in HIP (csrc/shard_index.hip: 5 launches over the edge lists and a BITMAP of the
+            # global id space, no host sync): local ids of every endpoint, the sorted distinct halo ids, halo rows per
+            # owner, remote-source edge count, own-source edges per type
+            ls, ld, counts, need_buf, sstats = ops.shard_index(adjacency_lists, g.lo, g.hi, g.bounds, g.bounds_host[-1])
+            need_counts = sstats[: g.world]
+            flag = sstats[g.world: g.world + 1]                     # edges with a remote source (0 = nothing is cut)
+            halo_total = sstats[g.world + 1: g.world + 2]
+            own_counts_dev = sstats[g.world + 2:]
+            n_edges = sum(counts)
+        else:   # gloo / CPU tests of the host logic: the same results from torch ops
+            src, dst, counts = _flatten(adjacency_lists)
+            flag = torch.zeros(1, dtype=torch.int64, device=dev)
+            if src.numel():
+                lo_s, hi_s = torch.aminmax(src)
+                flag = ((lo_s < g.lo) | (hi_s >= g.hi)).to(torch.int64).reshape(1)
+            need_counts = g.index_locally(adjacency_lists, (src, dst, counts))   # device int64 [world], no host sync yet
+            halo_total = need_counts.sum().reshape(1)
+            n_edges = int(src.numel())
         # ONE small all-reduce: the cut flag and the group-wide (edges, own rows, halo rows) the layers choose their
         # form from -- a per-rank choice would make ranks disagree on what the halo all-to-all carries
-        stats = torch.cat([flag, _to_device_ints([int(src.numel()), g.n_local], dev), need_counts.sum().reshape(1)])
+        stats = torch.cat([flag, _to_device_ints([n_edges, g.n_local], dev), halo_total])
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
         got_counts = torch.empty_like(need_counts)
-        dist.all_to_all_single(got_counts, need_counts, group=group)
+        dist.all_to_all_single(got_counts, need_counts.contiguous(), group=group)
         # ONE host read-back per minibatch: the flag + stats, the split sizes all_to_all_single wants as host ints
         # and (two-block mode) the per-type own-source edge counts
-        extra = [g.own_source_counts()] if overlap else []
+        extra = [own_counts_dev if hip else g.own_source_counts()] if overlap else []
         both = torch.cat([stats, need_counts, got_counts] + extra).tolist()
         g.global_stats = (int(both[1]), int(both[2]), int(both[3]))
         both = [both[0]] + both[4:]
@@ -212,7 +226,7 @@ class ShardedGraph:
             g.send_ids = g.need_ids
             g.send_splits = [0] * g.world
             g.recv_splits = [0] * g.world
-            g.local_adj = _unflatten(src - g.lo, dst - g.lo, counts)
+            g.local_adj = _unflatten(ls, ld, counts) if hip else _unflatten(src - g.lo, dst - g.lo, counts)
             g._flat = g._slot = g._mark = None
             if build_plan:
                 g.build_plan()
@@ -221,7 +235,12 @@ class ShardedGraph:
         g.recv_splits = [int(v) for v in both[: g.world]]            # halo rows I receive per owner
         g.send_splits = [int(v) for v in both[g.world: 2 * g.world]]  # rows I send per peer
         g.n_halo = sum(g.recv_splits)
-        g.finish_local_index()
+        if hip:
+            g.need_ids = need_buf[: g.n_halo]
+            g._flat = g._local_flat = (ls, ld, counts)               # `_flat` only serves `_type_ids` (device + counts)
+            g.local_adj = _unflatten(ls, ld, counts)
+        else:
+            g.finish_local_index()
         if overlap:
             g.split_blocks([int(v) for v in both[2 * g.world:]])
         g._flat = None
@@ -358,7 +377,7 @@ class ShardedGraph:
 
     @staticmethod
     def build_local(adjacency_lists: Adj, all_ranges: Sequence[Tuple[int, int]], rank: int,
-                    overlap: bool = False) -> "ShardedGraph":
+                    overlap: bool = False, use_hip_index: bool = True) -> "ShardedGraph":
         """Collective-free construction of ONE rank's view (no process group): everything `build` derives from
         this rank's own edges -- halo ids, remapped adjacency, plan.  The send side (`send_ids`) needs the peers
         and stays empty, so this serves single-process simulations of a sharded run (tests, dry runs) where
@@ -368,14 +387,24 @@ class ShardedGraph:
         g.lo, g.hi = int(all_ranges[rank][0]), int(all_ranges[rank][1])
         g.n_local = g.hi - g.lo
         g.set_bounds(all_ranges, adjacency_lists[0][0].device)
-        g.recv_splits = [int(v) for v in g.index_locally(adjacency_lists).tolist()]
-        g.n_halo = sum(g.recv_splits)
-        g.global_stats = (sum(int(a[0].shape[0]) for a in adjacency_lists), g.n_local, g.n_halo)
         g.no_cut = False
-        g.finish_local_index()
+        if adjacency_lists[0][0].is_cuda and use_hip_index:
+            ls, ld, counts, need_buf, sstats = ops.shard_index(adjacency_lists, g.lo, g.hi, g.bounds, g.bounds_host[-1])
+            host = sstats.tolist()
+            g.recv_splits = [int(v) for v in host[: g.world]]
+            g.n_halo = sum(g.recv_splits)
+            g.need_ids = need_buf[: g.n_halo]
+            g._flat = g._local_flat = (ls, ld, counts)
+            g.local_adj = _unflatten(ls, ld, counts)
+            own_counts = [int(v) for v in host[g.world + 2:]] if overlap else None
+        else:
+            g.recv_splits = [int(v) for v in g.index_locally(adjacency_lists).tolist()]
+            g.n_halo = sum(g.recv_splits)
+            g.finish_local_index()
+            own_counts = [int(v) for v in g.own_source_counts().tolist()] if overlap else None
+        g.global_stats = (sum(int(a[0].shape[0]) for a in adjacency_lists), g.n_local, g.n_halo)
         g.send_splits = [0] * g.world
         g.send_ids = g.need_ids[:0]
-        own_counts = [int(v) for v in g.own_source_counts().tolist()] if overlap else None
         if adjacency_lists[0][0].is_cuda:
             g.build_plan()
         if overlap:

@@ -374,9 +374,9 @@ def test_gru_cell_matches_oracle(n, m, h):
 def test_gru_ring_kernel_is_bit_identical_to_the_other_gru_kernels(n, m, h, monkeypatch):
     """The fused GRU cell whose weight slab does not fit LDS (K = M + H > ~400: BASELINE config 5, H = M = 256)
     streams its weights through a two-panel ring (stream_gemm.hip k_stream_gru_ring).  It accumulates K in the
-    library's one fixed order, so it must reproduce the tile kernel -- and, at shapes both take, the slab-resident
-    streaming kernel -- bit for bit, with and without the training-time gate outputs; and sit within 1e-5 of
-    float64 (gatedmessagepassing.py:69)."""
+    library's one fixed order with the streaming kernels' gate math, so at shapes both take it must reproduce the
+    slab-resident streaming kernel bit for bit (outputs and training-time gates); the tile kernel differs only by
+    its libm gate math (<= 1e-6); all within 1e-5 of float64 (gatedmessagepassing.py:69)."""
     from ptgnn_amd import ops
     g = torch.Generator().manual_seed(n + m)
     a, hh = torch.randn(n, m, generator=g), torch.randn(n, h, generator=g)
@@ -395,8 +395,13 @@ def test_gru_ring_kernel_is_bit_identical_to_the_other_gru_kernels(n, m, h, monk
         tile = ops.gru_cell(*args)
     finally:
         ops.set_gemm_mode(prev)
-    assert torch.equal(ring, other) and torch.equal(ring, tile) and torch.equal(ring, ring_out)
-    assert torch.equal(ring_out, other_out) and torch.equal(ring_gates, other_gates)
+    assert torch.equal(ring, ring_out)
+    slab_fits = 96 * (m + h + 4) * 4 + 16 + 8 * 288 * 4 <= 160 * 1024     # stream_gemm.hip stream_gru
+    if slab_fits:    # `other` is the slab-resident streaming kernel: same MFMA order, same gate-math routine
+        assert torch.equal(ring, other) and torch.equal(ring_out, other_out) and torch.equal(ring_gates, other_gates)
+    else:            # `other` is the tile kernel, whose gate math is libm's (the streaming kernels use v_exp / v_rcp)
+        assert float((ring - other).abs().max()) <= 1e-6 and float((ring_gates - other_gates).abs().max()) <= 1e-6
+    assert float((ring - tile).abs().max()) <= 1e-6
     assert float((ring.cpu().double() - want64).abs().max()) <= TOL
 
 
@@ -2120,3 +2125,73 @@ def test_row_epilogue_equals_the_fused_inference_epilogue_bitwise_and_handles_ed
     assert y0.shape == (0, dim) and float(ln.weight.grad.abs().max()) == 0.0
     with pytest.raises(Exception):
         dense.row_epilogue(torch.zeros(4, 600, device="cuda"), True, None)        # wider than the kernels tile
+
+
+# ------------------------------------------------------------------------------------------------
+# the opt-in "f32 via 3 x bf16 split" GEMM mode over the configs it had not been checked on
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["cfg1_ppi", "cfg2_sum", "cfg2_max", "golden_ggnn_max_edge", "golden_ggnn_sum_table",
+                                  "golden_mlp_sum_edge", "golden_mlp_max_table", "autograd_ggnn_sum_edge",
+                                  "autograd_mlp_mean_table"])
+def test_split_gemm_mode_parity_matrix(case, monkeypatch):
+    """ptgnn_amd_set_gemm_mode(2) against the SAME bars as the exact mode: BASELINE configs 1 and 2 at full size vs
+    the oracle (1e-5), and the training step -- outputs, d x and every parameter gradient -- vs the reference's own
+    gradients (tests/golden/train_*.npz) and vs oracle autograd.  (Configs 3, 4 and 5 carry a `split` parameter in
+    their own tests.)  The split mode replaces the forward / input-gradient GEMMs; the weight-gradient kernels are
+    exact fp32 in every mode."""
+    from ptgnn_amd import ops
+    prev = ops.set_gemm_mode("split")
+    try:
+        if case == "cfg1_ppi":
+            test_config1_ppi_ggnn_full_size_vs_oracle()
+        elif case.startswith("cfg2_"):
+            test_config2_full_size_vs_oracle(case.split("_")[1])
+        elif case.startswith("golden_"):
+            _, kind, agg, path = case.split("_")
+            name = {"ggnn": f"train_ggnn_{agg}", "mlp": "train_mlp_sum_target" if agg == "sum" else "train_mlp_max_notarget"}[kind]
+            test_training_gradients_match_reference_golden(name, path, monkeypatch)
+        else:
+            _, kind, agg, path = case.split("_")
+            test_training_gradients_match_oracle_autograd(kind, agg, path, monkeypatch)
+    finally:
+        ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("case", ["cfg4_like_T21", "one_type_random", "no_remote", "types_over_table"])
+def test_shard_index_kernels_equal_the_torch_bookkeeping(case):
+    """csrc/shard_index.hip (bitmap mark / compact / remap) against the torch-op chain it replaces (and which the
+    gloo CPU tests still run): identical halo id lists, per-owner counts, remapped adjacency and own-source counts,
+    for every rank of a 3-way partition."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import sharded, workloads
+    g = torch.Generator().manual_seed(23)
+    if case == "cfg4_like_T21":
+        mb = workloads.batched_graphs(6, 900, 10, 2.4, seed=5)
+        n = mb["num_nodes"]
+        adj = O.augment_adjacency(mb["adjacency_lists"], n, True, True)
+    elif case == "one_type_random":
+        n = 50_001
+        adj = [(torch.randint(0, n, (400_000,), generator=g), torch.randint(0, n, (400_000,), generator=g))]
+    elif case == "no_remote":
+        n = 3000
+        adj = [(torch.randint(0, 1000, (5000,), generator=g) + 1000 * (i % 3), torch.randint(0, 1000, (5000,), generator=g) + 1000 * (i % 3))
+               for i in range(3)]
+    else:
+        n = 2000
+        adj = [(torch.randint(0, n, (30 + t,), generator=g), torch.randint(0, n, (30 + t,), generator=g)) for t in range(70)]
+    indeg = torch.zeros(n, dtype=torch.int64)
+    for _, d in adj:
+        indeg += torch.bincount(d, minlength=n)
+    ranges = [(0, 1000), (1000, 2000), (2000, 3000)] if case == "no_remote" else sharded.balanced_node_ranges(indeg, 3)
+    for rank, (lo, hi) in enumerate(ranges):
+        mine = [(s[(d >= lo) & (d < hi)].cuda(), d[(d >= lo) & (d < hi)].cuda()) for s, d in adj]
+        a = sharded.ShardedGraph.build_local(mine, ranges, rank, overlap=True, use_hip_index=True)
+        b = sharded.ShardedGraph.build_local(mine, ranges, rank, overlap=True, use_hip_index=False)
+        assert a.recv_splits == b.recv_splits and a.n_halo == b.n_halo
+        assert torch.equal(a.need_ids, b.need_ids)
+        for (sa, da), (sb, db) in zip(a.local_adj, b.local_adj):
+            assert torch.equal(sa, sb) and torch.equal(da, db)
+        for (sa, da), (sb, db) in zip(a.adj_own + a.adj_halo, b.adj_own + b.adj_halo):   # the own-source counts agree
+            assert torch.equal(sa, sb) and torch.equal(da, db)
+        if case == "no_remote":
+            assert a.n_halo == 0

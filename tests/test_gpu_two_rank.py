@@ -36,3 +36,26 @@ def test_sharded_paths_over_real_process_group(world):
     assert r.returncode == 0, tail
     # 8 layer cases + 1 stack + 2 training cases + 2 graph-boundary cases per rank (ranks may interleave their lines)
     assert len(re.findall(r"rank \d+ ok ", r.stdout)) == 13 * world, tail
+
+
+def test_bench_watchdog_emits_the_primary_line_when_a_rank_stalls():
+    """bench.py --gpus 2 (gloo, both ranks on cuda:0 -- the validation hook for 1-GPU boxes) with rank 1 stalled right
+    before the sharded cut-edge variants: rank 0 blocks in their first collective, the per-rank watchdog ends every
+    rank cleanly and rank 0 still prints the ONE JSON line with the primary measurement (distributedtrainer.py:250-297
+    is the reference's multi-GPU entry; a hung collective must not cost the driver its SCALE line)."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-secondary"]
+    env = dict(os.environ, OMP_NUM_THREADS="4", PTGNN_AMD_BENCH_BACKEND="gloo", PTGNN_AMD_BENCH_SHARE_GPU="1",
+               PTGNN_AMD_BENCH_FAULT="hang:1", PTGNN_AMD_BENCH_VARIANT_DEADLINE="15")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + "\n" + r.stderr)[-4000:]
+    assert r.returncode == 0, tail
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, tail
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "timed out" in res["cut_edges_variant"]["error"], tail
