@@ -21,13 +21,17 @@
 // dwordx4 stores per wave instead of 64 strided dword stores); k_wgrad_reduce reads them in the same order and
 // un-permutes on its (much rarer) stores.
 #include "dense_common.h"
+#include "stream_gemm.h"
 
 namespace ptgnn_amd {
 namespace {
 
 constexpr int kMaxTypesW = 64;
 constexpr int WG_LD = 132;            // floats per LDS row: 128 + 4 (rows stay 16-byte aligned)
-constexpr int STEP = 32;              // edges per LDS stage
+#ifndef PTGNN_WGRAD_STEP
+#define PTGNN_WGRAD_STEP 32
+#endif
+constexpr int STEP = PTGNN_WGRAD_STEP;   // edges per LDS stage (multiple of 8).  32 / 48 measured level, 64 loses a third (two workgroups per CU): profiles/r03_notes.md
 constexpr int kTile = 128 * 128;      // floats per partial tile
 
 struct WgradTable {
@@ -92,63 +96,55 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nsteps = (int)((e_end - e_begin + STEP - 1) / STEP);
-  // software pipeline: node ids of stage s+2 and rows of stage s+1 are in flight under the MFMAs of
-  // stage s.  (Plain scalars + macros: arrays captured by a lambda ended up in scratch memory.)
-  int64_t nid0, nid1, nid2, nid3;
-  float4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
-#define WG_EDGE(S, R) ([&]() -> int64_t {                                   \
-    int64_t e_ = e_begin + (int64_t)(S) * STEP + erow + (R) * 8;            \
-    return e_ < n_edges ? e_ : n_edges - 1; }())
-#define WG_CLAMP(V) ([&]() -> int64_t { int64_t v_ = (V); v_ = v_ < 0 ? 0 : v_;            \
-    return v_ < num_rows ? v_ : num_rows - 1; }())   /* ids were range-checked by the plan build */
-#define WG_LOAD_IDX(S)                                                       \
-  do {                                                                       \
-    if (idx) { /* uniform: a null index list means "row e of x" (dense weight gradient) */ \
-      nid0 = WG_CLAMP(idx[WG_EDGE(S, 0)]); nid1 = WG_CLAMP(idx[WG_EDGE(S, 1)]); \
-      nid2 = WG_CLAMP(idx[WG_EDGE(S, 2)]); nid3 = WG_CLAMP(idx[WG_EDGE(S, 3)]); \
-    } else {                                                                 \
-      nid0 = WG_EDGE(S, 0); nid1 = WG_EDGE(S, 1);                            \
-      nid2 = WG_EDGE(S, 2); nid3 = WG_EDGE(S, 3);                            \
-    }                                                                        \
-  } while (0)
-#define WG_LOAD_ROW(S, R, VA, VB, NID)                                                        \
-  do {                                                                                        \
-    VA = *reinterpret_cast<const float4 *>(gm + (gm_row0 + WG_EDGE(S, R)) * ld_gm + ca);      \
-    VB = *reinterpret_cast<const float4 *>(x + (NID) * ld_x + cb);                            \
-  } while (0)
-#define WG_LOAD_ROWS(S)                                                      \
-  do {                                                                       \
-    WG_LOAD_ROW(S, 0, va0, vb0, nid0); WG_LOAD_ROW(S, 1, va1, vb1, nid1);    \
-    WG_LOAD_ROW(S, 2, va2, vb2, nid2); WG_LOAD_ROW(S, 3, va3, vb3, nid3);    \
-  } while (0)
-#define WG_STORE(S, R, VA, VB)                                                               \
-  do {                                                                                       \
-    const int64_t e_ = e_begin + (int64_t)(S) * STEP + erow + (R) * 8;                       \
-    /* rows past the chunk must add nothing; only the last stage of a chunk can hold any (uniform test) */ \
-    const bool valid_ = (S) + 1 < nsteps || e_ < e_end;                                      \
-    float4 b_ = VB;                                                                          \
-    if constexpr (DROP) b_ = dropout_apply4(drop, gm_row0 + e_, kc, b_);                     \
-    /* componentwise: `cond ? float4 : float4` becomes a pointer select through scratch */   \
-    const float4 a_ = make_float4(valid_ ? VA.x : 0.f, valid_ ? VA.y : 0.f,                  \
-                                  valid_ ? VA.z : 0.f, valid_ ? VA.w : 0.f);                 \
-    b_ = make_float4(valid_ ? b_.x : 0.f, valid_ ? b_.y : 0.f, valid_ ? b_.z : 0.f,          \
-                     valid_ ? b_.w : 0.f);                                                   \
-    *reinterpret_cast<float4 *>(As + (erow + (R) * 8) * WG_LD + c4) = a_;                    \
-    *reinterpret_cast<float4 *>(Bs + (erow + (R) * 8) * WG_LD + c4) = b_;                    \
-  } while (0)
-  WG_LOAD_IDX(0);
-  WG_LOAD_ROWS(0);
-  if (nsteps > 1) WG_LOAD_IDX(1);
+  // software pipeline: node ids of stage s+2 and rows of stage s+1 are in flight under the MFMAs of stage s.
+  // A thread stages NR = STEP / 8 edges of each operand (one float4 column of each); fixed-trip unrolled loops
+  // over plain arrays keep them in registers (arrays captured by a lambda ended up in scratch memory).
+  constexpr int NR = STEP / 8;
+  int64_t nid[NR];
+  float4 va[NR], vb[NR];
+  auto edge_of = [&](int s_, int r_) -> int64_t {
+    const int64_t e_ = e_begin + (int64_t)s_ * STEP + erow + r_ * 8;
+    return e_ < n_edges ? e_ : n_edges - 1;
+  };
+#define WG_LOAD_IDX(S)                                                                                   \
+  _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) {                                                    \
+    int64_t v_ = edge_of(S, r_);                                                                         \
+    if (idx) { /* uniform: a null index list means "row e of x" (dense weight gradient) */              \
+      v_ = idx[v_];                                                                                      \
+      v_ = v_ < 0 ? 0 : v_;                                                                              \
+      v_ = v_ < num_rows ? v_ : num_rows - 1;   /* ids were range-checked by the plan build */           \
+    }                                                                                                    \
+    nid[r_] = v_;                                                                                        \
+  }
+#define WG_LOAD_ROWS(S)                                                                                  \
+  _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) {                                                    \
+    va[r_] = *reinterpret_cast<const float4 *>(gm + (gm_row0 + edge_of(S, r_)) * ld_gm + ca);            \
+    vb[r_] = *reinterpret_cast<const float4 *>(x + nid[r_] * ld_x + cb);                                 \
+  }
+  WG_LOAD_IDX(0)
+  WG_LOAD_ROWS(0)
+  if (nsteps > 1) { WG_LOAD_IDX(1) }
 
   float colsum = 0.f;
   for (int s = 0; s < nsteps; ++s) {
     __syncthreads();
-    WG_STORE(s, 0, va0, vb0); WG_STORE(s, 1, va1, vb1);
-    WG_STORE(s, 2, va2, vb2); WG_STORE(s, 3, va3, vb3);
+    const bool tail = s + 1 == nsteps;   // rows past the chunk must add nothing; only the last stage can hold any
+#pragma unroll
+    for (int r_ = 0; r_ < NR; ++r_) {
+      const int64_t e_ = e_begin + (int64_t)s * STEP + erow + r_ * 8;
+      float4 a_ = va[r_], b_ = vb[r_];
+      if constexpr (DROP) b_ = dropout_apply4(drop, gm_row0 + e_, kc, b_);
+      if (tail && e_ >= e_end) {   /* componentwise: `cond ? float4 : float4` becomes a pointer select through scratch */
+        a_ = make_float4(0.f, 0.f, 0.f, 0.f);
+        b_ = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      *reinterpret_cast<float4 *>(As + (erow + r_ * 8) * WG_LD + c4) = a_;
+      *reinterpret_cast<float4 *>(Bs + (erow + r_ * 8) * WG_LD + c4) = b_;
+    }
     __syncthreads();
     if (s + 1 < nsteps) {
-      WG_LOAD_ROWS(s + 1);
-      if (s + 2 < nsteps) WG_LOAD_IDX(s + 2);
+      WG_LOAD_ROWS(s + 1)
+      if (s + 2 < nsteps) { WG_LOAD_IDX(s + 2) }
     }
     if constexpr (COLSUM) {
       if (kt == 0 && threadIdx.x < 128) {
@@ -175,13 +171,8 @@ __global__ __launch_bounds__(256, 3) void k_edge_wgrad(
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
-
-#undef WG_EDGE
 #undef WG_LOAD_IDX
-#undef WG_CLAMP
-#undef WG_LOAD_ROW
 #undef WG_LOAD_ROWS
-#undef WG_STORE
   if constexpr (COLSUM) {
     if (kt == 0 && threadIdx.x < 128)
       colsum_partial[((int64_t)(chunk_base + chunk) * mtiles + mt) * 128 + threadIdx.x] = colsum;
@@ -265,13 +256,26 @@ __global__ __launch_bounds__(256) void k_colsum_reduce(const float *__restrict__
   if (sub == 0) grad_b[m] = s;
 }
 
-// Edges per chunk: aim at ~1024 workgroups (4 per CU on 256 CUs) so the partial-tile traffic
-// (64 KiB per workgroup) stays ~10 % of the operand reads.
-inline int chunk_edges_for(int64_t num_edges, int mtiles, int ktiles) {
-  int64_t ch = (num_edges * mtiles * ktiles + 1023) / 1024;
+// Edges per chunk.  The kernel is resident three workgroups to a CU (__launch_bounds__(256, 3)), i.e. 768 at a time
+// on an MI355X, and every workgroup does the same work -- so the launch should be ONE wave of workgroups: round 2
+// aimed at ~1024 ("4 per CU"), which ran as 1.3 rounds, a third of the chip idle through the second (the dense GRU
+// weight gradient: 987 workgroups, 171 us against a 72 us MFMA floor).  `slots` whole rounds, with room for the one
+// extra chunk every edge type may add.
+constexpr int kWgradPerCu = 3;
+inline int chunk_edges_for(int64_t num_edges, int mtiles, int ktiles, int num_types = 1) {
+  const int64_t slots = (int64_t)kWgradPerCu * num_compute_units();
+  const int64_t tiles = (int64_t)mtiles * ktiles;
+  int64_t rounds = 1;
+  int64_t ch;
+  for (;;) {   // smallest number of rounds whose chunks are not longer than the pipeline can use
+    int64_t budget = slots * rounds / tiles - num_types;
+    if (budget < 1) budget = 1;
+    ch = (num_edges + budget - 1) / budget;
+    if (ch <= 8192 || rounds >= 64) break;
+    ++rounds;
+  }
   ch = (ch + STEP - 1) / STEP * STEP;
   if (ch < 256) ch = 256;
-  if (ch > 8192) ch = 8192;
   return (int)ch;
 }
 
@@ -284,7 +288,7 @@ extern "C" size_t ptgnn_amd_edge_wgrad_workspace_bytes(int64_t num_edges, int32_
                                                        int32_t msg_dim, int32_t in_dim) {
   if (num_edges <= 0 || num_types <= 0 || msg_dim <= 0 || in_dim <= 0) return 0;
   const int mtiles = (msg_dim + 127) / 128, ktiles = (in_dim + 127) / 128;
-  const int ch = chunk_edges_for(num_edges, mtiles, ktiles);
+  const int ch = chunk_edges_for(num_edges, mtiles, ktiles, num_types);
   const int64_t chunks = num_edges / ch + num_types;   // upper bound of sum_t ceil(E_t / ch)
   return (size_t)chunks * mtiles * (ktiles * kTile + 128) * sizeof(float);   // tiles + column-sum partials
 }
@@ -316,7 +320,7 @@ static int weight_grad_launch(const float *x, int64_t ld_x, int64_t num_rows, in
     PTGNN_REQUIRE(edges_per_type[t] >= 0, PTGNN_AMD_EINVAL, "edge_weight_grad: negative edge count");
     E += edges_per_type[t];
   }
-  const int ch = chunk_edges_for(E, mtiles, ktiles);
+  const int ch = chunk_edges_for(E, mtiles, ktiles, num_types);
   PTGNN_REQUIRE(workspace_bytes >= ptgnn_amd_edge_wgrad_workspace_bytes(E, num_types, msg_dim, K) &&
                     (E == 0 || workspace),
                 PTGNN_AMD_EINVAL, "edge_weight_grad: workspace too small (%zu bytes)", workspace_bytes);

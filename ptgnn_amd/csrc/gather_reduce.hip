@@ -24,6 +24,7 @@
 //     without hubs costs one ~2 us launch whose workgroups read a zero count and exit.
 // Algorithmic bytes per edge: 4*M (message row) + 4 (col) ; per node: 4*M (out) [+ 4*M dst term].
 #include <float.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -33,6 +34,7 @@ namespace ptgnn_amd {
 namespace {
 
 constexpr int kHubChunk = 1024;  // CSR slots per hub chunk; hub_threshold must be >= 2 * kHubChunk
+constexpr int kLongRow = 256;    // rows beyond this many in-edges fold in their own launch (k_long_rows)
 
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -66,6 +68,7 @@ struct Args {
   const int32_t *mask_arg;   // MASKED: [num source rows of this launch, M] winning forward slot
   const int32_t *mask_slot;  // MASKED: [E] forward slot of each slot of THIS plan
   int32_t hub_threshold;     // rows with more in-edges are left to the hub kernels (0 = no hub path)
+  int32_t long_threshold;    // rows with more in-edges (up to hub_threshold) are left to k_long_rows (0 = none)
   float *hub_part;           // [2 * num_chunks, M] chunk partials
   int32_t *hub_arg;          // [2 * num_chunks, M] (argout only)
   int32_t *hub_tickets;      // [num_chunks * col_blocks] arrival counters, zero between launches
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
   if (row >= a.num_nodes) return;  // whole lane-group exits together (no cross-group shuffles)
   const int beg = a.rowptr[row], end = a.rowptr[row + 1];
   if (a.hub_threshold > 0 && end - beg > a.hub_threshold) return;  // hub: the chunk kernel owns it
+  if (a.long_threshold > 0 && end - beg > a.long_threshold) return;  // long row: k_long_rows owns it
   // column block (only > 0 when msg_dim exceeds LPR*VEC*CH; epilogues are then disabled by host)
   RowOp<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED> op(a, threadIdx.x % LPR,
                                                          blockIdx.y * (LPR * VEC * CH));
@@ -402,6 +406,40 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
   if constexpr (UP == 0) op.reduce(row, beg, end, 1);
   else op.template reduce_pf<UP, HAS_DST && DST1>(row, beg, end, 1);
   op.finish_and_store(row, end - beg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// long rows (long_threshold < in-degree <= hub_threshold), on the side stream next to the main launch
+// ------------------------------------------------------------------------------------------------
+// A row of 2048 in-edges folded by one lane group of the main kernel is 256 dependent round trips (~0.5 ms on a
+// 2.6 ms launch): wherever it starts, the launch cannot end before it does, and on a power-law graph some start
+// late.  These rows fold in the SAME slot order (bit-identical sums) but 16 slots per round trip, in a launch of
+// their own that starts together with the main one.  A wave scans 64 consecutive rowptr entries per load and visits
+// the long rows among them one at a time on its first LPR lanes.
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_ARG>
+__global__ __launch_bounds__(256) void k_long_rows(Args a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t base = wave * 64; base < a.num_nodes; base += nwaves * 64) {
+    const int64_t r = base + lane;
+    int beg = 0, deg = 0;
+    if (r < a.num_nodes) {
+      beg = a.rowptr[r];
+      deg = a.rowptr[r + 1] - beg;
+    }
+    unsigned long long todo = __ballot(deg > a.long_threshold && deg <= a.hub_threshold);
+    while (todo) {
+      const int b = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int rbeg = __shfl(beg, b, 64), rdeg = __shfl(deg, b, 64);
+      if (lane < LPR) {
+        RowOp<VEC, LPR, CH, REDUCE, false, HAS_ARG, false> op(a, lane, blockIdx.y * (LPR * VEC * CH));
+        op.template reduce_pf<16>(base + b, rbeg, rbeg + rdeg, 1);
+        op.finish_and_store(base + b, rdeg);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -494,12 +532,76 @@ __global__ __launch_bounds__(256) void k_hub_chunks(Args a) {
 // ------------------------------------------------------------------------------------------------
 // launch plumbing
 // ------------------------------------------------------------------------------------------------
+// The hub launch is independent of the main launch (disjoint rows), both are bandwidth-bound, and each has a tail
+// (the main kernel: its last long rows, one wave each; the hub kernel: the last chunks of the largest hub) -- so the
+// hub kernel runs on a SIDE stream of the library, forked from and joined back into the caller's stream with events
+// (the fork-join pattern that is also legal under stream capture): the two overlap instead of queueing.
+// PTGNN_AMD_HUB_STREAM=0 keeps both on the caller's stream (A/B).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+
+SideStream *side_stream() {
+  static SideStream per_device[16];
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char *e = getenv("PTGNN_AMD_HUB_STREAM");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideStream &s = per_device[dev];
+  if (s.stream == nullptr) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    // creating streams / events is not a capturable operation: a first use inside a capture stays on one stream
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      s.stream = nullptr;
+      return nullptr;
+    }
+    (void)st;
+  }
+  return &s;
+}
+
 template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED>
 int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
   constexpr int ROWS_PER_BLOCK = 256 / LPR;
   Args a = a0;
   a.num_tiles = (a.num_nodes + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   dim3 grid((unsigned)xcd_padded_blocks(a.num_tiles), (unsigned)col_blocks);
+  SideStream *side = nullptr;
+  // large plans only: on a minibatch-sized graph the launches are ~0.1 ms, have no tail worth hiding, and the
+  // fork / join events cost more than they save (measured on cfg3: +20 us per aggregation)
+  if (a.hub_threshold > 0 && a.num_edges >= ((int64_t)1 << 21)) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cs);
+    static bool created_outside_capture = false;
+    if (cs == hipStreamCaptureStatusNone || created_outside_capture) side = side_stream();
+    if (side && cs == hipStreamCaptureStatusNone) created_outside_capture = true;
+  }
+  if (side) {   // fork: the hub kernel goes first, on the side stream
+    PTGNN_HIP(hipEventRecord(side->fork, stream));
+    PTGNN_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+    if constexpr (VEC == 4 && CH == 1 && !HAS_DST && !MASKED) {
+      {
+        a.long_threshold = kLongRow;
+        const int64_t lb = (a.num_nodes + 255) / 256;
+        dim3 lgrid((unsigned)(lb < 2048 ? lb : 2048), (unsigned)col_blocks);
+        k_long_rows<VEC, LPR, CH, REDUCE, HAS_ARG><<<lgrid, 256, 0, side->stream>>>(a);
+        PTGNN_LAUNCH_CHECK();
+      }
+    }
+    int64_t chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;
+    dim3 hgrid((unsigned)(chunks < 1024 ? chunks : 1024), (unsigned)col_blocks);
+    k_hub_chunks<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED><<<hgrid, 256, 0, side->stream>>>(a);
+    PTGNN_LAUNCH_CHECK();
+    PTGNN_HIP(hipEventRecord(side->join, side->stream));
+  }
   // one edge type (type_bits == 0): the destination term of a row is one row -> the DST1 variant loads it once
   constexpr bool kDst1Variant = VEC == 4 && HAS_DST && !MASKED;
   if (kDst1Variant && a.type_bits == 0)
@@ -507,6 +609,10 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
   else
     k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED><<<grid, 256, 0, stream>>>(a);
   PTGNN_LAUNCH_CHECK();
+  if (side) {   // join: the caller's stream continues once the hub rows are written too
+    PTGNN_HIP(hipStreamWaitEvent(stream, side->join, 0));
+    return PTGNN_AMD_OK;
+  }
   if (a.hub_threshold > 0) {
     // the list length lives on the device: a fixed grid strides over it (zero entries => instant exit)
     int64_t chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;

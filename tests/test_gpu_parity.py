@@ -1071,6 +1071,38 @@ def test_training_gradients_match_oracle_autograd(kind, agg, path, monkeypatch):
 # ------------------------------------------------------------------------------------------------
 # hub rows (power-law graphs, BASELINE config 5 shape scaled to one GPU)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("reduce,dim", [("sum", 64), ("max", 64), ("sum", 256), ("mean", 128)])
+def test_long_rows_launch_keeps_the_serial_fold_order(reduce, dim):
+    """Plans of >= 2 M edges fold rows of 257 .. 2048 in-edges in a launch of their own (k_long_rows, on the library's
+    side stream, 16 slots per round trip) -- in the SAME slot order: sums over rows up to the hub threshold stay
+    bit-identical to the CPU scatter, max with its arg exact."""
+    from oracle import scatter_ref
+    from ptgnn_amd import ops, workloads
+    N, E = 150_000, 2_200_000
+    adj = workloads.power_law_graph(N, E, alpha=0.9, seed=13)
+    src, dst = adj[0]
+    deg = torch.bincount(dst, minlength=N)
+    assert int(((deg > 256) & (deg <= ops.HUB_THRESHOLD)).sum()) >= 20 and int((deg > ops.HUB_THRESHOLD).sum()) >= 2
+    y = workloads.node_states(N, dim, seed=4)
+    plan = ops.build_plan(to_cuda_adj(adj), N)
+    res = ops.gather_reduce(y.cuda(), plan, dim, reduce, return_arg=reduce == "max")
+    got = (res[0] if isinstance(res, tuple) else res).cpu()
+    msgs = y[src]
+    want = scatter_ref.scatter(msgs, dst, dim=0, dim_size=N, reduce=reduce)
+    small = deg <= ops.HUB_THRESHOLD
+    if reduce == "max":
+        np.testing.assert_array_equal(got.numpy(), want.numpy())
+        want_arg = scatter_ref.scatter_max(msgs, dst, 0, dim_size=N)[1]
+        arg = res[1].cpu().long()
+        perm = plan.perm[:E].cpu().long()
+        got_edge = torch.where(arg >= 0, perm[arg.clamp(min=0)], torch.full_like(arg, E))
+        np.testing.assert_array_equal(got_edge.numpy(), want_arg.numpy())
+    elif reduce == "sum":
+        np.testing.assert_array_equal(got[small].numpy(), want[small].numpy())
+    else:
+        np.testing.assert_allclose(got[small].numpy(), want[small].numpy(), rtol=0, atol=1e-6)
+
+
 @pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
 @pytest.mark.parametrize("with_dst", [False, True])
 def test_hub_rows_match_oracle(reduce, with_dst):
