@@ -362,7 +362,7 @@ def pmc_traffic(workload, kernel):
     cannot be read from inside a plain bench run, so the figure is the profiled one and names its source; null
     when no profile holds the kernel."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(root, f"{rnd}_{workload}_traffic.json")
         try:
             with open(path) as f:
@@ -596,8 +596,15 @@ def config5_shard(dev, parity=True):
             with torch.no_grad():
                 return layer(x, cadj, None, {}, {}, [None])
         dt, out = clock(step)
+        timer = ops.KernelTimer()       # per-kernel HIP-event pass over 3 more steps
+        ops.set_kernel_timer(timer)
+        for _ in range(3):
+            step()
+        ops.set_kernel_timer(None)
+        ktab = {k: {kk: v[kk] for kk in ("calls", "avg_ms", "bound", "achieved", "unit", "frac")}
+                for k, v in kernel_table(timer.summary()).items()}
         entry = {"ms_per_layer_step": round(dt * 1e3, 3), "edges_per_sec_per_layer": round(E / dt, 1),
-                 "nodes_per_sec_per_layer": round(N / dt, 1)}
+                 "nodes_per_sec_per_layer": round(N / dt, 1), "kernels": ktab}
         if parity:
             entry["parity"] = sampled_layer_parity(kind, spec, adj, x_cpu, out, deg)
             ok = ok and entry["parity"]["ok"]

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from ptgnn_amd import ops
-from ptgnn_amd.layers import AbstractMessagePassingLayer, forward_scope
+from ptgnn_amd.layers import AbstractMessagePassingLayer, ConcatResidualLayer, forward_scope, set_output_hint
 
 try:
     from ptgnn.neuralmodels.gnn.structs import GnnOutput  # type: ignore
@@ -140,12 +140,25 @@ class GraphNeuralNetwork(ModuleWithMetrics):
             ops.plan_for(adjacency_lists, node_representations.shape[0])
         all_states = [node_representations]
         with forward_scope():   # tied layers share their stacked weights within this forward
-            for mp_layer in self.__message_passing_layers:            # :122-131
+            layers = list(self.__message_passing_layers)
+            for li, mp_layer in enumerate(layers):                    # :122-131
+                buf = None
+                nxt = layers[li + 1] if li + 1 < len(layers) else None
+                if (isinstance(nxt, ConcatResidualLayer) and node_representations.is_cuda and not return_all_states
+                        and node_representations.dtype == torch.float32
+                        and not (torch.is_grad_enabled() and (node_representations.requires_grad or self.training))):
+                    # the layer in front of a concat residual writes into the right half of the residual's result
+                    out_dim = mp_layer.output_state_dimension
+                    buf = nxt.make_result_buffer(node_representations.shape[0], out_dim, node_representations)
+                    set_output_hint(buf[:, buf.shape[1] - out_dim:])
                 node_representations = mp_layer(
                     node_states=node_representations, adjacency_lists=adjacency_lists,
                     node_to_graph_idx=node_to_graph_idx, reference_node_ids=reference_node_ids,
                     reference_node_graph_idx=reference_node_graph_idx,
                     edge_features=edge_feature_embeddings)
+                set_output_hint(None)
+                if buf is not None and node_representations.data_ptr() == buf[:, buf.shape[1] - out_dim:].data_ptr():
+                    node_representations._ptgnn_amd_concat_buffer = buf
                 all_states.append(node_representations)
         if return_all_states:
             node_representations = torch.cat(all_states, dim=-1)

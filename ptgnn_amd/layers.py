@@ -108,6 +108,24 @@ def _scoped(owner, name, make):
     return val
 
 
+# Output hint: ptgnn_amd.gnn.GraphNeuralNetwork knows which layer feeds a ConcatResidualLayer; it hands that layer the
+# right half of the [N, D0 + D1] buffer the residual will return, so the layer's last kernel writes there and the
+# residual only has to fill in the left half instead of torch.cat-ing both (inference only; a layer is free to
+# ignore the hint -- the residual checks what it actually got).
+def set_output_hint(buf: Optional[torch.Tensor]) -> None:
+    _SCOPE.out_hint = buf
+
+
+def _take_output_hint(rows: int, cols: int, like: torch.Tensor) -> Optional[torch.Tensor]:
+    hint = getattr(_SCOPE, "out_hint", None)
+    _SCOPE.out_hint = None
+    if hint is None or torch.is_grad_enabled() and like.requires_grad:
+        return None
+    if tuple(hint.shape) != (rows, cols) or hint.dtype != torch.float32 or hint.device != like.device:
+        return None
+    return hint
+
+
 def _no_grad_needed(*tensors) -> bool:
     if not torch.is_grad_enabled():
         return True
@@ -276,7 +294,8 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
             else:
                 y = ops.linear(node_states, self._stacked_edge_weights())      # [N, T*M]
                 agg = ops.gather_reduce(y, plan, M, self.__aggregation_fn)
-            return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
+            return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh,
+                                out=_take_output_hint(num_nodes, self.__state_dimension, node_states))
 
         no_feats = self._edge_feature_dimension == 0 and not any(
             f is not None and f.shape[-1] != 0 for f in edge_features)
@@ -759,7 +778,17 @@ class MeanResidualLayer(_ResidualBase):
 class ConcatResidualLayer(_ResidualBase):
     def forward(self, node_states, adjacency_lists, node_to_graph_idx, reference_node_ids,
                 reference_node_graph_idx, edge_features):
-        return torch.cat((self._pop(), node_states), dim=-1)
+        orig = self._pop()
+        buf = getattr(node_states, "_ptgnn_amd_concat_buffer", None)
+        if (buf is not None and buf.shape[1] == orig.shape[1] + node_states.shape[1] and buf.dtype == orig.dtype
+                and node_states.data_ptr() == buf[:, orig.shape[1]:].data_ptr()):
+            # the previous layer wrote straight into the right half of the result (see set_output_hint)
+            buf[:, : orig.shape[1]].copy_(orig)
+            return buf
+        return torch.cat((orig, node_states), dim=-1)
+
+    def make_result_buffer(self, num_nodes: int, next_dim: int, like: torch.Tensor) -> torch.Tensor:
+        return torch.empty(num_nodes, self._input_dim + next_dim, dtype=like.dtype, device=like.device)
 
     @property
     def output_state_dimension(self) -> int:

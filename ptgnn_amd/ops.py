@@ -823,19 +823,24 @@ def row_epilogue_backward(x: torch.Tensor, grad_y: torch.Tensor, flags: int, ln_
     return gx, gg, gb
 
 
-def gru_cell(a: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh) -> torch.Tensor:
+def gru_cell(a: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`out`: optional caller-owned [n, hd] fp32 destination with unit inner stride (e.g. the right half of the
+    buffer a concat residual returns)."""
     lib = _lib.load()
     _require_cuda_f32("a", a)
     _require_cuda_f32("h", h)
     a, h = _rowmajor(a), _rowmajor(h)
     n, m = a.shape
     hd = h.shape[1]
-    out = torch.empty(n, hd, dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty(n, hd, dtype=torch.float32, device=a.device)
+    elif tuple(out.shape) != (n, hd) or out.dtype != torch.float32 or out.stride(1) != 1 or not out.is_cuda:
+        raise _lib.PtgnnAmdError(f"gru_cell: `out` must be a float32 CUDA [{n}, {hd}] view with unit inner stride")
     with _timed("gru_cell", flops=2.0 * n * 3 * hd * (m + hd), bytes=4.0 * (n * (m + 2 * hd) + 3 * hd * (m + hd))):
         rc = lib.ptgnn_amd_gru_cell_f32(a.data_ptr(), _ld(a), h.data_ptr(), _ld(h),
                                         w_ih.contiguous().data_ptr(), w_hh.contiguous().data_ptr(),
                                         b_ih.contiguous().data_ptr(), b_hh.contiguous().data_ptr(),
-                                        n, m, hd, out.data_ptr(), hd, _stream(out))
+                                        n, m, hd, out.data_ptr(), _ld(out), _stream(out))
     _lib.check(rc, "ptgnn_amd_gru_cell_f32")
     return out
 

@@ -30,34 +30,28 @@ class AbstractVarSizedElementReduce(nn.Module):
         raise NotImplementedError
 
 
-# (weakref(index), version, is_sorted, upper) of the most recent index tensors: the sortedness test costs
-# one host read-back, so it is made once per index tensor (= once per minibatch), not once per layer.
-_INDEX_INFO = []
+_NUM_SAMPLES = []   # (weakref(index), version, max + 1) of the most recent index tensors
 
 
-def _index_info(index: torch.Tensor):
-    """(is_sorted, max + 1) of an element -> sample map.  The reference's reducers are plain
-    torch_scatter calls (varsizedsummary.py:35-41,76-81) and accept ANY map; only a non-decreasing one
-    (`node_to_graph_idx` of a disjoint-union batch, graphneuralnetwork.py:418-423,440-443) may take the
-    sort-free plan."""
-    for ref, ver, srt, upper in _INDEX_INFO:
+def _num_samples(index: torch.Tensor) -> int:
+    """`index.max() + 1` -- the reference's own host read-back (globalgraphexchange.py:40, once per LAYER there);
+    made once per index tensor, i.e. once per minibatch, here."""
+    for ref, ver, upper in _NUM_SAMPLES:
         if ref() is index and ver == index._version:
-            return srt, upper
-    if index.numel() == 0:
-        srt, upper = True, 0
-    else:
-        unsorted, last = torch.stack([(index[1:] < index[:-1]).any().to(torch.int64), index[-1]]).tolist()
-        srt = not unsorted
-        upper = int(last) + 1 if srt else int(index.max()) + 1
-    _INDEX_INFO.insert(0, (weakref.ref(index), index._version, srt, upper))
-    del _INDEX_INFO[4:]
-    return srt, upper
+            return upper
+    upper = int(index.max()) + 1 if index.numel() else 0
+    _NUM_SAMPLES.insert(0, (weakref.ref(index), index._version, upper))
+    del _NUM_SAMPLES[4:]
+    return upper
 
 
 def _index_plan(index: torch.Tensor, num_samples: int) -> "ops.GraphPlan":
-    if _index_info(index)[0]:
-        return ops.plan_from_sorted_index(index, int(num_samples))
-    return ops.build_plan([(index, index)], int(num_samples))      # arbitrary map: one stable sort
+    """Plan of an element -> sample map.  The reference's reducers are plain torch_scatter calls
+    (varsizedsummary.py:35-41,76-81) and accept ANY map, so every map takes the stable plan build -- cached per index
+    tensor (`ops.plan_for`), i.e. once per minibatch for all global-exchange layers.  Round 2 tested the map for
+    sortedness first to skip the sort for `node_to_graph_idx` (graphneuralnetwork.py:418-423,440-443); that test was
+    a host read-back per minibatch, which now costs more than the ~40 us of device time the sort takes."""
+    return ops.plan_for([(index, index)], int(num_samples))
 
 
 def _pool(values: torch.Tensor, index: torch.Tensor, num_samples, reduce: str) -> torch.Tensor:
@@ -112,9 +106,7 @@ class AbstractGlobalGraphExchange(AbstractMessagePassingLayer):
         if node_states.dtype in (torch.float16, torch.bfloat16):   # AMP: fp32 inside, caller's dtype outside
             return self.forward(node_states.float(), adjacency_lists, node_to_graph_idx, reference_node_ids,
                                 reference_node_graph_idx, edge_features).to(node_states.dtype)
-        # the reference's `node_to_graph_idx.max() + 1` (globalgraphexchange.py:40) is a host read-back;
-        # the same read-back here also tells whether the map is sorted (disjoint-union batches are)
-        num_graphs = _index_info(node_to_graph_idx)[1]
+        num_graphs = _num_samples(node_to_graph_idx)
         e = ElementsToSummaryRepresentationInput(node_states, node_to_graph_idx, num_graphs)
         graph_reps = self.__dropout(self.__global_graph_representation_module(e))
         if graph_reps.dtype != torch.float32:
