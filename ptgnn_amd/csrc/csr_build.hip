@@ -2,32 +2,31 @@
 // See include/ptgnn_amd.h (ptgnn_amd_csr_build) for the contract and the reference lines replaced.
 //
 // The plan is a STABLE sort of the edges by plan row (the order of a numpy stable argsort: tests compare bit
-// for bit), built MSD-first by hand-written kernels only -- no vendor sort, no vendor scan:
+// for bit), built by hand-written kernels only -- no vendor sort, no vendor scan:
 //
-//   k_split_count    per tile of the edge list: LDS histogram of the HIGH row bits (reads only the key column of
-//                    the int64 lists), stored as the tile's row of the aggregate table; digit totals by one
-//                    global atomic per (tile, digit) into the control block
-//   k_split_scatter  one pass over the lists: stable scatter of compact records into <= 512 buckets of
-//                    consecutive rows.  Cross-tile prefix of a digit = column sum of the aggregate rows of all
-//                    earlier tiles (complete: previous launch) -- no flags, no inter-workgroup ordering
-//   k_plan_buckets   one workgroup per bucket: stable counting sort by the LOW row bits -> rowptr, col, perm and
-//                    the hub list; the last workgroup puts the control block back to its zero-at-rest state
+//   k_split_count    per sub-tile of the edge list: LDS histogram of one digit of the key (reads only the key column
+//                    of the int64 lists), stored as the tile's row of the aggregate table
+//   k_tile_scan      aggregate table -> exclusive prefix over the tiles, in place, + the digit totals
+//   k_split_scatter  one pass over the lists: stable scatter by that digit.  Ranks: a wave owns a CONTIGUOUS run of
+//                    records and walks it in rounds of 64; the rank of a record among the equal digits of its round is
+//                    a ballot match, the count of its wave's earlier rounds sits in a WAVE-PRIVATE LDS counter row (no
+//                    workgroup barrier per round).  The records then leave through LDS in sorted order, so that the
+//                    global stores of a digit are contiguous runs: written straight from the ranking lanes every record
+//                    is its own partial-line write request, and the request rate of the L2s (~50 per clock chip-wide),
+//                    not bytes, bounds these kernels (profiles/r03_notes.md)
+//   k_plan_buckets   MSD form only: one workgroup per bucket of consecutive rows: stable counting sort by the low row
+//                    bits -> rowptr, col, perm and the hub list; the bucket's window is staged in LDS
 //
-// Ranking ("many keys per thread, ranks in registers"): a wave owns a CONTIGUOUS run of records and walks it in
-// rounds of 64; the rank of a record among the equal digits of its round is a ballot match, the count of its
-// wave's earlier rounds sits in a WAVE-PRIVATE LDS counter row -- no workgroup barrier per round (round 2 ranked
-// every 1024 records with three barriers and a 16-wave prefix; that LDS-latency chain bounded the build).  Two
-// barriers per tile turn the wave rows into global positions.  Ranks stay in registers between the two.
-//
-// Sizes:
-//   * row ids <= 18 bits and <= 4 M edges (every minibatch): 8-byte records (low row bits | position, payload),
-//     buckets of <= 512 rows;
-//   * anything larger (cfg5 shard: 1.25 M rows / 12.5 M edges; backward plans over rows = src * T + type):
-//     12-byte records, buckets of up to 4096 rows whose wave-private counters are packed 16-bit pairs
-//     (144 KB of LDS per workgroup -- CDNA4's 160 KB is what makes the two-level form reach 21 bits);
-//   * more than 21 row bits: the lowest bits are peeled off first by LSD pre-passes of the same two kernels
-//     (stable, so the MSD levels that follow keep their order), and rowptr comes from the sorted keys.
-// HBM-bound integer work; the lists are read 1.5 times (8 + 16 B/edge), records written and read once.
+// Forms (choose_path):
+//   * MSD, row ids <= 18 bits and <= 4 M edges (every minibatch): count / scan / scatter on the high bits with 8-byte
+//     records (low row bits | position, payload), then k_plan_buckets over <= 512-row buckets;
+//   * MSD, <= 21 bits and <= 4 M edges (backward plans over rows = src * T + type): 12-byte records, buckets of up to
+//     4096 rows whose wave-private counters are packed 16-bit pairs (144 KB of LDS per workgroup);
+//   * LSD, anything larger (BASELINE config 5: 1.25 M rows / 12.5 M edges per GPU): ceil(bits / 9) passes of count /
+//     scan / scatter from the low digit up, the last one writing col / perm / sorted keys, rowptr from the keys.  Every
+//     pass is tiled over the input order, so a power-law hub costs nothing extra (the workgroup that owns a hub's
+//     bucket in the MSD form walked 200 k records alone: 0.66 ms).
+// HBM-bound integer work in principle; at minibatch size a chain of dependent launches.
 #include <stdlib.h>
 #include <string.h>
 

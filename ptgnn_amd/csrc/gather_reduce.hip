@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
 // late.  These rows fold in the SAME slot order (bit-identical sums) but 16 slots per round trip, in a launch of
 // their own that starts together with the main one.  A wave scans 64 consecutive rowptr entries per load and visits
 // the long rows among them one at a time on its first LPR lanes.
-template <int VEC, int LPR, int CH, int REDUCE, bool HAS_ARG>
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG>
 __global__ __launch_bounds__(256) void k_long_rows(Args a) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -434,8 +434,8 @@ __global__ __launch_bounds__(256) void k_long_rows(Args a) {
       todo &= todo - 1;
       const int rbeg = __shfl(beg, b, 64), rdeg = __shfl(deg, b, 64);
       if (lane < LPR) {
-        RowOp<VEC, LPR, CH, REDUCE, false, HAS_ARG, false> op(a, lane, blockIdx.y * (LPR * VEC * CH));
-        op.template reduce_pf<16>(base + b, rbeg, rbeg + rdeg, 1);
+        RowOp<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, false> op(a, lane, blockIdx.y * (LPR * VEC * CH));
+        op.template reduce_pf<16, HAS_DST>(base + b, rbeg, rbeg + rdeg, 1);   // HAS_DST: one edge type (host checks)
         op.finish_and_store(base + b, rdeg);
       }
     }
@@ -538,8 +538,9 @@ __global__ __launch_bounds__(256) void k_hub_chunks(Args a) {
 // (the fork-join pattern that is also legal under stream capture): the two overlap instead of queueing.
 // PTGNN_AMD_HUB_STREAM=0 keeps both on the caller's stream (A/B).
 struct SideStream {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
+  hipStream_t stream = nullptr;    // hub chunks
+  hipStream_t stream2 = nullptr;   // long rows
+  hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
 };
 
 SideStream *side_stream() {
@@ -557,8 +558,10 @@ SideStream *side_stream() {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     // creating streams / events is not a capturable operation: a first use inside a capture stays on one stream
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.join2, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
       s.stream = nullptr;
       return nullptr;
@@ -584,23 +587,29 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
     if (cs == hipStreamCaptureStatusNone || created_outside_capture) side = side_stream();
     if (side && cs == hipStreamCaptureStatusNone) created_outside_capture = true;
   }
-  if (side) {   // fork: the hub kernel goes first, on the side stream
+  bool long_launch = false;
+  if (side) {   // fork: hub chunks and long rows each on a side stream of their own, next to the main launch
     PTGNN_HIP(hipEventRecord(side->fork, stream));
     PTGNN_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
-    if constexpr (VEC == 4 && CH == 1 && !HAS_DST && !MASKED) {
-      {
-        a.long_threshold = kLongRow;
-        const int64_t lb = (a.num_nodes + 255) / 256;
-        dim3 lgrid((unsigned)(lb < 2048 ? lb : 2048), (unsigned)col_blocks);
-        k_long_rows<VEC, LPR, CH, REDUCE, HAS_ARG><<<lgrid, 256, 0, side->stream>>>(a);
-        PTGNN_LAUNCH_CHECK();
-      }
-    }
     int64_t chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;
     dim3 hgrid((unsigned)(chunks < 1024 ? chunks : 1024), (unsigned)col_blocks);
     k_hub_chunks<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED><<<hgrid, 256, 0, side->stream>>>(a);
     PTGNN_LAUNCH_CHECK();
     PTGNN_HIP(hipEventRecord(side->join, side->stream));
+    // long rows: plain rows, and rows with a destination term when there is one edge type (the term is then one
+    // row per destination, loaded once -- the DST1 form of the main kernel)
+    if constexpr (VEC == 4 && CH == 1 && !MASKED) {
+      if (!HAS_DST || a.type_bits == 0) {
+        a.long_threshold = kLongRow;
+        long_launch = true;
+        PTGNN_HIP(hipStreamWaitEvent(side->stream2, side->fork, 0));
+        const int64_t lb = (a.num_nodes + 255) / 256;
+        dim3 lgrid((unsigned)(lb < 2048 ? lb : 2048), (unsigned)col_blocks);
+        k_long_rows<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG><<<lgrid, 256, 0, side->stream2>>>(a);
+        PTGNN_LAUNCH_CHECK();
+        PTGNN_HIP(hipEventRecord(side->join2, side->stream2));
+      }
+    }
   }
   // one edge type (type_bits == 0): the destination term of a row is one row -> the DST1 variant loads it once
   constexpr bool kDst1Variant = VEC == 4 && HAS_DST && !MASKED;
@@ -609,8 +618,9 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
   else
     k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED><<<grid, 256, 0, stream>>>(a);
   PTGNN_LAUNCH_CHECK();
-  if (side) {   // join: the caller's stream continues once the hub rows are written too
+  if (side) {   // join: the caller's stream continues once the hub and long rows are written too
     PTGNN_HIP(hipStreamWaitEvent(stream, side->join, 0));
+    if (long_launch) PTGNN_HIP(hipStreamWaitEvent(stream, side->join2, 0));
     return PTGNN_AMD_OK;
   }
   if (a.hub_threshold > 0) {

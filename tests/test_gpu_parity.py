@@ -1071,8 +1071,9 @@ def test_training_gradients_match_oracle_autograd(kind, agg, path, monkeypatch):
 # ------------------------------------------------------------------------------------------------
 # hub rows (power-law graphs, BASELINE config 5 shape scaled to one GPU)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("reduce,dim", [("sum", 64), ("max", 64), ("sum", 256), ("mean", 128)])
-def test_long_rows_launch_keeps_the_serial_fold_order(reduce, dim):
+@pytest.mark.parametrize("reduce,dim,with_dst", [("sum", 64, False), ("max", 64, False), ("sum", 256, False),
+                                                 ("mean", 128, False), ("sum", 128, True), ("max", 256, True)])
+def test_long_rows_launch_keeps_the_serial_fold_order(reduce, dim, with_dst):
     """Plans of >= 2 M edges fold rows of 257 .. 2048 in-edges in a launch of their own (k_long_rows, on the library's
     side stream, 16 slots per round trip) -- in the SAME slot order: sums over rows up to the hub threshold stay
     bit-identical to the CPU scatter, max with its arg exact."""
@@ -1084,10 +1085,12 @@ def test_long_rows_launch_keeps_the_serial_fold_order(reduce, dim):
     deg = torch.bincount(dst, minlength=N)
     assert int(((deg > 256) & (deg <= ops.HUB_THRESHOLD)).sum()) >= 20 and int((deg > ops.HUB_THRESHOLD).sum()) >= 2
     y = workloads.node_states(N, dim, seed=4)
+    yd = workloads.node_states(N, dim, seed=6) if with_dst else None     # one edge type: the MLP-MP destination term
     plan = ops.build_plan(to_cuda_adj(adj), N)
-    res = ops.gather_reduce(y.cuda(), plan, dim, reduce, return_arg=reduce == "max")
+    res = ops.gather_reduce(y.cuda(), plan, dim, reduce, ydst=yd.cuda() if with_dst else None,
+                            return_arg=reduce == "max")
     got = (res[0] if isinstance(res, tuple) else res).cpu()
-    msgs = y[src]
+    msgs = y[src] + yd[dst] if with_dst else y[src]
     want = scatter_ref.scatter(msgs, dst, dim=0, dim_size=N, reduce=reduce)
     small = deg <= ops.HUB_THRESHOLD
     if reduce == "max":

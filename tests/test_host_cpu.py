@@ -263,3 +263,15 @@ def test_committed_bench_line_keeps_the_driver_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["parity"]["max_abs"] <= d["parity"]["tol"] == 1e-5
+
+
+def test_library_carries_no_vendor_sort_or_scan(lib):
+    """The plan build is hand-written end to end (VERDICT r02 #2): no rocPRIM symbol or kernel name in the product .so."""
+    import subprocess
+    from ptgnn_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rocprim" not in out.lower()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"rocprim" not in blob, "a rocPRIM kernel or symbol is linked into libptgnn_amd.so"
+    src = open(os.path.join(os.path.dirname(_lib.LIB_PATH), "csr_build.hip")).read()
+    assert "#include <rocprim" not in src and "hipcub" not in src
