@@ -137,7 +137,19 @@ class AbstractGlobalGraphExchange(AbstractMessagePassingLayer):
         else:
             raise _lib.PtgnnAmdError(f"forward_sharded: cannot combine partial pools of {type(pool).__name__}")
         counts = torch.bincount(idx, minlength=G)[:G]
-        graph_reps = self.__dropout(sharded.combine_graph_pools(local, counts, kind, shard.group))
+        graph_reps = sharded.combine_graph_pools(local, counts, kind, shard.group)
+        p = self.__dropout.p if self.training else 0.0
+        if p > 0 and shard.world > 1:
+            # the unsharded layer draws ONE dropout mask per graph representation (globalgraphexchange.py:44-46); every
+            # rank holds the same combined representations, so the mask must be the same on every rank too: rank 0 of
+            # the group draws it, one small broadcast ([num_graphs, D]) carries it
+            import torch.distributed as dist
+            keep = (torch.rand_like(graph_reps) >= p).to(graph_reps.dtype) / (1.0 - p)
+            dist.broadcast(keep, src=dist.get_global_rank(shard.group, 0) if shard.group is not None else 0,
+                           group=shard.group)
+            graph_reps = graph_reps * keep
+        else:
+            graph_reps = self.__dropout(graph_reps)
         if _no_grad_needed(graph_reps):
             per_node = ops.gather_rows(graph_reps.contiguous(), idx)
         else:
