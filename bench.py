@@ -91,6 +91,9 @@ def dist_setup(args):
     backend = os.environ.get("PTGNN_AMD_BENCH_BACKEND", "nccl")
     if os.environ.get("PTGNN_AMD_BENCH_SHARE_GPU", "0") not in ("", "0"):
         local = 0
+        # two PROCESSES time-slicing one GPU turn every cross-stream event wait into a scheduling quantum (measured:
+        # 42 -> 345 ms per cfg5 step with the aggregation's side streams engaged): keep the library on one stream here
+        os.environ.setdefault("PTGNN_AMD_HUB_STREAM", "0")
     if world > 1 or args.force_sharded or args.sharded_variants:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -653,6 +656,11 @@ def sharded_cfg5(dev, rank, world, k=5):
     Per step: halo bookkeeping + plan build + halo all-to-all (RCCL) + edge-free table form."""
     from ptgnn_amd import layers as L, sharded, workloads
     N, E, H = 1_250_000, 12_500_000, 256
+    if (os.environ.get("PTGNN_AMD_BENCH_SHARE_GPU", "0") not in ("", "0")
+            and os.environ.get("PTGNN_AMD_BENCH_FULL_VARIANTS", "0") in ("", "0")):
+        # validation mode (every rank on cuda:0 over gloo, whose all-to-all stages 1.3 GB per rank through the host):
+        # the same code on a tenth of the shard -- the numbers of such a run mean nothing anyway
+        N, E = N // 10, E // 10
     lo = rank * N
     adj = workloads.power_law_graph(N, E, alpha=0.8, seed=1234 + rank)
     g = torch.Generator().manual_seed(99 + rank)
@@ -668,15 +676,18 @@ def sharded_cfg5(dev, rank, world, k=5):
         ops.clear_plan_cache()
         with torch.no_grad():
             return sharded.layer_forward(layer, state)
+    _log("  cfg5 shard: inputs built")
     dt = _clock_collective(step, k, 2, world, dev)
+    _log(f"  cfg5 shard: {dt * 1e3:.2f} ms/step (single block)")
     state["overlap"] = True      # two-block mode: own-source block aggregated under the halo all-to-all
     dt2 = _clock_collective(step, k, 2, world, dev)
+    _log(f"  cfg5 shard: {dt2 * 1e3:.2f} ms/step (two blocks, overlapped)")
     state["overlap"] = False
     shard = sharded.ShardedGraph.build(state["adj_global"], state["range"], all_ranges=state["all_ranges"])
     y = torch.empty(N, H, device=dev)
     t_x = 0.0 if shard.no_cut else _clock_collective(lambda: shard.exchange(y), k, 2, world, dev)
     halo = sum_over_ranks(shard.n_halo, world, dev)
-    return {"workload": f"cfg5 shard x{world}: one power-law graph of {world} x 1.25M nodes, 12.5M in-edges per GPU, "
+    return {"workload": f"cfg5 shard x{world}: one power-law graph of {world} x {N / 1e6:.3g}M nodes, {E / 1e6:.3g}M in-edges per GPU, "
                         f"sources uniform over all GPUs ({world - 1}/{world} of the edges cut), 1 GGNN layer H=M=256, sum",
             "ms_per_step": round(dt * 1e3, 3), "edges_per_sec_per_layer": round(E * world / dt, 1),
             "ms_per_step_two_block_overlap": round(dt2 * 1e3, 3),

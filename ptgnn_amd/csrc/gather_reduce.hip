@@ -580,7 +580,11 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
   SideStream *side = nullptr;
   // large plans only: on a minibatch-sized graph the launches are ~0.1 ms, have no tail worth hiding, and the
   // fork / join events cost more than they save (measured on cfg3: +20 us per aggregation)
-  if (a.hub_threshold > 0 && a.num_edges >= ((int64_t)1 << 21)) {
+  static const int64_t side_min_edges = [] {
+    const char *e = getenv("PTGNN_AMD_SIDE_MIN_EDGES");     // test knob: engage the side streams on small plans too
+    return e ? (int64_t)atoll(e) : ((int64_t)1 << 21);
+  }();
+  if (a.hub_threshold > 0 && a.num_edges >= side_min_edges) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cs);
     static bool created_outside_capture = false;

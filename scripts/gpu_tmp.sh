@@ -1,11 +1,8 @@
 #!/bin/bash
-out=gpurun_out/r03l; mkdir -p $out
-timeout 900 python -m pytest tests -x -q -m gpu -k "edge or config3 or config4 or golden or sharded" > $out/focus.log 2>&1; tail -3 $out/focus.log
-for e in 0 1; do
-PTGNN_AMD_EDGE_TWO_SLABS=$e timeout 600 python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('two_slabs=$e', d['ms_per_step'], {k:(v['avg_ms'],v['frac']) for k,v in d['kernels'].items()}, d['repeats']['ms_per_step_median'])"
+out=gpurun_out/r03p; mkdir -p $out
+export OMP_NUM_THREADS=4 PTGNN_AMD_BENCH_BACKEND=gloo PTGNN_AMD_BENCH_SHARE_GPU=1 PTGNN_AMD_BENCH_VARIANT_DEADLINE=60
+for side in 0 1; do
+if [ $side = 1 ]; then export PTGNN_AMD_SIDE_MIN_EDGES=0; fi
+timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 2961$side bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $out/b$side.json 2> $out/b$side.err
+echo "side=$side rc=$?"; grep "bench " $out/b$side.err | tail -8
 done
-python scripts/profile_cfg4.py 20
-PTGNN_AMD_EDGE_TWO_SLABS=0 python scripts/profile_cfg4.py 20

@@ -59,3 +59,36 @@ def test_bench_watchdog_emits_the_primary_line_when_a_rank_stalls():
     assert len(lines) == 1, tail
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["value"] > 0 and "timed out" in res["cut_edges_variant"]["error"], tail
+
+
+def test_bench_two_ranks_runs_the_sharded_variants_end_to_end():
+    """`bench.py --gpus 2` as the driver launches it, except over gloo with both ranks on cuda:0 (RCCL refuses two ranks
+    per device): the primary weak-scaling line plus BOTH dst-range-sharded workloads with real cut edges -- the cfg5
+    shard (HIP index pass, halo all-to-all, two-block mode) and the cfg4 stack in its graph-boundary and its
+    through-graphs partition -- must complete and explain themselves in the one JSON line."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-secondary"]
+    env = dict(os.environ, OMP_NUM_THREADS="4", PTGNN_AMD_BENCH_BACKEND="gloo", PTGNN_AMD_BENCH_SHARE_GPU="1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + "\n" + r.stderr)[-4000:]
+    assert r.returncode == 0, tail
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, tail
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
+    assert [p[0] for p in res["rccl_ranks_seen"]] == [0, 1]
+    v = res["cut_edges_variant"]
+    assert "error" not in v, tail
+    c5 = v["cfg5_shard"]
+    assert "error" not in c5 and "error" not in v["cfg4_stack"], tail
+    # (in this validation mode the cfg5 variant runs on a tenth of the shard: 125 k nodes per rank)
+    assert c5["ms_per_step"] > 0 and c5["halo_rows_all_ranks"] > 100_000 and not c5["no_cut"] and c5["all_to_all_ms"] > 0
+    c4 = v["cfg4_stack"]
+    assert c4["graph_boundaries"]["ms_per_forward"] > 0
+    tg = c4["through_graphs"]
+    assert tg["ms_per_forward"] > 0 and not tg["no_cut"] and tg["halo_rows_all_ranks"] > 0
