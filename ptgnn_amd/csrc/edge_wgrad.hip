@@ -22,6 +22,7 @@
 // un-permutes on its (much rarer) stores.
 #include "dense_common.h"
 #include "stream_gemm.h"
+#include "wgrad_stream.h"
 
 namespace ptgnn_amd {
 namespace {
@@ -290,7 +291,9 @@ extern "C" size_t ptgnn_amd_edge_wgrad_workspace_bytes(int64_t num_edges, int32_
   const int mtiles = (msg_dim + 127) / 128, ktiles = (in_dim + 127) / 128;
   const int ch = chunk_edges_for(num_edges, mtiles, ktiles, num_types);
   const int64_t chunks = num_edges / ch + num_types;   // upper bound of sum_t ceil(E_t / ch)
-  return (size_t)chunks * mtiles * (ktiles * kTile + 128) * sizeof(float);   // tiles + column-sum partials
+  const size_t tile_form = (size_t)chunks * mtiles * (ktiles * kTile + 128) * sizeof(float);   // tiles + column-sum partials
+  const size_t stream_form = stream_wgrad_workspace_floats(num_edges, num_types, msg_dim, in_dim) * sizeof(float);
+  return tile_form > stream_form ? tile_form : stream_form;
 }
 
 static int weight_grad_launch(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
@@ -347,6 +350,24 @@ static int weight_grad_launch(const float *x, int64_t ld_x, int64_t num_rows, in
       PTGNN_REQUIRE(chunk_base + chunks < ((int64_t)1 << 30), PTGNN_AMD_EUNSUPPORTED,
                     "edge_weight_grad: too many chunks");
       tab.chunk_off[t + 1] = (int32_t)chunks;
+    }
+    {   // the streaming form (wgrad_stream.hip) takes widths that are multiples of 32
+      WsTable ws;
+      ws.num_types = tab.num_types;
+      for (int t = 0; t < tab.num_types; ++t) {
+        ws.src[t] = tab.src[t];
+        ws.dst[t] = tab.dst[t];
+        ws.edge_off[t] = tab.edge_off[t];
+      }
+      ws.edge_off[tab.num_types] = tab.edge_off[tab.num_types];
+      const int taken = stream_wgrad(ws, x, ld_x, num_rows, state_dim, use_dst, grad_msg, ld_grad_msg, row_base, msg_dim,
+                                     dropout_p, dropout_seed, grad_w, t0, grad_b, (float *)workspace, workspace_bytes / sizeof(float), st);
+      PTGNN_REQUIRE(taken >= 0, PTGNN_AMD_EHIP, "edge_weight_grad: streaming launch failed");
+      if (taken == 1) {
+        row_base += tab.edge_off[tab.num_types];
+        chunk_base += tab.chunk_off[tab.num_types];
+        continue;
+      }
     }
     const int64_t total = (int64_t)tab.chunk_off[tab.num_types] * mtiles * ktiles;
     if (total > 0) {

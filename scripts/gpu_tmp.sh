@@ -1,8 +1,8 @@
 #!/bin/bash
 out=gpurun_out/r03p; mkdir -p $out
-export OMP_NUM_THREADS=4 PTGNN_AMD_BENCH_BACKEND=gloo PTGNN_AMD_BENCH_SHARE_GPU=1 PTGNN_AMD_BENCH_VARIANT_DEADLINE=60
-for side in 0 1; do
-if [ $side = 1 ]; then export PTGNN_AMD_SIDE_MIN_EDGES=0; fi
-timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 2961$side bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $out/b$side.json 2> $out/b$side.err
-echo "side=$side rc=$?"; grep "bench " $out/b$side.err | tail -8
-done
+cd "$(dirname "$0")/.."
+timeout 600 python -m pytest tests -x -q -m gpu -k "weight_grad or wgrad or training or golden or backward" > $out/focus.log 2>&1
+echo "focus rc=$?" >> $out/focus.log; tail -6 $out/focus.log
+timeout 200 python scripts/wgrad_bench.py > $out/wgrad_stream.json 2> $out/wgrad_stream.err; cat $out/wgrad_stream.json
+PTGNN_AMD_WGRAD_STREAM=0 timeout 200 python scripts/wgrad_bench.py > $out/wgrad_tile.json 2> $out/wgrad_tile.err; cat $out/wgrad_tile.json
+timeout 400 python bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; grep -i "train" $out/bench.err | tail -5
