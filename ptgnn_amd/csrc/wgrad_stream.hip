@@ -29,7 +29,10 @@
 namespace ptgnn_amd {
 namespace {
 
-constexpr int kDepth = 8;          // k-steps of rows in flight per wave
+#ifndef PTGNN_WS_DEPTH
+#define PTGNN_WS_DEPTH 8
+#endif
+constexpr int kDepth = PTGNN_WS_DEPTH;   // k-steps of rows in flight per wave
 constexpr int kWavesPerWg = 4;
 
 struct WsArgs {
@@ -73,17 +76,21 @@ __global__ __launch_bounds__(kWavesPerWg * 64, 1) void k_wgrad_stream(WsArgs p) 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WA = 32 * NBA, WB = 32 * NBB, D = kDepth;
   constexpr int kTileFloats = WA * WB;
+  // The tiles of one row group read the same rows: they take consecutive positions on ONE XCD (block b runs on XCD b % 8),
+  // so the second and third reader of a row hit that XCD's L2 instead of HBM.
+  const int wg = (int)xcd_swizzle(blockIdx.x, p.tab.wg_off[p.tab.num_types]);
+  if (wg >= p.tab.wg_off[p.tab.num_types]) return;      // ragged tail of the padded grid
   int t;
   {
     int lo = 0, hi_t = p.tab.num_types;
     while (hi_t - lo > 1) {
       const int mid = (lo + hi_t) >> 1;
-      if (p.tab.wg_off[mid] <= (int)blockIdx.x) lo = mid; else hi_t = mid;
+      if (p.tab.wg_off[mid] <= wg) lo = mid; else hi_t = mid;
     }
     t = lo;
   }
   const int tiles = p.mtiles * p.ktiles;
-  const int local = (int)blockIdx.x - p.tab.wg_off[t];
+  const int local = wg - p.tab.wg_off[t];
   const int g = local / tiles, tile = local - g * tiles;
   const int mt = tile / p.ktiles, kt = tile - mt * p.ktiles;
   const int64_t n_edges = p.tab.edge_off[t + 1] - p.tab.edge_off[t];
@@ -146,7 +153,77 @@ __global__ __launch_bounds__(kWavesPerWg * 64, 1) void k_wgrad_stream(WsArgs p) 
     // a drain of all rows in flight, once per block).
     __builtin_amdgcn_s_waitcnt(0);
     const int nblocks = (nsteps + D - 1) / D;
-    for (int j = 0; j < nblocks; ++j) {
+    int j = 0;
+    // Blocks whose own rows, refills (block j + 1) and id loads (block j + 2) all lie inside the wave's range take no
+    // masks and no clamps of the row index, and their addresses advance by constants: four or five vector ALU
+    // instructions a step instead of ~25.  That matters because fp32 MFMA shares the vector lanes with the VALU on
+    // gfx950 -- address arithmetic between the MFMAs is not hidden behind them (profiles/r02_notes.md).
+    const int nfull = (int)((e1 - e0) >> 1) / D;                          // blocks made of whole, valid steps
+    const int nfast = nfull > 2 ? nfull - 2 : 0;
+    if (nfast > 0) {
+      const char *pa = reinterpret_cast<const char *>(a_col + gm_off(e0 + 2 * D + hi));       // step D = block 1, slot 0
+      const uint64_t astep = 8ull * ldg;                                                       // two rows, in bytes
+      const unsigned ldxb = 4u * ldx;
+      const char *const bbase = reinterpret_cast<const char *>(b_col);
+      const char *pb = bbase + (uint64_t)(unsigned)(e0 + 2 * D + hi) * ldxb;                   // dense form: row e of x
+      const uint64_t bstep = 2ull * ldxb;
+      const int *pid = nullptr;
+      if constexpr (GATHER) pid = reinterpret_cast<const int *>(idx) + 2 * (e0 + hi) + 4 * (2 * D);   // block 2, slot 0
+      for (; j < nfast; ++j) {
+        if constexpr (GATHER) {
+#pragma unroll
+          for (int s = 0; s < D; ++s) nid2[s] = pid[4 * s];
+          pid += 4 * D;
+        }
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+          float bv[NBB];
+#pragma unroll
+          for (int i = 0; i < NBB; ++i) bv[i] = b[s][i];
+          if constexpr (DROP) {
+            const int64_t e = e0 + 2 * (int64_t)(j * D + s) + hi;
+            const float4 m4 = dropout_apply4(p.drop, gm_row0 + e, colb, make_float4(bv[0], bv[1], bv[2], bv[3]));
+            bv[0] = m4.x; bv[1] = m4.y; bv[2] = m4.z; bv[3] = m4.w;
+          }
+          if constexpr (COLSUM) {
+#pragma unroll
+            for (int i = 0; i < NBA; ++i) cs[i] += a[s][i];
+          }
+#ifdef PTGNN_WS_PROBE_NOMFMA
+          acc[0][0][s] += a[s][0] * bv[0] + a[s][NBA - 1] * bv[NBB - 1];
+#else
+#pragma unroll
+          for (int i = 0; i < NBA; ++i)
+#pragma unroll
+            for (int k = 0; k < NBB; ++k)
+              acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], bv[k], acc[i][k], 0, 0, 0);
+#endif
+          __builtin_amdgcn_sched_barrier(0);               // (see the fences of the masked loop below)
+#ifndef PTGNN_WS_PROBE_NOLOAD
+          load_vec<NBA>(reinterpret_cast<const float *>(pa), a[s]);
+          pa += astep;
+          if constexpr (GATHER) {
+            const unsigned u = (unsigned)nid1[s];
+            load_vec<NBB>(reinterpret_cast<const float *>(bbase + (uint64_t)(u < last_row ? u : last_row) * ldxb), b[s]);
+          } else {
+            load_vec<NBB>(reinterpret_cast<const float *>(pb), b[s]);
+            pb += bstep;
+          }
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (GATHER) {
+#pragma unroll
+          for (int s = 0; s < D; ++s) nid1[s] = nid2[s];
+        }
+      }
+      if constexpr (!GATHER) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) nid1[s] = raw_id(edge_at((j + 1) * D + s));
+      }
+    }
+    // the last blocks of the range (and ranges shorter than three blocks): masked rows, clamped indices
+    for (; j < nblocks; ++j) {
 #pragma unroll
       for (int s = 0; s < D; ++s) nid2[s] = raw_id(edge_at((j + 2) * D + s));
 #pragma unroll
@@ -194,7 +271,7 @@ __global__ __launch_bounds__(kWavesPerWg * 64, 1) void k_wgrad_stream(WsArgs p) 
   // here).  The sums are taken by all 256 threads from LDS, ((w0 + w1) + (w2 + w3)), and go straight to the partial.
   // C block (i, k), register r of lane (li, hi) = tile row NBA * ((r & 3) + 8 (r >> 2) + 4 hi) + i, column NBB * li + k
   {
-    float *const out = p.partial + (int64_t)blockIdx.x * kTileFloats;
+    float *const out = p.partial + (int64_t)wg * kTileFloats;
     constexpr int kPiece = NBB * 16 * 64;                 // floats of one wave's row of blocks
 #pragma unroll
     for (int i = 0; i < NBA; ++i) {
@@ -325,7 +402,7 @@ int stream_wgrad(const WsTable &tab_in, const float *x, int64_t ld_x, int64_t nu
   if (nba == 0 || nbb == 0) return 0;
   if (use_dst && state_dim % (32 * nbb) != 0) return 0;        // a k-tile must not straddle the [src ; dst] seam
   if (drop.thr != 0 && nbb != 4) return 0;
-  if (ld_x >= ((int64_t)1 << 31) || ld_gm >= ((int64_t)1 << 31) || num_rows >= ((int64_t)1 << 31)) return 0;
+  if (ld_x >= ((int64_t)1 << 29) || ld_gm >= ((int64_t)1 << 29) || num_rows >= ((int64_t)1 << 31)) return 0;
   const int WA = 32 * nba, WB = 32 * nbb;
   const int mtiles = msg_dim / WA, ktiles = K / WB, tiles = mtiles * ktiles;
   WsArgs p;
@@ -364,7 +441,7 @@ int stream_wgrad(const WsTable &tab_in, const float *x, int64_t ld_x, int64_t nu
     auto kern = gather ? k_wgrad_stream<NBA_, NBB_, DROP_, false, true>              \
                        : k_wgrad_stream<NBA_, NBB_, false, CS_, false>;              \
     if (!set_lds(kern, lds)) return 0;                                               \
-    kern<<<(unsigned)total, kWavesPerWg * 64, lds, st>>>(p);                         \
+    kern<<<(unsigned)xcd_padded_blocks(total), kWavesPerWg * 64, lds, st>>>(p);                         \
   } while (0)
 #define PTGNN_WS_NBB(NBA_)                                                           \
   do {                                                                               \
