@@ -354,6 +354,32 @@ __device__ __forceinline__ void store_block(const f32x16 &c, float *yp, int64_t 
   }
 }
 
+// bias + activation + store of one unit's NB column blocks; leaves the accumulators zeroed
+template <int NB>
+__device__ __forceinline__ void linear_epilogue(const LinearArgs &p, f32x16 (&acc)[NB], float *tq, int64_t row0,
+                                                int col_base, int lane, int li, int hi) {
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int col = col_base + n * 32 + li;
+    if (col_base + n * 32 < p.n_out) {   // n_out % 32 == 0: whole column blocks
+      const float bv = p.bias ? p.bias[col] : 0.f;
+      if (p.vec_store) {
+        float *yb = p.y + row0 * p.ld_y + col_base + n * 32;
+        const int64_t left = p.rows - row0;
+        if (p.act == PTGNN_AMD_ACT_TANH) store_block_tq<PTGNN_AMD_ACT_TANH>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
+        else if (p.act == PTGNN_AMD_ACT_RELU) store_block_tq<PTGNN_AMD_ACT_RELU>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
+        else store_block_tq<PTGNN_AMD_ACT_NONE>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
+      } else {
+        float *yp = p.y + (row0 + 4 * hi) * p.ld_y + col;
+        if (p.act == PTGNN_AMD_ACT_TANH) store_block<PTGNN_AMD_ACT_TANH>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
+        else if (p.act == PTGNN_AMD_ACT_RELU) store_block<PTGNN_AMD_ACT_RELU>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
+        else store_block<PTGNN_AMD_ACT_NONE>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
+      }
+    }
+    acc[n] = zero16();
+  }
+}
+
 template <int NB, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -415,26 +441,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
     unit_fence();
     unit_kloop<NB, NB, false, SPLIT>(acc, a0, a1, smem, sl, li, hi, rows, nch, nch);
     const int64_t row0 = (int64_t)(rb0 + cur) * 32;
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      const int col = col_base + n * 32 + li;
-      if (col_base + n * 32 < p.n_out) {   // n_out % 32 == 0: whole column blocks
-        const float bv = p.bias ? p.bias[col] : 0.f;
-        if (p.vec_store) {
-          float *yb = p.y + row0 * p.ld_y + col_base + n * 32;
-          const int64_t left = p.rows - row0;
-          if (p.act == PTGNN_AMD_ACT_TANH) store_block_tq<PTGNN_AMD_ACT_TANH>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
-          else if (p.act == PTGNN_AMD_ACT_RELU) store_block_tq<PTGNN_AMD_ACT_RELU>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
-          else store_block_tq<PTGNN_AMD_ACT_NONE>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
-        } else {
-          float *yp = p.y + (row0 + 4 * hi) * p.ld_y + col;
-          if (p.act == PTGNN_AMD_ACT_TANH) store_block<PTGNN_AMD_ACT_TANH>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
-          else if (p.act == PTGNN_AMD_ACT_RELU) store_block<PTGNN_AMD_ACT_RELU>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
-          else store_block<PTGNN_AMD_ACT_NONE>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
-        }
-      }
-      acc[n] = zero16();
-    }
+    linear_epilogue<NB>(p, acc, tq, row0, col_base, lane, li, hi);
     cur = nxt;
     nxt = nn;
     rows.c0 = rows.c1 = rows.n0;
@@ -603,7 +610,6 @@ constexpr int kRingWaves = 4;
 
 __global__ __launch_bounds__(kRingWaves * 64, 2) void k_stream_gru_ring(GruArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NT = kRingWaves * 64;
   const int b = blockIdx.x, G = gridDim.x;
   int slab, part;
   if (G % (kNumXcd * p.ncs) == 0) {
@@ -710,6 +716,109 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void k_stream_gru_ring(GruArgs 
     rows.c0 = rows.n0; rows.c1 = rows.n1;
     const int64_t r1 = clampr(u + 2 * kRingWaves);
     rows.n0 = p.a + r1 * p.ld_a + lofs; rows.n1 = p.h + r1 * p.ld_h + lofs;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// linear whose [128, K] weight slab does not fit LDS (K > ~300: the GRU's input gradients  d_a = d_gates . W_ih,
+// d_h = d_gates . W_hh  with K = 3 H = 384 at H = 128, which the slab kernel sent back to the tile kernel at 0.64 of
+// the MFMA peak): the same panel ring as k_stream_gru_ring, 128 output columns x 64 K columns per panel (2 x 34 KB),
+// four waves a workgroup, two workgroups a CU.  Same chunk order and k permutation as k_stream_linear and the tile
+// kernel: identical bits.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLinRingPanelFloats = 128 * kRingLd;
+
+__global__ __launch_bounds__(kRingWaves * 64, 2) void k_stream_linear_ring(LinearArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, G = gridDim.x;
+  int slab, part;
+  if (G % (kNumXcd * p.ncs) == 0) {
+    const int xcd = b % kNumXcd, j = b / kNumXcd;
+    slab = j % p.ncs;
+    part = xcd + kNumXcd * (j / p.ncs);
+  } else {
+    slab = b / p.rps;
+    part = b % p.rps;
+  }
+  const int rb0 = part * p.run_len;
+  const int rb1 = rb0 + p.run_len < p.nrb ? rb0 + p.run_len : p.nrb;
+  if (rb0 >= rb1) return;
+  const int count = rb1 - rb0;
+  const int rounds = (count + kRingWaves - 1) / kRingWaves;
+
+  const int K = p.K;
+  const int npan = K / kRingPanel, nch = K >> 5;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  float *const tq = smem + 2 * kLinRingPanelFloats + wave * kTqFloats;
+  const int col_base = slab * 128;
+
+  // this thread's eight float4 of a weight panel: element e = t + 256 q -> panel row (t >> 4) + 16 q, columns 4 (t & 15)
+  const int trow = threadIdx.x >> 4, tc4 = (threadIdx.x & 15) * 4;
+  const int wbase = (col_base + trow) * K + tc4;        // 32-bit offsets (see k_stream_gru_ring)
+  const int wq = 16 * K;
+  {
+    float *const d = smem + trow * kRingLd + tc4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      *reinterpret_cast<float4 *>(d + 16 * q * kRingLd) = *reinterpret_cast<const float4 *>(p.w + (wbase + q * wq));
+  }
+  __syncthreads();
+
+  const int lofs = lane_piece_offset<false>(hi);
+  auto rowp = [&](int u) {
+    int64_t row = (int64_t)(rb0 + (u < count ? u : count - 1)) * 32 + li;
+    row = row < p.rows ? row : p.rows - 1;
+    return p.x + row * p.ld_x + lofs;
+  };
+  ARows rows;
+  rows.c0 = rows.c1 = rowp(wave);
+  rows.n0 = rows.n1 = rowp(wave + kRingWaves);
+  float4 a0[4], a1[4];
+  prologue_loads<false>(a0, a1, rows, nch, nch);
+  f32x16 acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc[n] = zero16();
+  const int cbs = 32 * kRingLd;
+
+  int P = 0;                                          // panels consumed so far: panel P sits in buffer P & 1
+  for (int i = 0; i < rounds; ++i) {
+    const int u = i * kRingWaves + wave;              // may be past the run: computed on clamped rows, not stored
+    unit_fence();
+    for (int pan = 0; pan < npan; ++pan, ++P) {
+      const float *bl = smem + (P & 1) * kLinRingPanelFloats + li * kRingLd + hi * 4;
+      float *const nb = smem + ((P + 1) & 1) * kLinRingPanelFloats + trow * kRingLd + tc4;
+      const float *const src = p.w + (wbase + (pan + 1 < npan ? pan + 1 : 0) * kRingPanel);
+      float4 w0 = *reinterpret_cast<const float4 *>(src);
+      float4 w1 = *reinterpret_cast<const float4 *>(src + wq);
+      float4 w2 = *reinterpret_cast<const float4 *>(src + 2 * wq);
+      float4 w3 = *reinterpret_cast<const float4 *>(src + 3 * wq);
+      __builtin_amdgcn_sched_barrier(0);
+      float4 bcur[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) bcur[n] = *reinterpret_cast<const float4 *>(bl + n * cbs);
+      chunk_f32<4, 4, 0, false>(acc, a0, bcur, bl, cbs, 0, 32, rows, 2 * pan + 2, nch, nch);
+      *reinterpret_cast<float4 *>(nb) = w0;
+      *reinterpret_cast<float4 *>(nb + 16 * kRingLd) = w1;
+      *reinterpret_cast<float4 *>(nb + 32 * kRingLd) = w2;
+      *reinterpret_cast<float4 *>(nb + 48 * kRingLd) = w3;
+      w0 = *reinterpret_cast<const float4 *>(src + 4 * wq);
+      w1 = *reinterpret_cast<const float4 *>(src + 5 * wq);
+      w2 = *reinterpret_cast<const float4 *>(src + 6 * wq);
+      w3 = *reinterpret_cast<const float4 *>(src + 7 * wq);
+      __builtin_amdgcn_sched_barrier(0);
+      chunk_f32<4, 4, 0, false>(acc, a1, bcur, bl, cbs, 32, 0, rows, 2 * pan + 3, nch, nch);
+      *reinterpret_cast<float4 *>(nb + 64 * kRingLd) = w0;
+      *reinterpret_cast<float4 *>(nb + 80 * kRingLd) = w1;
+      *reinterpret_cast<float4 *>(nb + 96 * kRingLd) = w2;
+      *reinterpret_cast<float4 *>(nb + 112 * kRingLd) = w3;
+      lds_barrier();   // panel P + 1 is complete; everyone is done reading panel P
+    }
+    if (u < count) linear_epilogue<4>(p, acc, tq, (int64_t)(rb0 + u) * 32, col_base, lane, li, hi);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = zero16();
+    rows.c0 = rows.c1 = rows.n0;
+    rows.n0 = rows.n1 = rowp(u + 2 * kRingWaves);
   }
 }
 
@@ -907,7 +1016,11 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   const int bn = n_out >= 128 ? 128 : n_out;
   const int nb = bn / 32;
   bool split = mode == 2;
-  {
+  const char *ring_env = getenv("PTGNN_AMD_LINEAR_RING");                     // "1": force (A/B, parity tests at small K)
+  const bool force_ring = ring_env && ring_env[0] == '1', no_ring = ring_env && ring_env[0] == '0';
+  const bool ring_shape = n_out % 128 == 0 && (int64_t)n_out * k < ((int64_t)1 << 30) && rows >= 32 * 64;
+  const bool ring = ring_shape && (force_ring || (!no_ring && Slab<false>::bytes(k, bn) + kEpiBytes > (size_t)kLdsBudget));
+  if (!ring) {
     // measured (profiles/r02_notes.md): the persistent kernel pays one slab copy per workgroup and re-reads
     // A once per column slab, so in exact fp32 it only beats the tile kernel with >= 3 units per wave and
     // few slabs; the split mode has no tile counterpart and always streams
@@ -920,15 +1033,25 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
     slab = Slab<false>::bytes(k, bn);
   }
   const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
-  if (lds > (size_t)kLdsBudget) return 0;
   LinearArgs p;
   p.x = x; p.rows = rows; p.K = k; p.ld_x = ld_x; p.w = w; p.n_out = n_out; p.bias = bias; p.act = act;
   p.y = y; p.ld_y = ld_y;
   p.nrb = (int)((rows + 31) / 32);
   p.ncs = (n_out + bn - 1) / bn;
+  p.vec_store = (ld_y % 4 == 0 && aligned16(y)) ? 1 : 0;
+  if (ring) {
+    // the slab does not fit: stream the weights through the panel ring (exact fp32 in both arithmetic modes)
+    const size_t rlds = (size_t)(2 * kLinRingPanelFloats + kRingWaves * kTqFloats) * sizeof(float);
+    dense_runs(p.nrb, p.ncs, p.rps, p.run_len, 2 * num_compute_units());   // two 4-wave workgroups per CU
+    p.lds_floats = 0;
+    auto kern = k_stream_linear_ring;
+    if (!set_lds(kern, rlds)) return 0;
+    kern<<<(unsigned)(p.ncs * p.rps), kRingWaves * 64, rlds, st>>>(p);
+    return 1;
+  }
+  if (lds > (size_t)kLdsBudget) return 0;
   dense_runs(p.nrb, p.ncs, p.rps, p.run_len);
   p.lds_floats = (int)(slab / 4);
-  p.vec_store = (ld_y % 4 == 0 && aligned16(y)) ? 1 : 0;
   const unsigned grid = (unsigned)(p.ncs * p.rps);
 #define PTGNN_K(NBV, SP)                                                            \
   do {                                                                              \

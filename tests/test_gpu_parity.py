@@ -405,6 +405,44 @@ def test_gru_ring_kernel_is_bit_identical_to_the_other_gru_kernels(n, m, h, monk
     assert float((ring.cpu().double() - want64).abs().max()) <= TOL
 
 
+@pytest.mark.parametrize("rows,k,n_out,act", [
+    (5000, 384, 128, None),        # the GRU's input-gradient GEMM at H = 128: slab too large, ring by default
+    (4099, 128, 128, "tanh"),      # forced onto the ring where the resident slab fits: ragged last unit, activation
+    (33000, 256, 256, None),       # two column slabs
+    (2048, 512, 128, "relu"),      # the smallest row count the ring takes
+])
+def test_linear_ring_kernel_is_bit_identical_to_the_other_linear_kernels(rows, k, n_out, act, monkeypatch):
+    """Linear layers whose [128, K] weight slab does not fit LDS stream the weights through a two-panel ring
+    (stream_gemm.hip k_stream_linear_ring).  K is accumulated in the library's one fixed order, so the ring, the
+    slab-resident streaming kernel and the tile kernel give the same bits; float64 within 1e-5 relative to the size of
+    the sums."""
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(rows + k)
+    x, w, b = torch.randn(rows, k, generator=g), torch.randn(n_out, k, generator=g) / k ** 0.5, torch.randn(n_out, generator=g)
+    want = x.double() @ w.double().t() + b.double()
+    want = torch.tanh(want) if act == "tanh" else (torch.relu(want) if act == "relu" else want)
+    xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+    monkeypatch.setenv("PTGNN_AMD_LINEAR_RING", "1")
+    timer = ops.KernelTimer()
+    ring = ops.linear(xc, wc, bc, act=act)
+    strided = torch.empty(rows, n_out + 4, device="cuda")[:, 2:2 + n_out]      # rows not 16-byte aligned: dword stores
+    ops.linear(xc, wc, bc, act=act, out=strided)
+    monkeypatch.setenv("PTGNN_AMD_LINEAR_RING", "0")
+    other = ops.linear(xc, wc, bc, act=act)
+    prev = ops.set_gemm_mode("tile")
+    try:
+        tile = ops.linear(xc, wc, bc, act=act)
+    finally:
+        ops.set_gemm_mode(prev)
+    del timer
+    assert torch.equal(ring, strided)
+    if act == "tanh":      # the tile kernel's tanh is libm's
+        assert float((ring - tile).abs().max()) <= 1e-6 and float((ring - other).abs().max()) <= 1e-6
+    else:
+        assert torch.equal(ring, tile) and torch.equal(ring, other)
+    assert float((ring.cpu().double() - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
+
+
 def test_gather_rows():
     from ptgnn_amd import ops
     g = torch.Generator().manual_seed(1)
@@ -905,6 +943,36 @@ def test_edge_weight_grad_matches_fp64(use_dst, H, M):
     scale = max(1.0, float(want.abs().max()))
     # relative to the size of the sums (up to 5000-term fp32 dot products)
     assert float((got.cpu() - want).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("use_dst", [False, True])
+@pytest.mark.parametrize("H,M,counts", [
+    (128, 128, [150000, 0, 70001, 3, 40000]),      # 128 x 128 tiles, long unmasked runs + ragged tails, odd row counts
+    (256, 128, [60000, 1, 20000]),                 # two k-tiles (four with the target half)
+    (96, 96, [30000, 5000]),                       # 32-wide blocks, 3 x 3 (3 x 6) tiles per group
+    (64, 64, [17, 2500, 0, 64, 129]),              # 64-wide blocks, ranges shorter than one prefetch block
+])
+def test_streaming_weight_grad_shapes_match_fp64(use_dst, H, M, counts):
+    """Shapes the streaming weight-gradient kernel takes (widths that are multiples of 32, wgrad_stream.hip): every
+    tile shape, ranges long enough for the unmasked loop and short enough for the masked one only, empty and
+    one-row types, odd counts (the half-filled last MFMA step).  float64 reference; bit-identical run to run."""
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(H + 7 * M + len(counts))
+    n = 4000
+    adj = [(torch.randint(0, n, (c,), generator=g), torch.randint(0, n, (c,), generator=g)) for c in counts]
+    x = torch.randn(n, H, generator=g)
+    gm = torch.randn(sum(counts), M, generator=g)
+    off = np.cumsum([0] + counts)
+    want = torch.stack([gm[off[t]:off[t + 1]].double().t()
+                        @ (torch.cat([x[s], x[d]], -1) if use_dst else x[s]).double()
+                        for t, (s, d) in enumerate(adj)])
+    cadj = to_cuda_adj(adj)
+    got = ops.edge_weight_grad(x.cuda(), cadj, gm.cuda(), use_dst)
+    assert torch.equal(got, ops.edge_weight_grad(x.cuda(), cadj, gm.cuda(), use_dst))
+    # fp32 sums of up to 150 k products: the bound scales with sqrt(count) * |terms|
+    for t, c in enumerate(counts):
+        tol = 1e-5 * max(1.0, float(want[t].abs().max())) + 2e-6 * np.sqrt(max(c, 1))
+        assert float((got[t].cpu().double() - want[t]).abs().max()) <= tol, (t, c)
 
 
 @pytest.mark.parametrize("p", [0.1, 0.5])
