@@ -339,7 +339,7 @@ def kernel_table(summary):
     for name, d in summary.items():
         ms = d["ms"] / d["calls"]
         row = {"calls": d["calls"], "avg_ms": round(ms, 5)}
-        if name in ("linear", "gru_cell", "edge_linear", "edge_weight_grad", "linear_weight_grad"):
+        if name in ("linear", "gru_cell", "edge_linear", "edge_linear_shared", "edge_weight_grad", "linear_weight_grad"):
             tf = d["flops"] / d["calls"] / (ms * 1e-3) / 1e12
             row.update(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                        frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
@@ -890,6 +890,10 @@ def main():
         "config": {"workload": st["desc"], "nodes_per_gpu": st["N"], "edges_per_gpu": st["E"],
                    "hidden": st["H"], "mp_layers_per_step": layers, "mode": "forward (inference), fp32",
                    "plan_build_in_step": True,
+                   # GGNN edge form: one GEMM row per distinct (edge type, source) pair of the batch, read per edge by
+                   # the aggregation -- the unit of `value` stays the edge (ptgnn_amd.ops.GraphPlan.unique_messages)
+                   "message_rows": ("shared per (edge type, source) pair" if "edge_linear_shared" in summary
+                                    else "one per edge"),
                    "parallelism": ("single GPU" if world == 1 else
                                    f"{world} GPUs x whole graphs (one batch per GPU), no data-path collective")
                    if "adj" in st else (

@@ -153,6 +153,37 @@ int ptgnn_amd_shard_index(const int64_t *const *src_per_type, const int64_t *con
                           int64_t *stats, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Unique (edge type, source) pairs of a forward plan.  A GGNN message is W_t . x[src]
+ * (gatedmessagepassing.py:52-58: index_select of the source states, then the type's bias-free Linear): edges of one
+ * type that leave the same node carry the SAME message row, so the grouped per-edge GEMM only has to produce one row
+ * per pair that occurs and the aggregation reads it through slot_row.  Integer bookkeeping over the plan's col array
+ * (ptgnn_amd_csr_build, mode 0); the values of the layer do not change.
+ *   unique_src [capacity >= min(num_edges, num_src_rows * num_types)]: source node of every message row -- rows are
+ *       type-major, ascending in the source id inside a type (so unique_src + the prefix of counts IS the adjacency
+ *       input of ptgnn_amd_edge_linear_f32 for the de-duplicated launch);
+ *   counts (device int64 [num_types + 1]): rows per edge type, [num_types] = rows in all;
+ *   slot_row (int32 [num_edges]): message row of every CSR slot (the `col` argument of ptgnn_amd_gather_reduce_f32
+ *       with type_bits = 0, where the per-edge form passes the plan's perm).
+ * Nothing synchronises with the host.
+ * ---------------------------------------------------------------------------------------- */
+size_t ptgnn_amd_unique_sources_workspace_bytes(int64_t num_src_rows, int32_t num_types);
+size_t ptgnn_amd_edge_table_bytes(void);
+int ptgnn_amd_unique_sources(const int32_t *col, int64_t num_edges, int32_t type_bits, int32_t num_types,
+                             int64_t num_src_rows, int32_t *slot_row, int64_t *unique_src, int64_t capacity,
+                             int64_t *counts, void *edge_table /* nullable; ptgnn_amd_edge_table_bytes() */,
+                             void *workspace, size_t workspace_bytes, void *stream);
+/* The grouped per-edge GEMM of ptgnn_amd_edge_linear_f32 (no target-state half) over the message rows of
+ * ptgnn_amd_unique_sources: msg[r] = act(W_t x[unique_src[r]]) for the rows r of edge type t.  How many rows each type
+ * has is only known on the device, so the launch geometry (rows, 32-row units and workgroups per edge type) is read from
+ * `edge_table`, which ptgnn_amd_unique_sources filled on the same stream -- the host never waits for the counts.
+ * msg must hold min(num_edges, num_src_rows * num_types) rows.  PTGNN_AMD_EUNSUPPORTED for shapes outside the streaming
+ * edge GEMM (ptgnn_amd_edge_linear_shared_supported == 0: the caller keeps the per-edge form). */
+int ptgnn_amd_edge_linear_shared_supported(int32_t state_dim, int32_t msg_dim, int32_t num_types);
+int ptgnn_amd_edge_linear_shared_f32(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
+                                     const void *edge_table, const float *const *w_per_type, int32_t num_types,
+                                     int32_t msg_dim, int act, float *msg, int64_t ld_msg, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused gather -> (+ destination term) -> segment reduce -> (row epilogue).
  *
  *   out[v, :] = EPI( REDUCE_{i in rowptr[v]..rowptr[v+1]}  Ysrc[src_i, t_i*M : (t_i+1)*M]

@@ -339,6 +339,36 @@ extern "C" int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int64_t n
                             num_types, msg_dim, act, msg, ld_msg, 0, 0.f, 0, stream_);
 }
 
+extern "C" int ptgnn_amd_edge_linear_shared_f32(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
+                                                const void *edge_table, const float *const *w_per_type,
+                                                int32_t num_types, int32_t msg_dim, int act, float *msg,
+                                                int64_t ld_msg, void *stream_) {
+  PTGNN_REQUIRE(num_types > 0 && state_dim > 0 && msg_dim > 0 && num_rows > 0, PTGNN_AMD_EINVAL,
+                "edge_linear_shared: bad sizes");
+  PTGNN_REQUIRE(act == PTGNN_AMD_ACT_NONE || act == PTGNN_AMD_ACT_TANH || act == PTGNN_AMD_ACT_RELU, PTGNN_AMD_EINVAL,
+                "edge_linear_shared: bad activation");
+  PTGNN_REQUIRE(x && edge_table && w_per_type && msg, PTGNN_AMD_EINVAL, "edge_linear_shared: null pointer");
+  PTGNN_REQUIRE(ld_x % 4 == 0 && ld_msg % 4 == 0 && ld_msg >= msg_dim && aligned16(x) && aligned16(msg),
+                PTGNN_AMD_EUNSUPPORTED, "edge_linear_shared: x/msg rows must be 16-byte aligned");
+  for (int t = 0; t < num_types; ++t)
+    PTGNN_REQUIRE(w_per_type[t] && aligned16(w_per_type[t]), PTGNN_AMD_EINVAL,
+                  "edge_linear_shared: weight of type %d is null or not 16-byte aligned", t);
+  const int taken = stream_edge_indirect((const StreamEdgeTable *)edge_table, w_per_type, num_types, x, ld_x, num_rows,
+                                         state_dim, msg_dim, act, msg, ld_msg, (hipStream_t)stream_);
+  PTGNN_REQUIRE(taken == 1, PTGNN_AMD_EUNSUPPORTED,
+                "edge_linear_shared: state_dim=%d msg_dim=%d num_types=%d is not a shape of the streaming edge GEMM",
+                state_dim, msg_dim, num_types);
+  PTGNN_LAUNCH_CHECK();
+  return PTGNN_AMD_OK;
+}
+
+extern "C" int ptgnn_amd_edge_linear_shared_supported(int32_t state_dim, int32_t msg_dim, int32_t num_types) {
+  return stream_gemm_mode() == 1 && num_types <= kStreamMaxTypes && state_dim % 64 == 0 &&
+                 stream_edge_supported(state_dim, msg_dim, 0)
+             ? 1
+             : 0;
+}
+
 extern "C" int ptgnn_amd_edge_linear_dropout_f32(const float *x, int64_t ld_x, int64_t num_rows,
                                                  int32_t state_dim,
                                                  const int64_t *const *src_per_type,

@@ -14,12 +14,13 @@
 //   k_shard_remap    second pass over the edge lists: remote source -> n_local + its halo slot
 // HBM-bound integer work; nothing here synchronises with the host.
 #include "common.h"
+#include "stream_gemm.h"
 
 namespace ptgnn_amd {
 namespace {
 
 constexpr int kShardTypes = 64;
-constexpr int kBlockWords = 1024;
+constexpr int kBlockWords = 256;     // bitmap words per workgroup of the rank kernels: one word per thread
 
 struct ShardTable {
   const int64_t *src[kShardTypes];
@@ -94,14 +95,17 @@ __global__ __launch_bounds__(256) void k_shard_blocks(const uint32_t *__restrict
   if (threadIdx.x == 0) block_sum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-// one workgroup per 1024-word block; thread t owns the 4 consecutive words 4 t .. 4 t + 3
+// one workgroup per kBlockWords-word block; thread t owns word t of the block (at one word per thread the serial part --
+// a store per set bit -- is 4x shorter than with the four words a thread of the first version owned: 19.4 -> 8.6 us on
+// the 2 M-bit map of BASELINE config 3's (type, source) pairs, every fourth bit set)
 __global__ __launch_bounds__(256) void k_shard_compact(const uint32_t *__restrict__ bitmap, int64_t words,
                                                        const int32_t *__restrict__ block_sum,
                                                        int32_t *__restrict__ word_slot, int64_t *__restrict__ need_ids) {
+  static_assert(kBlockWords == 256, "one bitmap word per thread");
   __shared__ int wsum[4];
   __shared__ int base_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {   // halo slots in front of this block = sum of the earlier blocks' counts
+  {   // slots in front of this block = sum of the earlier blocks' counts
     int c = 0;
     for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) c += block_sum[j];
 #pragma unroll
@@ -111,34 +115,26 @@ __global__ __launch_bounds__(256) void k_shard_compact(const uint32_t *__restric
     if (threadIdx.x == 0) base_s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     __syncthreads();
   }
-  const int64_t w0 = (int64_t)blockIdx.x * kBlockWords + 4 * threadIdx.x;
-  uint32_t v[4];
-  int mine = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    v[k] = w0 + k < words ? bitmap[w0 + k] : 0u;
-    mine += __popc(v[k]);
-  }
+  const int64_t w = (int64_t)blockIdx.x * kBlockWords + threadIdx.x;
+  uint32_t bits = w < words ? bitmap[w] : 0u;
+  const int mine = __popc(bits);
   int inc = mine;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int t = __shfl_up(inc, o, 64);
     if (lane >= o) inc += t;
   }
+  __syncthreads();                       // base_s / wsum of the prefix above are read by now
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
   int run = base_s + inc - mine;
-  for (int w = 0; w < wave; ++w) run += wsum[w];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (w0 + k < words) {
-      word_slot[w0 + k] = run;
-      uint32_t bits = v[k];
-      while (bits) {
-        const int b = __ffs((int)bits) - 1;
-        bits &= bits - 1;
-        need_ids[run++] = (w0 + k) * 32 + b;
-      }
+  for (int v = 0; v < wave; ++v) run += wsum[v];
+  if (w < words) {
+    word_slot[w] = run;
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1;
+      need_ids[run++] = w * 32 + b;
     }
   }
 }
@@ -182,6 +178,168 @@ __global__ __launch_bounds__(256) void k_shard_remap(ShardTable tab, int64_t edg
       const int64_t w = s >> 5;
       local_src[edge_base + e] = n_local + word_slot[w] + __popc(bitmap[w] & ((1u << (s & 31)) - 1u));
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Unique (edge type, source) pairs of a plan.  A GGNN message  W_t x[src]  (gatedmessagepassing.py:52-58) depends on the
+// edge only through (t, src): edges that share the pair share the message row.  The same bitmap machinery ranks the
+// pairs -- key = t * num_src_rows + src, so the rows come out type-major (what the grouped per-edge GEMM wants) and
+// ascending in src inside a type -- and gives every CSR slot the row of its pair.  Integer bookkeeping only; which edges
+// share a row never changes a value (a message row is the same fmaf chain wherever it is computed).
+//   k_uniq_mark     one pass over the plan's col array ((src << type_bits) | type): a bit per pair that occurs
+//   k_shard_blocks / k_shard_compact  (above): rank of every set bit, the sorted key list
+//   k_uniq_counts   rows per edge type (+ the total) for the one host read-back
+//   k_uniq_sources  key -> source node id, in place (the "adjacency list" of the de-duplicated GEMM)
+//   k_uniq_remap    CSR slot -> message row
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t uniq_key(int32_t c, int type_bits, int num_types, int64_t num_src_rows) {
+  const uint32_t u = (uint32_t)c;
+  int64_t t = u & ((1u << type_bits) - 1u), s = u >> type_bits;
+  t = t < num_types ? t : num_types - 1;             // a plan never holds such entries; keep the key inside the bitmap
+  s = s < num_src_rows ? s : num_src_rows - 1;
+  return t * num_src_rows + s;
+}
+
+// A byte per pair, plain stores (every writer stores the same 1): bit-granular marks need device-scope atomics, which
+// execute at the memory side -- 53 us for the 625 k edges of BASELINE config 3 against ~8 us for the byte stores.
+__global__ __launch_bounds__(256) void k_uniq_mark(const int32_t *__restrict__ col, int64_t num_edges, int type_bits,
+                                                   int num_types, int64_t num_src_rows, uint8_t *__restrict__ flags) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < num_edges; i += (int64_t)gridDim.x * blockDim.x)
+    flags[uniq_key(col[i], type_bits, num_types, num_src_rows)] = 1;
+}
+
+// flags -> bitmap (thread t of a workgroup: the 32 flags of word t) + the workgroup's population count (k_shard_blocks
+// of the shard index, fused); `flags` is padded to whole words and zero behind the last key
+__global__ __launch_bounds__(256) void k_uniq_pack(const uint8_t *__restrict__ flags, int64_t words,
+                                                   uint32_t *__restrict__ bitmap, int32_t *__restrict__ block_sum) {
+  __shared__ int part[4];
+  const int64_t w = (int64_t)blockIdx.x * kBlockWords + threadIdx.x;
+  uint32_t bits = 0;
+  if (w < words) {
+    const uint4 a = reinterpret_cast<const uint4 *>(flags)[2 * w], b = reinterpret_cast<const uint4 *>(flags)[2 * w + 1];
+    const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {      // four flag bytes (0 / 1) -> four bits
+      const uint32_t x = v[k];
+      bits |= ((x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u)) << (4 * k);
+    }
+    bitmap[w] = bits;
+  }
+  int c = __popc(bits);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(64) void k_uniq_counts(const uint32_t *__restrict__ bitmap,
+                                                    const int32_t *__restrict__ word_slot, int64_t words,
+                                                    const int32_t *__restrict__ block_sum, int nblocks, int num_types,
+                                                    int64_t num_src_rows, int64_t *__restrict__ counts,
+                                                    const int64_t *unique_src, StreamEdgeTable *__restrict__ table,
+                                                    int budget_cus) {
+  const int lane = threadIdx.x;
+  int c = 0;
+  for (int j = lane; j < nblocks; j += 64) c += block_sum[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  const int64_t total = c;
+  if (lane == 0) counts[num_types] = total;
+  int64_t first = 0, rows = 0;                     // lane t: the rows of edge type t (num_types <= 64 with a table)
+  for (int t = lane; t < num_types; t += 64) {
+    const int64_t a = slot_of(bitmap, word_slot, words, (int64_t)t * num_src_rows, total);
+    const int64_t b = slot_of(bitmap, word_slot, words, (int64_t)(t + 1) * num_src_rows, total);
+    counts[t] = b - a;
+    first = a; rows = b - a;
+  }
+  if (!table) return;
+  // The grouped per-edge GEMM's table (stream_gemm.h), on the device: the same apportioning of one workgroup per CU
+  // to the edge types as stream_edge() computes on the host -- proportional start, then the spare workgroups go to /
+  // the excess comes from the type whose load per workgroup moves the maximum least.
+  const bool live = lane < num_types;
+  const int units = live ? (int)((rows + 31) / 32) : 0;
+  int unit_incl = units;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(unit_incl, o, 64);
+    if (lane >= o) unit_incl += v;
+  }
+  const int total_units = __shfl(unit_incl, 63, 64);
+  int budget = budget_cus;
+  if (budget > total_units / 8 + 1) budget = total_units / 8 + 1;
+  int w = units == 0 ? 0 : (int)((int64_t)units * budget / (total_units > 0 ? total_units : 1));
+  if (units > 0 && w == 0) w = 1;
+  auto wave_sum = [](int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  int sum = wave_sum(w);
+  const int nonempty = wave_sum(units > 0 ? 1 : 0);
+  if (budget < nonempty) budget = nonempty;
+  for (int it = 0; it < 4 * 64 + budget_cus && sum != budget; ++it) {
+    const bool give = sum < budget;
+    // candidate value of this lane; the winner is the largest load per workgroup (give) / the smallest load after the
+    // cut (take), the lowest edge type among equals
+    double v = -1.0;
+    if (units > 0 && (give || w > 1)) v = give ? (double)units / w : (double)units / (w - 1);
+    double best = v;
+    int who = v >= 0.0 ? lane : 64;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(best, o, 64);
+      const int ow = __shfl_xor(who, o, 64);
+      const bool take_other = ow < 64 && (who == 64 || (give ? (ov > best || (ov == best && ow < who))
+                                                              : (ov < best || (ov == best && ow < who))));
+      if (take_other) { best = ov; who = ow; }
+    }
+    if (who == 64) break;
+    if (lane == who) w += give ? 1 : -1;
+    sum += give ? 1 : -1;
+  }
+  int wg_incl = w;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(wg_incl, o, 64);
+    if (lane >= o) wg_incl += v;
+  }
+  if (live) {
+    table->src[lane] = unique_src + first;
+    table->dst[lane] = unique_src + first;
+    table->w[lane] = nullptr;
+    table->edge_off[lane] = first;
+    table->unit_off[lane] = unit_incl - units;
+    table->wg_off[lane] = wg_incl - w;
+  }
+  if (lane == 0) {
+    table->edge_off[num_types] = total;
+    table->unit_off[num_types] = total_units;
+    table->wg_off[num_types] = sum;
+    table->num_types = num_types;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_uniq_sources(int64_t *__restrict__ ids, int64_t capacity,
+                                                      const int64_t *__restrict__ counts, int num_types,
+                                                      int64_t num_src_rows) {
+  const int64_t total = counts[num_types] < capacity ? counts[num_types] : capacity;
+  for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < total; u += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t key = ids[u];
+    ids[u] = key - (key / num_src_rows) * num_src_rows;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_uniq_remap(const int32_t *__restrict__ col, int64_t num_edges, int type_bits,
+                                                    int num_types, int64_t num_src_rows,
+                                                    const uint32_t *__restrict__ bitmap,
+                                                    const int32_t *__restrict__ word_slot,
+                                                    int32_t *__restrict__ slot_row) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < num_edges; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t key = uniq_key(col[i], type_bits, num_types, num_src_rows);
+    const int64_t w = key >> 5;
+    slot_row[i] = word_slot[w] + __popc(bitmap[w] & ((1u << (key & 31)) - 1u));
   }
 }
 
@@ -267,4 +425,65 @@ extern "C" int ptgnn_amd_shard_index(const int64_t *const *src_per_type, const i
     k_shard_remap<<<grid, 256, 0, st>>>(tab, base, lo, hi, total_nodes, hi - lo, bitmap, word_slot, local_src);
   });
   return rc;
+}
+
+extern "C" size_t ptgnn_amd_edge_table_bytes(void) { return sizeof(StreamEdgeTable); }
+
+extern "C" size_t ptgnn_amd_unique_sources_workspace_bytes(int64_t num_src_rows, int32_t num_types) {
+  if (num_src_rows < 0 || num_types <= 0) return 0;
+  const int64_t keys = num_src_rows * num_types;
+  const size_t words = (size_t)((keys + 31) / 32) + 1;
+  return ptgnn_amd_shard_index_workspace_bytes(keys) + sh_align(words * 32);      // + a flag byte per (type, source)
+}
+
+extern "C" int ptgnn_amd_unique_sources(const int32_t *col, int64_t num_edges, int32_t type_bits, int32_t num_types,
+                                        int64_t num_src_rows, int32_t *slot_row, int64_t *unique_src,
+                                        int64_t capacity, int64_t *counts, void *edge_table, void *workspace,
+                                        size_t workspace_bytes, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  PTGNN_REQUIRE(num_edges >= 0 && num_types > 0 && num_src_rows > 0 && type_bits >= 0 && type_bits < 31 &&
+                    num_types <= (1 << type_bits),
+                PTGNN_AMD_EINVAL, "unique_sources: bad sizes");
+  const int64_t keys = num_src_rows * num_types;
+  PTGNN_REQUIRE(keys < ((int64_t)1 << 31), PTGNN_AMD_EUNSUPPORTED, "unique_sources: %lld (type, source) pairs",
+                (long long)keys);
+  PTGNN_REQUIRE(counts && (num_edges == 0 || (col && slot_row)), PTGNN_AMD_EINVAL, "unique_sources: null pointer");
+  const int64_t most = num_edges < keys ? num_edges : keys;
+  PTGNN_REQUIRE(capacity >= most && (unique_src || most == 0), PTGNN_AMD_EINVAL,
+                "unique_sources: unique_src holds %lld ids, up to %lld may be written", (long long)capacity,
+                (long long)most);
+  PTGNN_REQUIRE(workspace_bytes >= ptgnn_amd_unique_sources_workspace_bytes(num_src_rows, num_types) && workspace,
+                PTGNN_AMD_EWORKSPACE, "unique_sources: workspace too small");
+  const int64_t words = (keys + 31) / 32 + 1;
+  const int nblocks = (int)((words + kBlockWords - 1) / kBlockWords);
+  char *ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  uint32_t *bitmap = (uint32_t *)ws;
+  int32_t *word_slot = (int32_t *)(ws + sh_align((size_t)words * 4));
+  int32_t *block_sum = (int32_t *)(ws + 2 * sh_align((size_t)words * 4));
+  uint8_t *flags = (uint8_t *)(ws + 2 * sh_align((size_t)words * 4) + sh_align((size_t)nblocks * 4) + 256);
+  PTGNN_HIP(hipMemsetAsync(flags, 0, (size_t)words * 32, st));
+  const int64_t eblocks = (num_edges + 255) / 256;
+  const unsigned egrid = (unsigned)(eblocks < 8192 ? (eblocks > 0 ? eblocks : 1) : 8192);
+  if (num_edges > 0) {
+    k_uniq_mark<<<egrid, 256, 0, st>>>(col, num_edges, type_bits, num_types, num_src_rows, flags);
+    PTGNN_LAUNCH_CHECK();
+  }
+  k_uniq_pack<<<(unsigned)nblocks, 256, 0, st>>>(flags, words, bitmap, block_sum);
+  PTGNN_LAUNCH_CHECK();
+  k_shard_compact<<<(unsigned)nblocks, 256, 0, st>>>(bitmap, words, block_sum, word_slot, unique_src);
+  PTGNN_LAUNCH_CHECK();
+  PTGNN_REQUIRE(!edge_table || num_types <= kStreamMaxTypes, PTGNN_AMD_EUNSUPPORTED,
+                "unique_sources: an edge table holds at most %d edge types", kStreamMaxTypes);
+  k_uniq_counts<<<1, 64, 0, st>>>(bitmap, word_slot, words, block_sum, nblocks, num_types, num_src_rows, counts,
+                                  unique_src, (StreamEdgeTable *)edge_table, edge_table_budget());
+  PTGNN_LAUNCH_CHECK();
+  if (num_edges > 0) {
+    const int64_t ublocks = (most + 255) / 256;
+    k_uniq_sources<<<(unsigned)(ublocks < 8192 ? ublocks : 8192), 256, 0, st>>>(unique_src, capacity, counts, num_types,
+                                                                                  num_src_rows);
+    PTGNN_LAUNCH_CHECK();
+    k_uniq_remap<<<egrid, 256, 0, st>>>(col, num_edges, type_bits, num_types, num_src_rows, bitmap, word_slot, slot_row);
+    PTGNN_LAUNCH_CHECK();
+  }
+  return PTGNN_AMD_OK;
 }

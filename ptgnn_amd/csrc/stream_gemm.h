@@ -33,4 +33,10 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
                 int use_dst, int32_t msg_dim, int act, float *msg, int64_t ld_msg, int64_t msg_row_base,
                 hipStream_t st);
 
+// the same GEMM over a table written on the device (ptgnn_amd_unique_sources); `edge_table_budget()` workgroups at most
+int edge_table_budget();
+int stream_edge_indirect(const StreamEdgeTable *tab_dev, const float *const *w_per_type, int num_types, const float *x,
+                         int64_t ld_x, int64_t num_rows, int32_t state_dim, int32_t msg_dim, int act, float *msg,
+                         int64_t ld_msg, hipStream_t st);
+
 }  // namespace ptgnn_amd

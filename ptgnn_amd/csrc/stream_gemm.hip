@@ -828,30 +828,40 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void k_stream_linear_ring(Linea
 // ---------------------------------------------------------------------------------------------------
 struct EdgeArgs {
   StreamEdgeTable tab;
+  const StreamEdgeTable *tab_dev;   // INDIRECT kernels: the table in device memory (tab then only carries w / num_types)
   const float *x; int64_t ld_x; int H; int use_dst; int M; int act;
   float *msg; int64_t ld_msg; int64_t msg_row_base;
   int64_t num_rows;          // rows of x (gathered ids are clamped into it)
   int run_len, lds_floats;
 };
 
-template <int NB, bool SPLIT>
+// INDIRECT: edge counts, unit split and workgroup apportioning are read from a table in DEVICE memory that an earlier
+// kernel of the same stream wrote (ptgnn_amd_unique_sources: the row counts of the shared-message form are only
+// known on the device, and fetching them would stall the host once per minibatch); the weights still come by value.
+template <int NB, bool SPLIT, bool INDIRECT>
 __global__ __launch_bounds__(512, 2) void k_stream_edge(EdgeArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 512, BN = 32 * NB;
+  const StreamEdgeTable *tabp;
+  if constexpr (INDIRECT) tabp = p.tab_dev; else tabp = &p.tab;
+  const StreamEdgeTable &tab = *tabp;
+  if constexpr (INDIRECT) {
+    if ((int)blockIdx.x >= tab.wg_off[tab.num_types]) return;   // the launch is sized for the largest apportioning
+  }
   // Workgroups are apportioned to edge types in proportion to their units, and a type's units are split evenly
   // over its workgroups: no run crosses a type boundary (a mid-run slab reload + barrier made the ~T affected
   // workgroups the stragglers that set the kernel time).
   int u, u_end;
   {
-    int lo = 0, hi_t = p.tab.num_types;
+    int lo = 0, hi_t = tab.num_types;
     while (hi_t - lo > 1) {
       const int mid = (lo + hi_t) >> 1;
-      if (p.tab.wg_off[mid] <= (int)blockIdx.x) lo = mid; else hi_t = mid;
+      if (tab.wg_off[mid] <= (int)blockIdx.x) lo = mid; else hi_t = mid;
     }
-    const int64_t w = p.tab.wg_off[lo + 1] - p.tab.wg_off[lo], part = (int)blockIdx.x - p.tab.wg_off[lo];
-    const int64_t units = p.tab.unit_off[lo + 1] - p.tab.unit_off[lo];
-    u = p.tab.unit_off[lo] + (int)(part * units / w);
-    u_end = p.tab.unit_off[lo] + (int)((part + 1) * units / w);
+    const int64_t w = tab.wg_off[lo + 1] - tab.wg_off[lo], part = (int)blockIdx.x - tab.wg_off[lo];
+    const int64_t units = tab.unit_off[lo + 1] - tab.unit_off[lo];
+    u = tab.unit_off[lo] + (int)(part * units / w);
+    u_end = tab.unit_off[lo] + (int)((part + 1) * units / w);
   }
   if (u >= u_end) return;
   const int K = p.use_dst ? 2 * p.H : p.H;
@@ -864,18 +874,18 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge(EdgeArgs p) {
   const int lofs = lane_piece_offset<SPLIT>(hi);
 
   while (u < u_end) {
-    int lo = 0, hi_t = p.tab.num_types;   // edge type of unit u (table lives in SGPRs)
+    int lo = 0, hi_t = tab.num_types;   // edge type of unit u (table lives in SGPRs)
     while (hi_t - lo > 1) {
       const int mid = (lo + hi_t) >> 1;
-      if (p.tab.unit_off[mid] <= u) lo = mid; else hi_t = mid;
+      if (tab.unit_off[mid] <= u) lo = mid; else hi_t = mid;
     }
     const int t = lo;
-    const int seg_end = p.tab.unit_off[t + 1] < u_end ? p.tab.unit_off[t + 1] : u_end;
-    const int ub = u - p.tab.unit_off[t];             // first unit of the segment inside the type
+    const int seg_end = tab.unit_off[t + 1] < u_end ? tab.unit_off[t + 1] : u_end;
+    const int ub = u - tab.unit_off[t];             // first unit of the segment inside the type
     const int count = seg_end - u;
-    const int64_t n_edges = p.tab.edge_off[t + 1] - p.tab.edge_off[t];
-    const int64_t *__restrict__ src = p.tab.src[t];
-    const int64_t *__restrict__ dst = p.tab.dst[t];
+    const int64_t n_edges = tab.edge_off[t + 1] - tab.edge_off[t];
+    const int64_t *__restrict__ src = tab.src[t];
+    const int64_t *__restrict__ dst = tab.dst[t];
     __syncthreads();   // every wave is done with the previous slab and its counter
     if (threadIdx.x == 0) *counter = 0;
     {
@@ -920,7 +930,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge(EdgeArgs p) {
         const int64_t s_nn = src[e_nn], d_nn = dst[e_nn];   // lands under this unit's MFMAs
         unit_kloop<NB, NB, false, SPLIT>(acc, a0, a1, smem, sl, li, hi, rows, ch0, nch);
         const int64_t e_row0 = (int64_t)(ub + cur) * 32;
-        const int64_t out_row0 = p.msg_row_base + p.tab.edge_off[t] + e_row0;
+        const int64_t out_row0 = p.msg_row_base + tab.edge_off[t] + e_row0;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
           if (n * 32 < p.M) {   // host guarantees 16-byte aligned message rows
@@ -1149,7 +1159,7 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   const int total = tab.unit_off[tab.num_types];
   if (total == 0) return 1;
   EdgeArgs p;
-  p.tab = tab; p.x = x; p.ld_x = ld_x; p.H = state_dim; p.use_dst = use_dst; p.M = msg_dim; p.act = act;
+  p.tab = tab; p.tab_dev = nullptr; p.x = x; p.ld_x = ld_x; p.H = state_dim; p.use_dst = use_dst; p.M = msg_dim; p.act = act;
   p.msg = msg; p.ld_msg = ld_msg; p.msg_row_base = msg_row_base; p.num_rows = num_rows;
   // apportion the workgroups (one per CU) to the edge types: proportional start, then hand the spare ones to /
   // take the excess from the type whose load per workgroup moves the maximum least
@@ -1189,13 +1199,50 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   const unsigned grid = (unsigned)p.tab.wg_off[tab.num_types];
 #define PTGNN_K(NBV, SP)                                      \
   do {                                                        \
-    auto kern = k_stream_edge<NBV, SP>;                       \
+    auto kern = k_stream_edge<NBV, SP, false>;                \
     if (!set_lds(kern, lds)) return 0;                        \
     kern<<<grid, 512, lds, st>>>(p);                          \
   } while (0)
   if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
 #undef PTGNN_K
   return 1;
+}
+
+// The grouped per-edge GEMM over a table that lives in device memory (no target-state half, exact fp32).  The launch
+// is one workgroup per CU; workgroups beyond the table's apportioning leave at once.
+int stream_edge_indirect(const StreamEdgeTable *tab_dev, const float *const *w_per_type, int num_types, const float *x,
+                         int64_t ld_x, int64_t num_rows, int32_t state_dim, int32_t msg_dim, int act, float *msg,
+                         int64_t ld_msg, hipStream_t st) {
+  size_t slab = 0;
+  if (num_types > kStreamMaxTypes || stream_gemm_mode() == 0) return 0;
+  if (state_dim % 64 != 0 || msg_dim % 32 != 0 || msg_dim > 128) return 0;
+  slab = Slab<false>::bytes(state_dim, msg_dim);
+  if (slab + kEpiBytes > (size_t)kLdsBudget) return 0;
+  const int nb = msg_dim / 32;
+  const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
+  EdgeArgs p;
+  p.tab.num_types = num_types;
+  for (int t = 0; t < num_types; ++t) p.tab.w[t] = w_per_type[t];
+  p.tab_dev = tab_dev;
+  p.x = x; p.ld_x = ld_x; p.H = state_dim; p.use_dst = 0; p.M = msg_dim; p.act = act;
+  p.msg = msg; p.ld_msg = ld_msg; p.msg_row_base = 0; p.num_rows = num_rows;
+  p.run_len = 0;
+  p.lds_floats = (int)(slab / 4);
+  const unsigned grid = (unsigned)edge_table_budget();
+#define PTGNN_K(NBV, SP)                                      \
+  do {                                                        \
+    auto kern = k_stream_edge<NBV, false, true>;              \
+    if (!set_lds(kern, lds)) return 0;                        \
+    kern<<<grid, 512, lds, st>>>(p);                          \
+  } while (0)
+  PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false);
+#undef PTGNN_K
+  return 1;
+}
+
+int edge_table_budget() {
+  const int cus = num_compute_units();
+  return cus > kStreamMaxTypes ? cus : kStreamMaxTypes;
 }
 
 }  // namespace ptgnn_amd

@@ -31,6 +31,7 @@ aggregation on the HIP segment-reduce seam with its autograd rule.  fp16 / bf16 
 to fp32 on entry and the result is cast back.  No path runs on the CPU or on a vendor BLAS.
 """
 import contextlib
+import os
 import threading
 from typing import Dict, List, Optional, Tuple, Union
 
@@ -135,12 +136,25 @@ def _no_grad_needed(*tensors) -> bool:
 # Per-edge grouped GEMM vs per-node pre-transform: FLOPs are 2*E*K*M vs 2*N*T*K*M, the per-edge rows pay a
 # random 512-B gather each; measured crossover on MI355X (profiles/) is near E ~ 0.8 * N * T.
 EDGE_PATH_BIAS = 1.25
+# GGNN inference, edge form: one message row per distinct (edge type, source) pair instead of one per edge
+UNIQUE_MESSAGES = os.environ.get("PTGNN_AMD_UNIQUE_MESSAGES", "1") not in ("", "0")
 
 
 def _prefer_edge_path(num_edges: int, num_nodes: int, num_types: int, state_dim: int, msg_dim: int) -> bool:
     if state_dim % 32 != 0 or msg_dim % 4 != 0 or num_types < 2:
         return False
     return num_edges * EDGE_PATH_BIAS < num_nodes * num_types
+
+
+def _edge_messages(table: torch.Tensor, adjacency_lists, plan, weights):
+    """GGNN messages of the edge form (inference) and the `col` that maps CSR slots to their rows: one row per distinct
+    (edge type, source) pair of the plan where the shared-row launch applies (GraphPlan.unique_messages), else one row
+    per edge in reference order (gatedmessagepassing.py:50-61).  The aggregate has the same bits either way."""
+    if UNIQUE_MESSAGES and ops.edge_linear_shared_supported(table.shape[1], weights[0].shape[0], len(weights)):
+        uniq = plan.unique_messages()
+        if uniq is not None:
+            return ops.edge_linear_shared(table, uniq, weights), uniq.slot_row
+    return ops.edge_linear(table, adjacency_lists, weights, False), plan.perm
 
 
 def _edge_training_ok(state_dim: int, msg_dim: int) -> bool:
@@ -287,10 +301,13 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
         if self._fused_ok(node_states, edge_features):
             M, T = self._message_dimension, len(adjacency_lists)
             if _prefer_edge_path(plan.num_edges, num_nodes, T, self.__state_dimension, M):
-                # many sparse edge types: one grouped per-edge GEMM, messages in reference order
-                msgs = ops.edge_linear(node_states, adjacency_lists,
-                                       [l.weight for l in self.__edge_message_transformation_layers], False)
-                agg = ops.gather_reduce(msgs, plan, M, self.__aggregation_fn, type_bits=0, col=plan.perm)
+                # many sparse edge types: one grouped per-edge GEMM.  The message W_t x[src] is the same row for
+                # every edge of type t that leaves src: the GEMM produces one row per distinct (type, source) pair
+                # of the plan (GraphPlan.unique_messages, built once per minibatch on the device) and the
+                # aggregation reads it per edge -- same bits, fewer rows.
+                weights = [l.weight for l in self.__edge_message_transformation_layers]
+                msgs, col = _edge_messages(node_states, adjacency_lists, plan, weights)
+                agg = ops.gather_reduce(msgs, plan, M, self.__aggregation_fn, type_bits=0, col=col)
             else:
                 y = ops.linear(node_states, self._stacked_edge_weights())      # [N, T*M]
                 agg = ops.gather_reduce(y, plan, M, self.__aggregation_fn)
@@ -381,7 +398,7 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                 if edge_form:
                     def table_of(block):
                         adj, plan = (shard.adj_own, shard.plan_own) if block == "own" else (shard.adj_halo, shard.plan_halo)
-                        return ops.edge_linear(table, adj, ws, False), plan.perm, 0
+                        return _edge_messages(table, adj, plan, ws) + (0,)
                 else:
                     w = self._stacked_edge_weights()
                     y = shard.new_table(T * M, node_states)
@@ -401,8 +418,8 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
             agg = sharded.aggregate_two_blocks(shard, work, table_of, M, self.__aggregation_fn)
         elif edge_form:
             table = shard.exchange(node_states)
-            msgs = ops.edge_linear(table, shard.local_adj, ws, False)
-            agg = ops.gather_reduce(msgs, shard.plan, M, self.__aggregation_fn, type_bits=0, col=shard.plan.perm)
+            msgs, col = _edge_messages(table, shard.local_adj, shard.plan, ws)
+            agg = ops.gather_reduce(msgs, shard.plan, M, self.__aggregation_fn, type_bits=0, col=col)
         else:
             w = self._stacked_edge_weights()
             if T * M <= H:   # ship message-table rows: no wider than the state, and no duplicated GEMM work

@@ -55,8 +55,9 @@ class KernelTimer:
             d = out.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
             d["calls"] += 1
             d["ms"] += s.elapsed_time(e)
-            d["bytes"] += work.get("bytes", 0.0)
-            d["flops"] += work.get("flops", 0.0)
+            b, f = work.get("bytes", 0.0), work.get("flops", 0.0)
+            d["bytes"] += b() if callable(b) else b
+            d["flops"] += f() if callable(f) else f
         return out
 
 
@@ -123,7 +124,7 @@ class GraphPlan:
 
     __slots__ = ("rowptr", "col", "perm", "type_bits", "num_nodes", "num_edges", "num_types",
                  "num_src_rows", "_backward", "_adj", "_adj_refs", "_inv_perm", "_ready", "_waited",
-                 "_hub_tickets", "hub_entries", "hub_count", "_slot_rows", "_ident", "_transposed",
+                 "_hub_tickets", "hub_entries", "hub_count", "_slot_rows", "_ident", "_transposed", "_uniq",
                  "__weakref__")
 
     def __init__(self, rowptr, col, perm, type_bits, num_nodes, num_edges, num_types):
@@ -140,6 +141,7 @@ class GraphPlan:
         self._hub_tickets = {}
         self.hub_entries = self.hub_count = None   # (chunk, row) pairs of rows > HUB_THRESHOLD
         self._slot_rows = self._ident = self._transposed = None
+        self._uniq = None      # UniqueMessages | pending read-back | False (not worth it / not applicable)
 
     def may_have_hubs(self) -> bool:
         """Only plans with more edges than the threshold can contain a hub row (whether they do is
@@ -163,6 +165,16 @@ class GraphPlan:
             if cur.cuda_stream not in self._waited:
                 cur.wait_event(self._ready)
                 self._waited.add(cur.cuda_stream)
+
+    def unique_messages(self) -> Optional["UniqueMessages"]:
+        """Message rows of the layers whose message depends on (edge type, source) only (GGNN without edge features /
+        per-edge dropout): one row per pair that occurs instead of one per edge -- see ptgnn_amd_unique_sources.  Built
+        on the first call behind the plan build and shared by all layers of the minibatch; everything the de-duplicated
+        launches need stays on the device (no host synchronisation).  None when it does not apply (small batches, more
+        than 64 edge types) or when recent minibatches saved fewer than UNIQUE_MIN_SAVING of their rows."""
+        if self._uniq is None:
+            self._uniq = _launch_unique_sources(self) or False
+        return self._uniq or None
 
     def backward_plan(self) -> "GraphPlan":
         """Plan of the transposed problem, rows = src * T + type, col = dst: row r of the [N*T, M] view
@@ -228,6 +240,137 @@ class GraphPlan:
                 self.num_edges, device=self.perm.device)
             self._inv_perm = inv
         return self._inv_perm
+
+
+class UniqueMessages:
+    """slot_row int32 [E]: message row of every CSR slot; unique_src int64: source node of every message row
+    (type-major); edge_table: the device-resident launch table of ptgnn_amd_edge_linear_shared_f32; capacity: rows the
+    message table must hold; counts: device int64 [T + 1] rows per type and in all."""
+    __slots__ = ("slot_row", "unique_src", "edge_table", "capacity", "counts", "num_edges", "num_types", "_host",
+                 "_event", "_rows")
+
+    def __init__(self, slot_row, unique_src, edge_table, capacity, counts, num_edges, num_types):
+        self.slot_row, self.unique_src, self.edge_table = slot_row, unique_src, edge_table
+        self.capacity, self.counts, self.num_edges, self.num_types = capacity, counts, num_edges, num_types
+        self._host = self._event = self._rows = None
+
+    def rows(self, wait: bool = False) -> Optional[int]:
+        """Rows of the message table, once the asynchronous read-back has arrived (None before; `wait` blocks)."""
+        if self._rows is None and self._event is not None:
+            if wait:
+                self._event.synchronize()
+            if self._event.query():
+                self._rows = int(self._host[self.num_types])
+                _PINNED_FREE.setdefault(int(self._host.numel()), []).append(self._host)
+                self._host = self._event = None
+        elif self._rows is None and wait:
+            self._rows = int(self.counts[self.num_types].item())
+        return self._rows
+
+    def adjacency(self):
+        """Per edge type (unique source ids, same) -- blocks for the counts; for tests and tools."""
+        counts = [int(c) for c in self.counts.tolist()]
+        adj, off = [], 0
+        for c in counts[:-1]:
+            adj.append((self.unique_src[off: off + c], self.unique_src[off: off + c]))
+            off += c
+        return adj
+
+
+# Sharing message rows costs ~6 small launches per minibatch.  Whether it pays is only known afterwards (the row counts
+# come back asynchronously): when the minibatches seen so far saved fewer than UNIQUE_MIN_SAVING of their rows, the
+# next UNIQUE_BACKOFF plans keep the per-edge form, then one is probed again.
+UNIQUE_MIN_SAVING = float(os.environ.get("PTGNN_AMD_UNIQUE_MIN_SAVING", "0.05"))
+UNIQUE_MIN_EDGES = int(os.environ.get("PTGNN_AMD_UNIQUE_MIN_EDGES", "65536"))
+UNIQUE_BACKOFF = 16
+_UNIQ_PENDING: List["UniqueMessages"] = []
+_UNIQ_SKIP = [0]
+_PINNED_FREE = {}    # words -> pinned int64 buffers not in flight (pinning host memory costs far more than the kernels)
+
+
+def _pinned_words(n: int) -> torch.Tensor:
+    free = _PINNED_FREE.setdefault(n, [])
+    return free.pop() if free else torch.empty(n, dtype=torch.int64).pin_memory()
+
+
+def _poll_unique_stats() -> None:
+    for u in list(_UNIQ_PENDING):
+        rows = u.rows()
+        if rows is not None:
+            _UNIQ_PENDING.remove(u)
+            if u.num_edges > 0 and rows > (1.0 - UNIQUE_MIN_SAVING) * u.num_edges:
+                _UNIQ_SKIP[0] = UNIQUE_BACKOFF
+    del _UNIQ_PENDING[:-8]
+
+
+def _launch_unique_sources(plan: "GraphPlan") -> Optional[UniqueMessages]:
+    lib = _lib.load()
+    E, T, ns = plan.num_edges, plan.num_types, plan.num_src_rows
+    if plan._adj is None or E < UNIQUE_MIN_EDGES or T > 64:
+        return None
+    capturing = torch.cuda.is_current_stream_capturing()
+    if not capturing:
+        _poll_unique_stats()
+        if _UNIQ_SKIP[0] > 0:
+            _UNIQ_SKIP[0] -= 1
+            return None
+    plan.wait()
+    dev = plan.col.device
+    cap = max(1, min(E, ns * T))
+    slot_row = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    unique_src = torch.empty(cap, dtype=torch.int64, device=dev)
+    counts = torch.empty(T + 1, dtype=torch.int64, device=dev)
+    table = torch.empty(int(lib.ptgnn_amd_edge_table_bytes()), dtype=torch.uint8, device=dev)
+    ws_bytes = int(lib.ptgnn_amd_unique_sources_workspace_bytes(ns, T))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    with _timed("unique_sources", bytes=E * 12.0 + ns * T / 4.0):
+        rc = lib.ptgnn_amd_unique_sources(plan.col.data_ptr(), E, plan.type_bits, T, ns, slot_row.data_ptr(),
+                                          unique_src.data_ptr(), cap, counts.data_ptr(), table.data_ptr(),
+                                          ws.data_ptr(), ws_bytes, _stream(slot_row))
+    _lib.check(rc, "ptgnn_amd_unique_sources")
+    u = UniqueMessages(slot_row, unique_src, table, cap, counts, E, T)
+    if not capturing:
+        u._host = _pinned_words(T + 1)
+        with torch.cuda.device(dev):
+            u._host.copy_(counts, non_blocking=True)
+            u._event = torch.cuda.Event()
+            u._event.record(torch.cuda.current_stream(dev))
+        _UNIQ_PENDING.append(u)
+    return u
+
+
+def edge_linear_shared_supported(state_dim: int, msg_dim: int, num_types: int) -> bool:
+    return bool(_lib.load().ptgnn_amd_edge_linear_shared_supported(state_dim, msg_dim, num_types))
+
+
+def edge_linear_shared(x: torch.Tensor, uniq: UniqueMessages, weights: Sequence[torch.Tensor],
+                       act: Optional[str] = None) -> torch.Tensor:
+    """msg[r] = act(W_t x[unique_src[r]]) over the message rows of `uniq` (GraphPlan.unique_messages): the grouped
+    per-edge GEMM of `edge_linear` with one row per distinct (edge type, source) pair; rows beyond the table's count
+    are not written.  The launch geometry comes from the device-resident table: no host synchronisation."""
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    x = _rowmajor(x)
+    T, H, M = uniq.num_types, x.shape[1], weights[0].shape[0]
+    if len(weights) != T:
+        raise _lib.PtgnnAmdError(f"edge_linear_shared: {len(weights)} weights for {T} edge types")
+    ws = [w.detach().contiguous() for w in weights]
+    for w in ws:
+        if tuple(w.shape) != (M, H) or not w.is_cuda or w.dtype != torch.float32:
+            raise _lib.PtgnnAmdError(f"edge_linear_shared: weight shape {tuple(w.shape)} does not match [{M}, {H}]")
+    msg = torch.empty(uniq.capacity, M, dtype=torch.float32, device=x.device)
+    wp = (ctypes.c_void_p * T)(*[w.data_ptr() for w in ws])
+
+    def rows():                       # resolved when the timer is summarised: the count is back by then
+        r = uniq.rows(wait=True)
+        return float(r if r is not None else uniq.num_edges)
+    with _timed("edge_linear_shared", flops=lambda: 2.0 * rows() * H * M,
+                bytes=lambda: 4.0 * (rows() * H + rows() * M + T * M * H) + 8.0 * rows()):
+        rc = lib.ptgnn_amd_edge_linear_shared_f32(x.data_ptr(), _ld(x), x.shape[0], H, uniq.edge_table.data_ptr(),
+                                                  ctypes.cast(wp, ctypes.c_void_p), T, M, ACT_IDS[act],
+                                                  msg.data_ptr(), M, _stream(msg))
+    _lib.check(rc, "ptgnn_amd_edge_linear_shared_f32")
+    return msg
 
 
 # ------------------------------------------------------------------------------------------------

@@ -920,6 +920,91 @@ def test_edge_path_equals_pretransform_path_and_oracle(kind, agg, monkeypatch):
     np.testing.assert_allclose(outs["node"].numpy(), want.numpy(), rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("n,counts,src_pool", [
+    (5000, [40000, 0, 7, 12000, 1], 300),          # heavy sharing: 300 distinct sources per type, an empty type
+    (70001, [90000, 30000], None),                 # sources over the whole node range (few duplicates)
+    (33, [1000], 33),                              # one edge type (type_bits = 0), every node a source many times
+])
+def test_unique_sources_equal_the_numpy_bookkeeping(n, counts, src_pool, monkeypatch):
+    """ptgnn_amd_unique_sources (integer work, bit-exact): per edge type the sorted distinct source ids, for every
+    CSR slot the row of its (type, source) pair in the type-major list of pairs, and the device-resident launch table
+    of the shared-row edge GEMM (row / unit prefixes; every workgroup of the apportioning owns work)."""
+    from ptgnn_amd import ops
+    g = torch.Generator().manual_seed(n + len(counts))
+    adj = [(torch.randint(0, src_pool or n, (c,), generator=g), torch.randint(0, n, (c,), generator=g)) for c in counts]
+    monkeypatch.setattr(ops, "UNIQUE_MIN_EDGES", 0)
+    monkeypatch.setattr(ops, "_UNIQ_SKIP", [0])
+    ops.clear_plan_cache()
+    plan = ops.plan_for(to_cuda_adj(adj), n)
+    uq = plan.unique_messages()
+    assert uq is not None and plan.unique_messages() is uq
+    want = [np.unique(a[0].numpy()) for a in adj]
+    off = np.cumsum([0] + [len(w) for w in want])
+    assert uq.rows(wait=True) == off[-1]
+    np.testing.assert_array_equal(uq.counts.cpu().numpy(), [len(w) for w in want] + [off[-1]])
+    for t, (got, _) in enumerate(uq.adjacency()):
+        np.testing.assert_array_equal(got.cpu().numpy(), want[t])
+    col = plan.col[: plan.num_edges].cpu().numpy().astype(np.int64)
+    typ, src = col & ((1 << plan.type_bits) - 1), col >> plan.type_bits
+    rows = np.array([off[t] + np.searchsorted(want[t], s_) for t, s_ in zip(typ, src)], dtype=np.int64)
+    np.testing.assert_array_equal(uq.slot_row[: plan.num_edges].cpu().numpy().astype(np.int64), rows)
+    # the launch table (stream_gemm.h StreamEdgeTable: 3 x 64 pointers, then int64 edge_off[65], int32 unit_off[65],
+    # int32 wg_off[65], int32 num_types)
+    raw = uq.edge_table.cpu().numpy().tobytes()
+    T = len(counts)
+    edge_off = np.frombuffer(raw, np.int64, 65, 3 * 64 * 8)[: T + 1]
+    unit_off = np.frombuffer(raw, np.int32, 65, 3 * 64 * 8 + 65 * 8)[: T + 1]
+    wg_off = np.frombuffer(raw, np.int32, 65, 3 * 64 * 8 + 65 * 8 + 65 * 4)[: T + 1]
+    num_types = np.frombuffer(raw, np.int32, 1, 3 * 64 * 8 + 65 * 8 + 2 * 65 * 4)[0]
+    assert num_types == T
+    np.testing.assert_array_equal(edge_off, off)
+    units = np.array([(len(w) + 31) // 32 for w in want])
+    np.testing.assert_array_equal(unit_off, np.cumsum([0] + list(units)))
+    wgs = np.diff(wg_off)
+    assert ((wgs > 0) == (units > 0)).all() and (wgs <= np.maximum(units, 0)).all() and wg_off[-1] <= 256
+
+
+@pytest.mark.parametrize("agg", ["sum", "max", "mean"])
+def test_ggnn_layer_with_shared_message_rows_gives_the_same_bits(agg, monkeypatch):
+    """GGNN inference, edge form: one message row per distinct (edge type, source) pair (GraphPlan.unique_messages)
+    instead of one per edge.  A row is the same fmaf chain wherever it is computed and the aggregation folds the
+    in-edges in the same CSR order, so the layer output does not change by a bit; it stays within 1e-5 of the
+    oracle (gatedmessagepassing.py:37-69)."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, ops, workloads
+    mb = workloads.batched_graphs(6, 700, 5, 3.0, seed=11)
+    N, H = mb["num_nodes"], 64
+    adj = O.augment_adjacency(mb["adjacency_lists"], N, True, True)
+    # make sources repeat inside a type, as the out-edges of one AST / token node do
+    adj = [(s - s % 3 if i % 2 == 0 else s, d) for i, (s, d) in enumerate(adj)]
+    T = len(adj)
+    torch.manual_seed(21)
+    layer = L.GatedMessagePassingLayer(H, H, T, agg)
+    x = workloads.node_states(N, H, seed=5)
+    want = O.ggnn_layer(x, adj, [torch.empty(a[0].shape[0], 0) for a in adj], layer.export_weights())
+    layer = layer.cuda().eval()
+    cadj = to_cuda_adj(adj)
+    monkeypatch.setattr(L, "EDGE_PATH_BIAS", 1e-9)
+    monkeypatch.setattr(ops, "UNIQUE_MIN_EDGES", 0)
+    monkeypatch.setattr(ops, "_UNIQ_SKIP", [0])
+    outs, rows = {}, {}
+    for name in ("per_edge", "shared"):
+        monkeypatch.setattr(L, "UNIQUE_MESSAGES", name == "shared")
+        ops.clear_plan_cache()
+        if name == "shared":
+            uq = ops.plan_for(cadj, N).unique_messages()
+            assert uq is not None and uq.rows(wait=True) < 0.9 * sum(int(a[0].shape[0]) for a in adj)
+        timer = ops.KernelTimer()
+        ops.set_kernel_timer(timer)
+        with torch.no_grad():
+            outs[name] = layer(x.cuda(), cadj, None, {}, {}, empty_feats(cadj, "cuda")).cpu()
+        ops.set_kernel_timer(None)
+        rows[name] = timer.summary()["edge_linear_shared" if name == "shared" else "edge_linear"]["flops"]
+    assert rows["shared"] < 0.9 * rows["per_edge"]
+    assert torch.equal(outs["shared"], outs["per_edge"])
+    np.testing.assert_allclose(outs["shared"].numpy(), want.numpy(), rtol=0, atol=TOL)
+
+
 @pytest.mark.parametrize("use_dst", [False, True])
 @pytest.mark.parametrize("H,M", [(32, 64), (128, 128), (64, 200), (160, 36)])
 def test_edge_weight_grad_matches_fp64(use_dst, H, M):
@@ -2116,8 +2201,12 @@ def test_sharded_two_block_overlap_mode_equals_unsharded(case, monkeypatch):
     layer = layer.cuda().eval()
     ops.clear_plan_cache()
     cadj = to_cuda_adj(adj)
+    monkeypatch.setattr(L, "UNIQUE_MESSAGES", False)      # the unsharded layer: one message row per edge ...
     with torch.no_grad():
         want = layer(x, cadj, None, {}, {}, empty_feats(cadj, "cuda"))
+    monkeypatch.setattr(L, "UNIQUE_MESSAGES", True)       # ... the shards (GGNN edge form): one per (type, source) pair
+    monkeypatch.setattr(ops, "UNIQUE_MIN_EDGES", 0)
+    monkeypatch.setattr(ops, "_UNIQ_SKIP", [0])
     indeg = torch.zeros(n, dtype=torch.int64)
     for _, d in adj:
         indeg += torch.bincount(d, minlength=n)
