@@ -363,10 +363,7 @@ extern "C" int ptgnn_amd_edge_linear_shared_f32(const float *x, int64_t ld_x, in
 }
 
 extern "C" int ptgnn_amd_edge_linear_shared_supported(int32_t state_dim, int32_t msg_dim, int32_t num_types) {
-  return stream_gemm_mode() == 1 && num_types <= kStreamMaxTypes && state_dim % 64 == 0 &&
-                 stream_edge_supported(state_dim, msg_dim, 0)
-             ? 1
-             : 0;
+  return num_types <= kStreamMaxTypes && stream_edge_supported(state_dim, msg_dim, 0) ? 1 : 0;
 }
 
 extern "C" int ptgnn_amd_edge_linear_dropout_f32(const float *x, int64_t ld_x, int64_t num_rows,

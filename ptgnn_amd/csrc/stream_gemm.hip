@@ -1208,16 +1208,17 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   return 1;
 }
 
-// The grouped per-edge GEMM over a table that lives in device memory (no target-state half, exact fp32).  The launch
+// The grouped per-edge GEMM over a table that lives in device memory (no target-state half; the arithmetic mode the
+// per-edge launch of the same shape would use).  The launch
 // is one workgroup per CU; workgroups beyond the table's apportioning leave at once.
 int stream_edge_indirect(const StreamEdgeTable *tab_dev, const float *const *w_per_type, int num_types, const float *x,
                          int64_t ld_x, int64_t num_rows, int32_t state_dim, int32_t msg_dim, int act, float *msg,
                          int64_t ld_msg, hipStream_t st) {
+  if (num_types > kStreamMaxTypes) return 0;
   size_t slab = 0;
-  if (num_types > kStreamMaxTypes || stream_gemm_mode() == 0) return 0;
-  if (state_dim % 64 != 0 || msg_dim % 32 != 0 || msg_dim > 128) return 0;
-  slab = Slab<false>::bytes(state_dim, msg_dim);
-  if (slab + kEpiBytes > (size_t)kLdsBudget) return 0;
+  const int kind = edge_plan(state_dim, msg_dim, 0, &slab);      // the arithmetic the per-edge launch would use
+  if (kind == 0) return 0;
+  const bool split = kind == 2;
   const int nb = msg_dim / 32;
   const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
   EdgeArgs p;
@@ -1231,11 +1232,11 @@ int stream_edge_indirect(const StreamEdgeTable *tab_dev, const float *const *w_p
   const unsigned grid = (unsigned)edge_table_budget();
 #define PTGNN_K(NBV, SP)                                      \
   do {                                                        \
-    auto kern = k_stream_edge<NBV, false, true>;              \
+    auto kern = k_stream_edge<NBV, SP, true>;                 \
     if (!set_lds(kern, lds)) return 0;                        \
     kern<<<grid, 512, lds, st>>>(p);                          \
   } while (0)
-  PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false);
+  if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
 #undef PTGNN_K
   return 1;
 }

@@ -964,8 +964,9 @@ def test_unique_sources_equal_the_numpy_bookkeeping(n, counts, src_pool, monkeyp
     assert ((wgs > 0) == (units > 0)).all() and (wgs <= np.maximum(units, 0)).all() and wg_off[-1] <= 256
 
 
+@pytest.mark.parametrize("mode", ["stream", "split"])
 @pytest.mark.parametrize("agg", ["sum", "max", "mean"])
-def test_ggnn_layer_with_shared_message_rows_gives_the_same_bits(agg, monkeypatch):
+def test_ggnn_layer_with_shared_message_rows_gives_the_same_bits(agg, mode, monkeypatch):
     """GGNN inference, edge form: one message row per distinct (edge type, source) pair (GraphPlan.unique_messages)
     instead of one per edge.  A row is the same fmaf chain wherever it is computed and the aggregation folds the
     in-edges in the same CSR order, so the layer output does not change by a bit; it stays within 1e-5 of the
@@ -987,19 +988,23 @@ def test_ggnn_layer_with_shared_message_rows_gives_the_same_bits(agg, monkeypatc
     monkeypatch.setattr(L, "EDGE_PATH_BIAS", 1e-9)
     monkeypatch.setattr(ops, "UNIQUE_MIN_EDGES", 0)
     monkeypatch.setattr(ops, "_UNIQ_SKIP", [0])
+    prev_mode = ops.set_gemm_mode(mode)
     outs, rows = {}, {}
-    for name in ("per_edge", "shared"):
-        monkeypatch.setattr(L, "UNIQUE_MESSAGES", name == "shared")
-        ops.clear_plan_cache()
-        if name == "shared":
-            uq = ops.plan_for(cadj, N).unique_messages()
-            assert uq is not None and uq.rows(wait=True) < 0.9 * sum(int(a[0].shape[0]) for a in adj)
-        timer = ops.KernelTimer()
-        ops.set_kernel_timer(timer)
-        with torch.no_grad():
-            outs[name] = layer(x.cuda(), cadj, None, {}, {}, empty_feats(cadj, "cuda")).cpu()
-        ops.set_kernel_timer(None)
-        rows[name] = timer.summary()["edge_linear_shared" if name == "shared" else "edge_linear"]["flops"]
+    try:
+        for name in ("per_edge", "shared"):
+            monkeypatch.setattr(L, "UNIQUE_MESSAGES", name == "shared")
+            ops.clear_plan_cache()
+            if name == "shared":
+                uq = ops.plan_for(cadj, N).unique_messages()
+                assert uq is not None and uq.rows(wait=True) < 0.9 * sum(int(a[0].shape[0]) for a in adj)
+            timer = ops.KernelTimer()
+            ops.set_kernel_timer(timer)
+            with torch.no_grad():
+                outs[name] = layer(x.cuda(), cadj, None, {}, {}, empty_feats(cadj, "cuda")).cpu()
+            ops.set_kernel_timer(None)
+            rows[name] = timer.summary()["edge_linear_shared" if name == "shared" else "edge_linear"]["flops"]
+    finally:
+        ops.set_gemm_mode(prev_mode)
     assert rows["shared"] < 0.9 * rows["per_edge"]
     assert torch.equal(outs["shared"], outs["per_edge"])
     np.testing.assert_allclose(outs["shared"].numpy(), want.numpy(), rtol=0, atol=TOL)
