@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kWavesPerWg * 64, 1) void k_wgrad_stream(WsArgs p) 
   const int64_t gm_row0 = p.gm_row_base + p.tab.edge_off[t];
   const float *const a_col = p.gm + (mt * WA + NBA * li);
   const int colb = kt * WB + NBB * li;                  // column of the input row [x_src ; x_dst]
-  const bool from_dst = p.use_dst && colb >= p.H;
+  const bool from_dst = p.use_dst && colb >= p.H;        // per LANE: a tile may hold columns of both halves
   const float *const b_col = p.x + (from_dst ? colb - p.H : colb);
   const int64_t *__restrict__ idx = from_dst ? p.tab.dst[t] : p.tab.src[t];   // null: row e of x (dense form)
 
@@ -400,7 +400,8 @@ int stream_wgrad(const WsTable &tab_in, const float *x, int64_t ld_x, int64_t nu
   const int K = state_dim * (use_dst ? 2 : 1);
   const int nba = blocks_for(msg_dim), nbb = blocks_for(K);
   if (nba == 0 || nbb == 0) return 0;
-  if (use_dst && state_dim % (32 * nbb) != 0) return 0;        // a k-tile must not straddle the [src ; dst] seam
+  // (a k-tile may straddle the [src ; dst] seam: which half -- table, id list -- a lane reads is decided per lane, and
+  //  a lane's NBB columns never straddle it because state_dim % 4 == 0)
   if (drop.thr != 0 && nbb != 4) return 0;
   if (ld_x >= ((int64_t)1 << 29) || ld_gm >= ((int64_t)1 << 29) || num_rows >= ((int64_t)1 << 31)) return 0;
   const int WA = 32 * nba, WB = 32 * nbb;

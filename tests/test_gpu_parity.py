@@ -1041,6 +1041,8 @@ def test_edge_weight_grad_matches_fp64(use_dst, H, M):
     (256, 128, [60000, 1, 20000]),                 # two k-tiles (four with the target half)
     (96, 96, [30000, 5000]),                       # 32-wide blocks, 3 x 3 (3 x 6) tiles per group
     (64, 64, [17, 2500, 0, 64, 129]),              # 64-wide blocks, ranges shorter than one prefetch block
+    (64, 64, [90000, 30001]),                      # with the target half: ONE 128-wide k-tile across the [src ; dst] seam
+    (96, 64, [50000, 7]),                          # K = 192 with the target half: the seam inside the middle 64-wide k-tile
 ])
 def test_streaming_weight_grad_shapes_match_fp64(use_dst, H, M, counts):
     """Shapes the streaming weight-gradient kernel takes (widths that are multiples of 32, wgrad_stream.hip): every
