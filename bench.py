@@ -208,18 +208,18 @@ def make_cfg3(dev, rank=0):
                     "(incl. reverse+self), Typilus GGNN arch: 8 GGNN layers H=128 (+concat residual), max"}
 
 
-def typilus_stack(arch, H, T, dropout):
+def typilus_stack(arch, H, T, dropout, agg=os.environ.get("TRAIN_AGG", "max")):
     """The two architectures of ptgnn/implementations/typilus/train.py: "ggnn" = create_ggnn_mp_layers
     (:37-64, the shape BASELINE configs[2] names, at the hidden size given) and "mlp" = create_mlp_mp_layers
     (:66-99), the DEFAULT the README's V100 numbers were measured on (hidden 64)."""
     from ptgnn_amd import layers as L
     if arch == "ggnn":
-        ggnn = L.GatedMessagePassingLayer(H, H, T, "max", dropout_rate=dropout)
+        ggnn = L.GatedMessagePassingLayer(H, H, T, agg, dropout_rate=dropout)
         r1 = L.ConcatResidualLayer(H)
-        last = L.GatedMessagePassingLayer(2 * H, H, T, "max", dropout_rate=dropout)
+        last = L.GatedMessagePassingLayer(2 * H, H, T, agg, dropout_rate=dropout)
         return [r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last]
-    mk = lambda: L.MlpMessagePassingLayer(H, H, H, T, "max", dropout_rate=dropout)          # noqa: E731
-    mk2 = lambda: L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, "max", dropout_rate=dropout)  # noqa: E731
+    mk = lambda: L.MlpMessagePassingLayer(H, H, H, T, agg, dropout_rate=dropout)          # noqa: E731
+    mk2 = lambda: L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, agg, dropout_rate=dropout)  # noqa: E731
     r1, r2 = L.ConcatResidualLayer(H), L.ConcatResidualLayer(H)
     return [r1.pass_through_dummy_layer(), mk(), mk(), mk(), r1, mk2(),
             r2.pass_through_dummy_layer(), mk(), mk(), mk(), r2, mk2()]

@@ -247,31 +247,37 @@ class UniqueMessages:
     (type-major); edge_table: the device-resident launch table of ptgnn_amd_edge_linear_shared_f32; capacity: rows the
     message table must hold; counts: device int64 [T + 1] rows per type and in all."""
     __slots__ = ("slot_row", "unique_src", "edge_table", "capacity", "counts", "num_edges", "num_types", "_host",
-                 "_event", "_rows")
+                 "_event", "_counts")
 
     def __init__(self, slot_row, unique_src, edge_table, capacity, counts, num_edges, num_types):
         self.slot_row, self.unique_src, self.edge_table = slot_row, unique_src, edge_table
         self.capacity, self.counts, self.num_edges, self.num_types = capacity, counts, num_edges, num_types
-        self._host = self._event = self._rows = None
+        self._host = self._event = self._counts = None
 
-    def rows(self, wait: bool = False) -> Optional[int]:
-        """Rows of the message table, once the asynchronous read-back has arrived (None before; `wait` blocks)."""
-        if self._rows is None and self._event is not None:
+    def host_counts(self, wait: bool = False) -> Optional[List[int]]:
+        """Rows per edge type + the total, once the asynchronous read-back has arrived (None before).  `wait` blocks
+        on the read-back's own event -- not on the stream: work enqueued after the bookkeeping keeps running."""
+        if self._counts is None and self._event is not None:
             if wait:
                 self._event.synchronize()
             if self._event.query():
-                self._rows = int(self._host[self.num_types])
+                self._counts = [int(c) for c in self._host.tolist()]
                 _PINNED_FREE.setdefault(int(self._host.numel()), []).append(self._host)
                 self._host = self._event = None
-        elif self._rows is None and wait:
-            self._rows = int(self.counts[self.num_types].item())
-        return self._rows
+        elif self._counts is None and wait:     # built under graph capture: no read-back was posted
+            self._counts = [int(c) for c in self.counts.tolist()]
+        return self._counts
+
+    def rows(self, wait: bool = False) -> Optional[int]:
+        """Rows of the message table (None while the read-back is in flight, unless `wait`)."""
+        c = self.host_counts(wait)
+        return None if c is None else c[self.num_types]
 
     def adjacency(self):
-        """Per edge type (unique source ids, same) -- blocks for the counts; for tests and tools."""
-        counts = [int(c) for c in self.counts.tolist()]
+        """Per edge type (unique source ids, same): the adjacency input of the host-sized launches (weight gradient,
+        tests).  Waits for the row counts."""
         adj, off = [], 0
-        for c in counts[:-1]:
+        for c in self.host_counts(wait=True)[:-1]:
             adj.append((self.unique_src[off: off + c], self.unique_src[off: off + c]))
             off += c
         return adj
