@@ -324,7 +324,11 @@ __device__ __forceinline__ void store_block_tq(const f32x16 &c, float *tq, float
   for (int q = 0; q < 4; ++q) {
     const float4 o = tq_transpose(tq, lane, li, hi, act_apply<ACT>(c[4 * q] + bv), act_apply<ACT>(c[4 * q + 1] + bv),
                                   act_apply<ACT>(c[4 * q + 2] + bv), act_apply<ACT>(c[4 * q + 3] + bv));
+#ifdef PTGNN_PROBE_NOSTORE   // timing probe only (scripts/build_variant.sh): everything but the global store
+    if (o.x == 12345.678f) *reinterpret_cast<float4 *>(yp + (int64_t)(8 * q) * ld_y) = o;
+#else
     if (8 * q + (lane >> 3) < rows_left) *reinterpret_cast<float4 *>(yp + (int64_t)(8 * q) * ld_y) = o;
+#endif
   }
 }
 
