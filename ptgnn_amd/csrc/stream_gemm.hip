@@ -842,10 +842,18 @@ struct EdgeArgs {
 // INDIRECT: edge counts, unit split and workgroup apportioning are read from a table in DEVICE memory that an earlier
 // kernel of the same stream wrote (ptgnn_amd_unique_sources: the row counts of the shared-message form are only
 // known on the device, and fetching them would stall the host once per minibatch); the weights still come by value.
+// Waves per workgroup of the edge kernel (A/B knob, scripts/build_variant.sh ... -DPTGNN_EDGE_WAVES=12): a third wave per
+// SIMD would cover the per-unit wait for the store acknowledgements (profiles/r03_notes.md 12) if the kernel fits 170
+// VGPRs.  8 is what ships.
+#ifndef PTGNN_EDGE_WAVES
+#define PTGNN_EDGE_WAVES 8
+#endif
+constexpr int kEdgeWaves = PTGNN_EDGE_WAVES;
+
 template <int NB, bool SPLIT, bool INDIRECT>
-__global__ __launch_bounds__(512, 2) void k_stream_edge(EdgeArgs p) {
+__global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_stream_edge(EdgeArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NT = 512, BN = 32 * NB;
+  constexpr int NT = kEdgeWaves * 64, BN = 32 * NB;
   const StreamEdgeTable *tabp;
   if constexpr (INDIRECT) tabp = p.tab_dev; else tabp = &p.tab;
   const StreamEdgeTable &tab = *tabp;
@@ -1129,17 +1137,19 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
 }
 
 // 0 = not taken, 1 = exact fp32 streaming, 2 = split streaming
+constexpr size_t kEdgeEpiBytes = 16 + (size_t)kEdgeWaves * kTqFloats * sizeof(float);   // = kEpiBytes at 8 waves
+
 static int edge_plan(int32_t state_dim, int32_t msg_dim, int use_dst, size_t *slab_bytes) {
   const int mode = stream_gemm_mode();
   if (mode == 0) return 0;
   const int K = use_dst ? 2 * state_dim : state_dim;
   if (K % 64 != 0 || state_dim % 32 != 0 || msg_dim % 32 != 0 || msg_dim > 128) return 0;
-  if (mode == 2 && Slab<true>::bytes(K, msg_dim) + kEpiBytes <= (size_t)kLdsBudget) {
+  if (mode == 2 && Slab<true>::bytes(K, msg_dim) + kEdgeEpiBytes <= (size_t)kLdsBudget) {
     *slab_bytes = Slab<true>::bytes(K, msg_dim);
     return 2;
   }
   // exact fp32: 12 % ahead of the tile kernel at K = 128 and 9 % at K = 256 (cfg3's last layer, 133 KB slab)
-  if (Slab<false>::bytes(K, msg_dim) + kEpiBytes <= (size_t)kLdsBudget) {
+  if (Slab<false>::bytes(K, msg_dim) + kEdgeEpiBytes <= (size_t)kLdsBudget) {
     *slab_bytes = Slab<false>::bytes(K, msg_dim);
     return 1;
   }
@@ -1159,7 +1169,7 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   if (kind == 0) return 0;
   const bool split = kind == 2;
   const int nb = msg_dim / 32;
-  const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
+  const size_t lds = slab + 16 + kEdgeWaves * kTqFloats * sizeof(float);
   const int total = tab.unit_off[tab.num_types];
   if (total == 0) return 1;
   EdgeArgs p;
@@ -1205,7 +1215,7 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   do {                                                        \
     auto kern = k_stream_edge<NBV, SP, false>;                \
     if (!set_lds(kern, lds)) return 0;                        \
-    kern<<<grid, 512, lds, st>>>(p);                          \
+    kern<<<grid, kEdgeWaves * 64, lds, st>>>(p);              \
   } while (0)
   if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
 #undef PTGNN_K
@@ -1224,7 +1234,7 @@ int stream_edge_indirect(const StreamEdgeTable *tab_dev, const float *const *w_p
   if (kind == 0) return 0;
   const bool split = kind == 2;
   const int nb = msg_dim / 32;
-  const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
+  const size_t lds = slab + 16 + kEdgeWaves * kTqFloats * sizeof(float);
   EdgeArgs p;
   p.tab.num_types = num_types;
   for (int t = 0; t < num_types; ++t) p.tab.w[t] = w_per_type[t];
@@ -1238,7 +1248,7 @@ int stream_edge_indirect(const StreamEdgeTable *tab_dev, const float *const *w_p
   do {                                                        \
     auto kern = k_stream_edge<NBV, SP, true>;                 \
     if (!set_lds(kern, lds)) return 0;                        \
-    kern<<<grid, 512, lds, st>>>(p);                          \
+    kern<<<grid, kEdgeWaves * 64, lds, st>>>(p);              \
   } while (0)
   if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
 #undef PTGNN_K
