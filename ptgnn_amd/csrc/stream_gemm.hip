@@ -895,9 +895,21 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
     const int seg_end = tab.unit_off[t + 1] < u_end ? tab.unit_off[t + 1] : u_end;
     const int ub = u - tab.unit_off[t];             // first unit of the segment inside the type
     const int count = seg_end - u;
-    const int64_t n_edges = tab.edge_off[t + 1] - tab.edge_off[t];
-    const int64_t *__restrict__ src = tab.src[t];
-    const int64_t *__restrict__ dst = tab.dst[t];
+    // every table field the unit loop needs is read HERE: with the table in device memory (INDIRECT) a read inside the
+    // loop -- after the kernel's own stores -- cannot be proven unclobbered, becomes a vector load whose result is needed
+    // at once, and the `s_waitcnt vmcnt(0)` in front of it makes the compiler give up counting the A-row loads of the
+    // whole loop (the table-driven kernel waited for every refill in full: 17.6 % of its wave cycles)
+    const int64_t type_row0 = tab.edge_off[t];
+    const int64_t n_edges = tab.edge_off[t + 1] - type_row0;
+    // The id lists are GLOBAL memory.  Read out of a table in device memory (INDIRECT) the pointers are generic as far as
+    // the compiler knows, their loads become flat_load, and a pending FLAT access makes the wait-count pass treat the
+    // whole queue as out of order: `s_waitcnt vmcnt(0) lgkmcnt(0)` in front of every chunk pair -- every A-row refill
+    // waited for in full, every B-fragment read drained -- while the ids of the unit after next are in flight, i.e.
+    // always (found in the ISA of the table-driven kernel; the by-value kernel, whose pointers come from the kernel
+    // arguments, counts `vmcnt(7) .. (4)` per piece).
+    using GlobalIds = const __attribute__((address_space(1))) int64_t *;
+    const GlobalIds src = (GlobalIds)tab.src[t];
+    const GlobalIds dst = (GlobalIds)tab.dst[t];
     __syncthreads();   // every wave is done with the previous slab and its counter
     if (threadIdx.x == 0) *counter = 0;
     {
@@ -942,7 +954,7 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
         const int64_t s_nn = src[e_nn], d_nn = dst[e_nn];   // lands under this unit's MFMAs
         unit_kloop<NB, NB, false, SPLIT>(acc, a0, a1, smem, sl, li, hi, rows, ch0, nch);
         const int64_t e_row0 = (int64_t)(ub + cur) * 32;
-        const int64_t out_row0 = p.msg_row_base + tab.edge_off[t] + e_row0;
+        const int64_t out_row0 = p.msg_row_base + type_row0 + e_row0;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
           if (n * 32 < p.M) {   // host guarantees 16-byte aligned message rows
