@@ -318,6 +318,41 @@ int ptgnn_amd_edge_linear_dropout_f32(const float *x, int64_t ld_x,
                                       void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The same per-edge dropout with the keep mask as ONE BIT per element (round 4).  Evaluating the hash
+ * inside the forward, input-gradient and weight-gradient GEMMs costs ~55 vector instructions per 16
+ * MFMAs, and on gfx950 fp32 MFMA shares the vector lanes with the VALU; as bits the mask costs one
+ * dword load per 32 columns and 3-4 instructions per element.
+ *
+ * ptgnn_amd_dropout_bitmask: bits[row * (width / 32) + c], bit b = keep flag of column 32 c + b of message
+ *   row `row`, from the SAME hash of (dropout_seed, row, column) the *_dropout_f32 / *_weight_grad_f32
+ *   entry points evaluate -- the two families are interchangeable and bit-identical.  width % 32 == 0;
+ *   `bits` holds ptgnn_amd_dropout_bitmask_bytes(rows, width) bytes.  One mask serves the forward, the
+ *   input gradient and the weight gradient of one layer call (E * H / 8 bytes; the gathered [E, H] input
+ *   it replaces is 32 x that).
+ * ptgnn_amd_edge_linear_masked_f32: ptgnn_amd_edge_linear_dropout_f32 (modes 1 and 2, same argument
+ *   meaning) with `mask_bits` in place of the seed; runs on the fence-free streaming kernel.  Shapes:
+ *   ptgnn_amd_edge_linear_masked_supported(state_dim, msg_dim, mode) (state_dim in {64, 128, 256},
+ *   msg_dim in {64, 128, 256}); anything else returns EUNSUPPORTED -- use the *_dropout_f32 form there.
+ * ptgnn_amd_edge_weight_grad_masked_f32: ptgnn_amd_edge_weight_grad_f32 (no target-state half) with
+ *   `mask_bits`; shapes: ptgnn_amd_edge_weight_grad_masked_supported (state_dim % 128 == 0, msg_dim % 32 == 0).
+ * ---------------------------------------------------------------------------------------- */
+size_t ptgnn_amd_dropout_bitmask_bytes(int64_t rows, int32_t width);
+int ptgnn_amd_dropout_bitmask(int64_t rows, int32_t width, float dropout_p, uint64_t dropout_seed,
+                              uint32_t *bits, void *stream);
+int ptgnn_amd_edge_linear_masked_supported(int32_t state_dim, int32_t msg_dim, int dropout_mode);
+int ptgnn_amd_edge_linear_masked_f32(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
+                                     const int64_t *const *src_per_type, const int64_t *edges_per_type,
+                                     const float *const *w_per_type, int32_t num_types, int32_t msg_dim,
+                                     float *msg, int64_t ld_msg, int dropout_mode, float dropout_p,
+                                     const uint32_t *mask_bits, void *stream);
+int ptgnn_amd_edge_weight_grad_masked_supported(int32_t state_dim, int32_t msg_dim);
+int ptgnn_amd_edge_weight_grad_masked_f32(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
+                                          const int64_t *const *src_per_type, const int64_t *edges_per_type,
+                                          const float *grad_msg, int64_t ld_grad_msg, int32_t num_types,
+                                          int32_t msg_dim, float dropout_p, const uint32_t *mask_bits,
+                                          float *grad_w, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Weight gradient of the per-edge message Linear for every edge type in one call (autograd of the
  * nn.Linear at gatedmessagepassing.py:20-23,57-61 / the MLP output layer at mlpmessagepassing.py:96-98):
  *   grad_w[t, m, k] = sum_{e < E_t} grad_msg[off_t + e, m] * in_t[e, k],

@@ -52,6 +52,14 @@ SIGNATURES = {
                                              _i64, _vp]),
     "ptgnn_amd_edge_linear_dropout_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i64,
                                                      _c.c_int, _c.c_float, _c.c_uint64, _vp]),
+    "ptgnn_amd_dropout_bitmask_bytes": (_c.c_size_t, [_i64, _i32]),
+    "ptgnn_amd_dropout_bitmask": (_c.c_int, [_i64, _i32, _c.c_float, _c.c_uint64, _vp, _vp]),
+    "ptgnn_amd_edge_linear_masked_supported": (_c.c_int, [_i32, _i32, _c.c_int]),
+    "ptgnn_amd_edge_linear_masked_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i64,
+                                                    _c.c_int, _c.c_float, _vp, _vp]),
+    "ptgnn_amd_edge_weight_grad_masked_supported": (_c.c_int, [_i32, _i32]),
+    "ptgnn_amd_edge_weight_grad_masked_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _i32,
+                                                         _c.c_float, _vp, _vp, _vp, _c.c_size_t, _vp]),
     "ptgnn_amd_edge_wgrad_workspace_bytes": (_c.c_size_t, [_i64, _i32, _i32, _i32]),
     "ptgnn_amd_edge_weight_grad_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                                   _c.c_float, _c.c_uint64, _vp, _vp, _c.c_size_t, _vp]),

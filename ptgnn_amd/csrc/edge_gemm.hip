@@ -208,16 +208,37 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
   }
 }
 
+// keep bits of the per-edge dropout (ptgnn_amd_dropout_bitmask): one thread per dword = 32 columns of one message row,
+// the hash of dense_common.h evaluated once per layer call instead of inside three GEMMs
+__global__ __launch_bounds__(256) void k_dropout_bitmask(DropoutParams d, int64_t rows, int words_per_row,
+                                                         uint32_t *__restrict__ bits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * words_per_row) return;
+  const int64_t row = i / words_per_row;
+  const int c = (int)(i - row * words_per_row);
+  uint32_t w = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t h = dropout_bits(d, row, c * 16 + j);
+    w |= ((h & 0xffffu) >= d.thr ? 1u : 0u) << (2 * j);
+    w |= ((h >> 16) >= d.thr ? 1u : 0u) << (2 * j + 1);
+  }
+  bits[i] = w;
+}
+
 }  // namespace
 }  // namespace ptgnn_amd
 
 using namespace ptgnn_amd;
 
+// `mask_bits` (nullable): the keep mask as bits; with it the dropout forms run on the streaming kernel (which has no
+// hash form) or fail with EUNSUPPORTED -- callers ask ptgnn_amd_edge_linear_masked_supported first
 static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
                               const int64_t *const *src_per_type, const int64_t *const *dst_per_type,
                               const int64_t *edges_per_type, const float *const *w_per_type,
                               int32_t num_types, int32_t msg_dim, int act, float *msg, int64_t ld_msg,
-                              int dropout_mode, float dropout_p, uint64_t dropout_seed, void *stream_) {
+                              int dropout_mode, float dropout_p, uint64_t dropout_seed, void *stream_,
+                              const uint32_t *mask_bits = nullptr) {
   PTGNN_REQUIRE(num_types >= 0 && state_dim > 0 && msg_dim > 0, PTGNN_AMD_EINVAL, "edge_linear: bad sizes");
   PTGNN_REQUIRE(act >= 0 && act <= PTGNN_AMD_ACT_RELU, PTGNN_AMD_EINVAL, "edge_linear: bad act");
   PTGNN_REQUIRE(state_dim % 32 == 0 && msg_dim % 4 == 0, PTGNN_AMD_EUNSUPPORTED,
@@ -245,9 +266,17 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
   const DropoutParams drop = make_dropout(dropout_p, dropout_seed, dropout_mode == 2 ? msg_dim : state_dim);
   hipStream_t st = (hipStream_t)stream_;
   int64_t row_base = 0;
-  // streaming core (stream_gemm.hip): inference / no-dropout shapes it tiles
-  bool streaming = dropout_mode == 0 && stream_edge_supported(state_dim, msg_dim, use_dst) &&
+  // streaming core (stream_gemm.hip): the shapes it tiles; the dropout forms only with the mask as bits.  A 256-wide
+  // output (the input gradient of the last Typilus layer, whose input is the 256-wide concat residual) is two column
+  // slabs of 128, each a launch of its own.
+  const int col_slabs = (msg_dim == 256 && stream_edge_supported(state_dim, 128, use_dst)) ? 2 : 1;
+  const int slab_dim = msg_dim / col_slabs;
+  bool streaming = (dropout_mode == 0 || mask_bits != nullptr) && stream_edge_supported(state_dim, slab_dim, use_dst) &&
                    ld_x % 4 == 0 && aligned16(x);
+  const int in_dim = use_dst ? 2 * state_dim : state_dim;
+  const int mask_words = (dropout_mode == 2 ? msg_dim : state_dim) / 32;   // the mask covers the FORWARD input row
+  for (int cs = 0; streaming && cs < col_slabs; ++cs) {
+  row_base = 0;
   for (int t0 = 0; streaming && t0 < num_types; t0 += kStreamMaxTypes) {
     StreamEdgeTable tab;
     tab.num_types = (num_types - t0 < kStreamMaxTypes) ? (num_types - t0) : kStreamMaxTypes;
@@ -263,13 +292,18 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
                     "edge_linear: weight of type %d is not 16-byte aligned", t0 + t);
       tab.src[t] = src_per_type[t0 + t];
       tab.dst[t] = use_dst ? dst_per_type[t0 + t] : src_per_type[t0 + t];
-      tab.w[t] = w_per_type[t0 + t];
+      tab.w[t] = w_per_type[t0 + t] ? w_per_type[t0 + t] + (size_t)cs * slab_dim * in_dim : nullptr;
       tab.edge_off[t + 1] = tab.edge_off[t] + n;
       const int64_t units = tab.unit_off[t] + (n + 31) / 32;
       PTGNN_REQUIRE(units < ((int64_t)1 << 30), PTGNN_AMD_EUNSUPPORTED, "edge_linear: too many units");
       tab.unit_off[t + 1] = (int32_t)units;
     }
-    if (stream_edge(tab, x, ld_x, num_rows, state_dim, use_dst, msg_dim, act, msg, ld_msg, row_base, st) != 1) {
+    StreamEdgeMask mk;
+    mk.mode = mask_bits ? dropout_mode : 0; mk.bits = mask_bits; mk.ld = mask_words;
+    mk.col0 = dropout_mode == 2 ? cs * (slab_dim / 32) : 0;
+    mk.scale = drop.scale;
+    if (stream_edge(tab, x, ld_x, num_rows, state_dim, use_dst, slab_dim, act, msg + cs * slab_dim, ld_msg, row_base, st,
+                    mk.mode ? &mk : nullptr) != 1) {
       // "not taken" (the dynamic-LDS attribute was refused, e.g. a first use inside a graph capture): like
       // stream_linear / stream_gru, fall through to the tile kernel, which recomputes every type chunk
       streaming = false;
@@ -279,7 +313,12 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
     PTGNN_LAUNCH_CHECK();
     row_base += tab.edge_off[tab.num_types];
   }
+  }
   if (streaming) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(mask_bits == nullptr, PTGNN_AMD_EUNSUPPORTED,
+                "edge_linear_masked: state_dim=%d msg_dim=%d mode=%d is not a shape of the streaming edge GEMM "
+                "(use ptgnn_amd_edge_linear_dropout_f32)", state_dim, msg_dim, dropout_mode);
+  row_base = 0;
   for (int t0 = 0; t0 < num_types; t0 += kMaxTypes) {
     EdgeTypeTable tab;
     tab.num_types = (num_types - t0 < kMaxTypes) ? (num_types - t0) : kMaxTypes;
@@ -377,4 +416,44 @@ extern "C" int ptgnn_amd_edge_linear_dropout_f32(const float *x, int64_t ld_x, i
   return edge_linear_launch(x, ld_x, num_rows, state_dim, src_per_type, nullptr, edges_per_type, w_per_type,
                             num_types, msg_dim, PTGNN_AMD_ACT_NONE, msg, ld_msg, dropout_mode, dropout_p,
                             dropout_seed, stream_);
+}
+
+extern "C" size_t ptgnn_amd_dropout_bitmask_bytes(int64_t rows, int32_t width) {
+  if (rows < 0 || width <= 0 || width % 32 != 0) return 0;
+  return (size_t)rows * (size_t)(width / 32) * sizeof(uint32_t);
+}
+
+extern "C" int ptgnn_amd_dropout_bitmask(int64_t rows, int32_t width, float dropout_p, uint64_t dropout_seed,
+                                         uint32_t *bits, void *stream_) {
+  PTGNN_REQUIRE(rows >= 0 && width > 0 && width % 32 == 0, PTGNN_AMD_EINVAL,
+                "dropout_bitmask: width must be a positive multiple of 32 (got %d)", width);
+  PTGNN_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, PTGNN_AMD_EINVAL, "dropout_bitmask: bad probability");
+  if (rows == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(bits != nullptr, PTGNN_AMD_EINVAL, "dropout_bitmask: null pointer");
+  const DropoutParams d = make_dropout(dropout_p, dropout_seed, width);
+  const int64_t words = rows * (width / 32);
+  PTGNN_REQUIRE((words + 255) / 256 < ((int64_t)1 << 31), PTGNN_AMD_EUNSUPPORTED, "dropout_bitmask: too many rows");
+  k_dropout_bitmask<<<(unsigned)((words + 255) / 256), 256, 0, (hipStream_t)stream_>>>(d, rows, width / 32, bits);
+  PTGNN_LAUNCH_CHECK();
+  return PTGNN_AMD_OK;
+}
+
+extern "C" int ptgnn_amd_edge_linear_masked_supported(int32_t state_dim, int32_t msg_dim, int dropout_mode) {
+  if (dropout_mode != 1 && dropout_mode != 2) return 0;
+  const int slab_dim = msg_dim == 256 ? 128 : msg_dim;
+  return stream_edge_masked_supported(state_dim, slab_dim) ? 1 : 0;
+}
+
+extern "C" int ptgnn_amd_edge_linear_masked_f32(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
+                                                const int64_t *const *src_per_type, const int64_t *edges_per_type,
+                                                const float *const *w_per_type, int32_t num_types, int32_t msg_dim,
+                                                float *msg, int64_t ld_msg, int dropout_mode, float dropout_p,
+                                                const uint32_t *mask_bits, void *stream_) {
+  PTGNN_REQUIRE(dropout_mode == 1 || dropout_mode == 2, PTGNN_AMD_EINVAL, "edge_linear_masked: dropout_mode must be 1 or 2");
+  PTGNN_REQUIRE(dropout_p > 0.f && dropout_p < 1.f && mask_bits != nullptr, PTGNN_AMD_EINVAL,
+                "edge_linear_masked: needs 0 < p < 1 and a mask");
+  PTGNN_REQUIRE(ptgnn_amd_edge_linear_masked_supported(state_dim, msg_dim, dropout_mode), PTGNN_AMD_EUNSUPPORTED,
+                "edge_linear_masked: state_dim=%d msg_dim=%d is not a shape of the streaming edge GEMM", state_dim, msg_dim);
+  return edge_linear_launch(x, ld_x, num_rows, state_dim, src_per_type, nullptr, edges_per_type, w_per_type, num_types,
+                            msg_dim, PTGNN_AMD_ACT_NONE, msg, ld_msg, dropout_mode, dropout_p, 0, stream_, mask_bits);
 }

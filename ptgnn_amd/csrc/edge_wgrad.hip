@@ -301,7 +301,7 @@ static int weight_grad_launch(const float *x, int64_t ld_x, int64_t num_rows, in
                               const int64_t *edges_per_type, const float *grad_msg, int64_t ld_grad_msg,
                               int32_t num_types, int32_t msg_dim, float dropout_p, uint64_t dropout_seed,
                               float *grad_w, void *workspace, size_t workspace_bytes, void *stream_,
-                              bool identity_rows, float *grad_b) {
+                              bool identity_rows, float *grad_b, const uint32_t *mask_bits = nullptr) {
   PTGNN_REQUIRE(num_types >= 0 && state_dim > 0 && msg_dim > 0, PTGNN_AMD_EINVAL, "edge_weight_grad: bad sizes");
   PTGNN_REQUIRE(state_dim % 4 == 0 && msg_dim % 4 == 0, PTGNN_AMD_EUNSUPPORTED,
                 "edge_weight_grad: needs state_dim %% 4 == 0 and msg_dim %% 4 == 0 (got %d, %d)",
@@ -361,13 +361,17 @@ static int weight_grad_launch(const float *x, int64_t ld_x, int64_t num_rows, in
       }
       ws.edge_off[tab.num_types] = tab.edge_off[tab.num_types];
       const int taken = stream_wgrad(ws, x, ld_x, num_rows, state_dim, use_dst, grad_msg, ld_grad_msg, row_base, msg_dim,
-                                     dropout_p, dropout_seed, grad_w, t0, grad_b, (float *)workspace, workspace_bytes / sizeof(float), st);
+                                     dropout_p, dropout_seed, grad_w, t0, grad_b, (float *)workspace, workspace_bytes / sizeof(float), st,
+                                     mask_bits);
       PTGNN_REQUIRE(taken >= 0, PTGNN_AMD_EHIP, "edge_weight_grad: streaming launch failed");
       if (taken == 1) {
         row_base += tab.edge_off[tab.num_types];
         chunk_base += tab.chunk_off[tab.num_types];
         continue;
       }
+      PTGNN_REQUIRE(mask_bits == nullptr, PTGNN_AMD_EUNSUPPORTED,
+                    "edge_weight_grad_masked: state_dim=%d msg_dim=%d is not a shape of the streaming weight-gradient "
+                    "kernel (use ptgnn_amd_edge_weight_grad_f32)", state_dim, msg_dim);
     }
     const int64_t total = (int64_t)tab.chunk_off[tab.num_types] * mtiles * ktiles;
     if (total > 0) {
@@ -411,6 +415,27 @@ extern "C" int ptgnn_amd_edge_weight_grad_f32(const float *x, int64_t ld_x, int6
   return weight_grad_launch(x, ld_x, num_rows, state_dim, src_per_type, dst_per_type, edges_per_type, grad_msg,
                             ld_grad_msg, num_types, msg_dim, dropout_p, dropout_seed, grad_w, workspace,
                             workspace_bytes, stream_, false, nullptr);
+}
+
+extern "C" int ptgnn_amd_edge_weight_grad_masked_supported(int32_t state_dim, int32_t msg_dim) {
+  return state_dim % 128 == 0 && msg_dim % 32 == 0 ? 1 : 0;   // the streaming kernel's dropout form: 128-wide k tiles
+}
+
+extern "C" int ptgnn_amd_edge_weight_grad_masked_f32(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
+                                                     const int64_t *const *src_per_type, const int64_t *edges_per_type,
+                                                     const float *grad_msg, int64_t ld_grad_msg, int32_t num_types,
+                                                     int32_t msg_dim, float dropout_p, const uint32_t *mask_bits,
+                                                     float *grad_w, void *workspace, size_t workspace_bytes,
+                                                     void *stream_) {
+  PTGNN_REQUIRE(num_rows > 0 || num_types == 0, PTGNN_AMD_EINVAL, "edge_weight_grad_masked: num_rows must be positive");
+  PTGNN_REQUIRE(dropout_p > 0.f && dropout_p < 1.f && mask_bits != nullptr, PTGNN_AMD_EINVAL,
+                "edge_weight_grad_masked: needs 0 < p < 1 and a mask");
+  PTGNN_REQUIRE(ptgnn_amd_edge_weight_grad_masked_supported(state_dim, msg_dim), PTGNN_AMD_EUNSUPPORTED,
+                "edge_weight_grad_masked: state_dim=%d msg_dim=%d is not a shape of the streaming weight-gradient kernel",
+                state_dim, msg_dim);
+  return weight_grad_launch(x, ld_x, num_rows, state_dim, src_per_type, nullptr, edges_per_type, grad_msg, ld_grad_msg,
+                            num_types, msg_dim, dropout_p, 0, grad_w, workspace, workspace_bytes, stream_, false, nullptr,
+                            mask_bits);
 }
 
 // grad_w [n_out, k] = grad_y^T [n_out, rows] . x [rows, k]: the same split-row GEMM with the identity

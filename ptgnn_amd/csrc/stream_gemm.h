@@ -29,9 +29,18 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
                const float *w_hh, const float *b_ih, const float *b_hh, int64_t n, int32_t m, int32_t hd,
                float *out, int64_t ld_out, float *gates, hipStream_t st);
 int stream_edge_supported(int32_t state_dim, int32_t msg_dim, int use_dst);
+int stream_edge_masked_supported(int32_t state_dim, int32_t msg_dim);   // the bit-mask dropout forms (fence-free kernel)
+// per-edge dropout as a bit mask (ptgnn_amd_dropout_bitmask): mode 1 = on the gathered input rows (forward), 2 = on the
+// output rows (input gradient); `bits` = [message rows][ld] dwords, bit b of dword c = column 32 c + b
+struct StreamEdgeMask {
+  int mode;
+  const uint32_t *bits;
+  int ld, col0;
+  float scale;
+};
 int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
                 int use_dst, int32_t msg_dim, int act, float *msg, int64_t ld_msg, int64_t msg_row_base,
-                hipStream_t st);
+                hipStream_t st, const StreamEdgeMask *mask = nullptr);
 
 // the same GEMM over a table written on the device (ptgnn_amd_unique_sources); `edge_table_budget()` workgroups at most
 int edge_table_budget();

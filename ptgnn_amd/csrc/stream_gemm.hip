@@ -976,6 +976,287 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
 }
 
 // ---------------------------------------------------------------------------------------------------
+// grouped per-edge GEMM, fence-free unit body (exact fp32, K in {64, 128, 256}, M in {64, 128}, no activation).
+//
+// k_stream_edge starts every unit from a drained memory queue (`unit_fence`): its epilogue stores are conditional (ragged
+// last unit of a type) and its K loop is a loop, and with either the compiler cannot count the loads that are in flight
+// across a unit boundary -- it falls back to waiting for everything, which includes the ACKNOWLEDGEMENT of the sixteen
+// row stores the previous unit issued a few hundred cycles earlier (~15 % of the kernel, profiles/r03_notes.md 12).
+// vmcnt retires in issue order, so a wait for loads that were issued BEFORE the stores (the next unit's first two chunks
+// are) never has to cover them -- if the compiler can prove what the queue holds.  Here it can:
+//   * the K loop is unrolled over a compile-time chunk count, so the unit loop is one straight-line body;
+//   * every store is issued unconditionally: lanes of rows past a type's end write to a sink buffer instead of being
+//     masked off (a store the program may skip cannot be counted);
+//   * the prologue of a segment leaves the queue in exactly the state the loop body leaves it in -- first two chunks,
+//     the id loads of the unit after, sixteen (sink) stores -- so both ways into the loop header agree.
+// The result: `s_waitcnt vmcnt(N)` with N >= 16 at the top of a unit, no drain anywhere in the loop.
+// Same chunk order, k permutation and MFMA sequence per accumulator as k_stream_edge: identical bits.
+//
+// DROP (the reference's per-edge dropout, gatedmessagepassing.py:57-61, training only): the keep mask arrives as ONE BIT
+// per element (`ptgnn_amd_dropout_bitmask`, the hash of dense_common.h evaluated once per layer call instead of inside
+// three GEMMs: the hash costs ~55 VALU instructions per 16 MFMAs, and fp32 MFMA shares the vector lanes with the VALU).
+//   1  mask on the gathered INPUT rows (forward):       one mask dword per (message row, 32-column chunk) rides with
+//      the chunk's four row pieces; 3 VALU per element (bit -> all-ones, scale, and);
+//   2  mask on the OUTPUT rows (input gradient, d in = (d msg . W) * mask): the row's mask dwords are fetched at the top
+//      of the unit and applied to the transposed float4 right before its store.
+// ---------------------------------------------------------------------------------------------------
+}  // namespace
+
+// sink of the unconditional stores: external linkage, so the stores cannot be proven dead
+__device__ float4 ptgnn_amd_edge_store_sink[64 * 17];
+
+namespace {
+
+struct EdgeV2Args {
+  EdgeArgs e;
+  const uint32_t *mask;     // DROP != 0: keep bits, [message rows][mask_ld] dwords, bit b of dword c = column 32 c + b
+  int mask_ld;              // dwords per mask row
+  int mask_col0;            // DROP == 2: first dword of this launch's column slab
+  float scale;              // 1 / (1 - p)
+};
+
+__device__ __forceinline__ float keep_scaled(float v, uint32_t m, int bit, float scale) {
+  const int t = ((int)(m << (31 - bit))) >> 31;   // v_bfe_i32: the keep bit spread over the word
+  return __uint_as_float(__float_as_uint(v * scale) & (uint32_t)t);
+}
+
+// one K chunk: MFMAs on the four pieces in `buf` (+ mask word `mw`), then the refill of `buf` (+ `mw`) from `refill`
+template <int NB, int DROP>
+__device__ __forceinline__ void chunk_v2(f32x16 (&acc)[NB], float4 (&buf)[4], uint32_t &mw, float4 (&bcur)[NB],
+                                         const float *bl, int cbs, int kofs, int kofs_next, const float *refill,
+                                         const uint32_t *mrefill, int hi, float scale) {
+  uint32_t m = 0;
+  if constexpr (DROP == 1) m = mw >> (4 * hi);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 bn[NB];
+    const int ko = g < 3 ? kofs + (g + 1) * 8 : kofs_next;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) bn[n] = *reinterpret_cast<const float4 *>(bl + n * cbs + ko);
+    __builtin_amdgcn_sched_barrier(0);
+    float4 a = buf[g];
+    if constexpr (DROP == 1) {
+      a.x = keep_scaled(a.x, m, 8 * g + 0, scale); a.y = keep_scaled(a.y, m, 8 * g + 1, scale);
+      a.z = keep_scaled(a.z, m, 8 * g + 2, scale); a.w = keep_scaled(a.w, m, 8 * g + 3, scale);
+    }
+#define PTGNN_STEP(C)                                                                     \
+    _Pragma("unroll") for (int n = 0; n < NB; ++n)                                        \
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.C, bcur[n].C, acc[n], 0, 0, 0);
+    PTGNN_STEP(x) PTGNN_STEP(y) PTGNN_STEP(z) PTGNN_STEP(w)
+#undef PTGNN_STEP
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) bcur[n] = bn[n];
+  }
+  if constexpr (DROP == 1) {   // first: the chunk's pieces are waited for one at a time, and the mask with the first
+    mw = *mrefill;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    buf[g] = *reinterpret_cast<const float4 *>(refill + g * 8);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// VAR: 0 = table by value, 1 = table in device memory (shared message rows), 2 = by value with a target-state half
+// (input row = [x_src ; x_dst], K = 2 H: the first NCH / 2 chunks come from the source row)
+template <int NB, int NCH, int DROP, int VAR>
+__global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
+  constexpr bool INDIRECT = VAR == 1;
+  constexpr int CH0 = VAR == 2 ? NCH / 2 : NCH;   // chunks of the source half
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 512, BN = 32 * NB, K = 32 * NCH;
+  const EdgeArgs &p = q.e;
+  const StreamEdgeTable *tabp;
+  if constexpr (INDIRECT) tabp = p.tab_dev; else tabp = &p.tab;
+  const StreamEdgeTable &tab = *tabp;
+  if constexpr (INDIRECT) {
+    if ((int)blockIdx.x >= tab.wg_off[tab.num_types]) return;
+  }
+  int u, u_end;
+  {
+    int lo = 0, hi_t = tab.num_types;
+    while (hi_t - lo > 1) {
+      const int mid = (lo + hi_t) >> 1;
+      if (tab.wg_off[mid] <= (int)blockIdx.x) lo = mid; else hi_t = mid;
+    }
+    const int64_t w = tab.wg_off[lo + 1] - tab.wg_off[lo], part = (int)blockIdx.x - tab.wg_off[lo];
+    const int64_t units = tab.unit_off[lo + 1] - tab.unit_off[lo];
+    u = tab.unit_off[lo] + (int)(part * units / w);
+    u_end = tab.unit_off[lo] + (int)((part + 1) * units / w);
+  }
+  if (u >= u_end) return;
+  const Slab<false> sl(K, BN);
+  int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
+  float *const tq = smem + p.lds_floats + 4 + (threadIdx.x >> 6) * kTqFloats;
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, hi = lane >> 5;
+  const int lofs = hi * 4;
+  const int srow = lane >> 3, scol = (lane & 7) * 4;          // this lane's row / column in the store layout
+  float *const sink = reinterpret_cast<float *>(ptgnn_amd_edge_store_sink) + lane * 4;
+  const float *const bl = smem + li * sl.ld + hi * 4;
+  const int cbs = 32 * sl.ld;
+
+  while (u < u_end) {
+    int lo = 0, hi_t = tab.num_types;
+    while (hi_t - lo > 1) {
+      const int mid = (lo + hi_t) >> 1;
+      if (tab.unit_off[mid] <= u) lo = mid; else hi_t = mid;
+    }
+    const int t = lo;
+    const int seg_end = tab.unit_off[t + 1] < u_end ? tab.unit_off[t + 1] : u_end;
+    const int ub = u - tab.unit_off[t];
+    const int count = seg_end - u;
+    const int64_t type_row0 = tab.edge_off[t];
+    const int64_t n_edges = tab.edge_off[t + 1] - type_row0;
+    using GlobalIds = const __attribute__((address_space(1))) int64_t *;
+    const GlobalIds src = (GlobalIds)tab.src[t];
+    const GlobalIds dst = (GlobalIds)tab.dst[t];
+    __syncthreads();
+    if (threadIdx.x == 0) *counter = 0;
+    {
+      const float *w = p.tab.w[t];
+      constexpr int kq = K >> 2;
+      for (int i = threadIdx.x; i < BN * kq; i += NT) {
+        const int r = i / kq, k = (i - r * kq) * 4;
+        sl.put4(smem, r, k, *reinterpret_cast<const float4 *>(w + (int64_t)r * K + k));
+      }
+    }
+    __syncthreads();
+
+    int cur = claim_unit(counter);
+    if (cur < count) {
+      int nxt = claim_unit(counter);
+      auto edge_of = [&](int unit) {
+        const int64_t e = (int64_t)(ub + (unit < count ? unit : count - 1)) * 32 + li;
+        return e < n_edges ? e : n_edges - 1;
+      };
+      auto node_row = [&](int64_t id) {
+        id = id < 0 ? 0 : id;
+        return p.x + (id < p.num_rows ? id : p.num_rows - 1) * p.ld_x + lofs;
+      };
+      // chunk cc of a unit whose source / target rows are r0 / r1
+      auto chunk_ptr = [&](const float *r0, const float *r1, int cc) {
+        return cc < CH0 ? r0 + cc * 32 : r1 + (cc - CH0) * 32;
+      };
+      const int64_t mrow_base = p.msg_row_base + type_row0;
+      auto mask_row = [&](int64_t e) { return q.mask + (mrow_base + e) * q.mask_ld; };   // DROP == 1: e = edge_of(unit)
+
+      const float *c0, *c1, *n0, *n1;           // row pointers of the current and the next unit
+      const uint32_t *mc = nullptr, *mn = nullptr;
+      {
+        const int64_t e0 = edge_of(cur);
+        c0 = node_row(src[e0]); c1 = node_row(dst[e0]);
+        if constexpr (DROP == 1) mc = mask_row(e0);
+      }
+      float4 a0[4], a1[4];
+      uint32_t m0 = 0, m1 = 0;
+      if constexpr (DROP == 1) { m0 = mc[0]; __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        a0[g] = *reinterpret_cast<const float4 *>(chunk_ptr(c0, c1, 0) + g * 8);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (DROP == 1) { m1 = mc[1]; __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        a1[g] = *reinterpret_cast<const float4 *>(chunk_ptr(c0, c1, 1) + g * 8);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      int64_t e_n = edge_of(nxt);
+      int64_t s_n = src[e_n], d_n = dst[e_n];    // consumed inside the first unit
+      __builtin_amdgcn_sched_barrier(0);
+      {                                          // the queue shape the loop body leaves behind: sixteen stores
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4 * NB; ++i) {
+          *reinterpret_cast<float4 *>(sink + (i + 1) * 256) = z;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      f32x16 acc[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[n] = zero16();
+      float4 bcur[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) bcur[n] = *reinterpret_cast<const float4 *>(bl + n * cbs);
+
+      while (true) {
+        const int n2 = claim_unit(counter);
+        const int64_t e_row0 = (int64_t)(ub + cur) * 32;
+        const int64_t out_row0 = mrow_base + e_row0;
+        const int64_t left = n_edges - e_row0;
+        uint4 mq[4];
+        if constexpr (DROP == 2) {   // keep bits of this lane's four output rows, all column blocks of the slab
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t rr = 8 * r + srow < left ? 8 * r + srow : left - 1;
+            const uint32_t *mp = q.mask + (out_row0 + rr) * q.mask_ld + q.mask_col0;
+            if constexpr (NB == 4) mq[r] = *reinterpret_cast<const uint4 *>(mp);
+            else { const uint2 v = *reinterpret_cast<const uint2 *>(mp); mq[r] = make_uint4(v.x, v.y, 0u, 0u); }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c += 2) {
+          if (c == NCH - 2) {        // the next unit's rows are first needed by this chunk pair's refills
+            __builtin_amdgcn_sched_barrier(0);
+            // the ids were requested during the previous unit's epilogue: pin their first use HERE (the compiler hoists the
+            // address arithmetic -- and with it the wait for the ids -- to the top of the unit otherwise)
+            asm volatile("" : "+v"(s_n), "+v"(d_n));
+            n0 = node_row(s_n); n1 = node_row(d_n);
+            if constexpr (DROP == 1) mn = mask_row(e_n);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const float *r0 = c + 2 < NCH ? chunk_ptr(c0, c1, c + 2) : chunk_ptr(n0, n1, 0);
+          const float *r1 = c + 2 < NCH ? chunk_ptr(c0, c1, c + 3) : chunk_ptr(n0, n1, 1);
+          const uint32_t *mr0 = nullptr, *mr1 = nullptr;
+          if constexpr (DROP == 1) {
+            mr0 = c + 2 < NCH ? mc + (c + 2) : mn;
+            mr1 = c + 2 < NCH ? mc + (c + 3) : mn + 1;
+          }
+          const int kn = c + 2 < NCH ? c * 32 + 64 : 0;
+          chunk_v2<NB, DROP>(acc, a0, m0, bcur, bl, cbs, c * 32, c * 32 + 32, r0, mr0, hi, q.scale);
+          chunk_v2<NB, DROP>(acc, a1, m1, bcur, bl, cbs, c * 32 + 32, kn, r1, mr1, hi, q.scale);
+        }
+        e_n = edge_of(n2);
+        s_n = src[e_n]; d_n = dst[e_n];          // consumed one unit later
+        __builtin_amdgcn_sched_barrier(0);
+        // epilogue: C fragments -> rows through the wave's transposing slab, every store issued
+        {
+          float *const yp = p.msg + (out_row0 + srow) * p.ld_msg + scol;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float *const yr = 8 * r + srow < left ? yp + (int64_t)(8 * r) * p.ld_msg : sink;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+              float4 o = tq_transpose(tq, lane, li, hi, acc[n][4 * r], acc[n][4 * r + 1], acc[n][4 * r + 2],
+                                      acc[n][4 * r + 3]);
+              if constexpr (DROP == 2) {
+                const uint32_t w = n == 0 ? mq[r].x : n == 1 ? mq[r].y : n == 2 ? mq[r].z : mq[r].w;
+                const uint32_t m = w >> scol;
+                o.x = keep_scaled(o.x, m, 0, q.scale); o.y = keep_scaled(o.y, m, 1, q.scale);
+                o.z = keep_scaled(o.z, m, 2, q.scale); o.w = keep_scaled(o.w, m, 3, q.scale);
+              }
+              *reinterpret_cast<float4 *>(yr + n * 32) = o;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+#pragma unroll
+          for (int n = 0; n < NB; ++n) acc[n] = zero16();
+        }
+        if (nxt >= count) break;
+        cur = nxt; nxt = n2;
+        c0 = n0; c1 = n1;
+        if constexpr (DROP == 1) mc = mn;
+      }
+    }
+    u = seg_end;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
 int g_mode = -1;
@@ -1148,6 +1429,39 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
   return 1;
 }
 
+// The fence-free kernel takes: exact fp32, no activation, K in {64, 128, 256}, message width 64 or 128.
+static bool edge_v2_shape(int32_t state_dim, int32_t msg_dim, int use_dst, int act) {
+  static int off = -1;
+  if (off < 0) { const char *e = getenv("PTGNN_AMD_EDGE_V2"); off = (e && e[0] == '0') ? 1 : 0; }   // A/B knob
+  if (off || stream_gemm_mode() != 1 || act != PTGNN_AMD_ACT_NONE) return false;
+  const int K = use_dst ? 2 * state_dim : state_dim;
+  if (!(K == 64 || K == 128 || K == 256) || state_dim % 32 != 0) return false;
+  if (!(msg_dim == 64 || msg_dim == 128)) return false;
+  return Slab<false>::bytes(K, msg_dim) + kEpiBytes <= (size_t)kLdsBudget;
+}
+
+template <int DROP, int VAR>
+static int edge_v2_launch(const EdgeV2Args &q, int K, int msg_dim, unsigned grid, size_t lds, hipStream_t st) {
+#define PTGNN_K(NBV, NCHV)                                            \
+  do {                                                                \
+    auto kern = k_stream_edge_v2<NBV, NCHV, DROP, VAR>;          \
+    if (!set_lds(kern, lds)) return 0;                                \
+    kern<<<grid, 512, lds, st>>>(q);                                  \
+    return 1;                                                         \
+  } while (0)
+  if (msg_dim == 128) {
+    if (K == 64) PTGNN_K(4, 2);
+    if (K == 128) PTGNN_K(4, 4);
+    if (K == 256) PTGNN_K(4, 8);
+  } else {
+    if (K == 64) PTGNN_K(2, 2);
+    if (K == 128) PTGNN_K(2, 4);
+    if (K == 256) PTGNN_K(2, 8);
+  }
+#undef PTGNN_K
+  return 0;
+}
+
 // 0 = not taken, 1 = exact fp32 streaming, 2 = split streaming
 constexpr size_t kEdgeEpiBytes = 16 + (size_t)kEdgeWaves * kTqFloats * sizeof(float);   // = kEpiBytes at 8 waves
 
@@ -1173,11 +1487,17 @@ int stream_edge_supported(int32_t state_dim, int32_t msg_dim, int use_dst) {
   return edge_plan(state_dim, msg_dim, use_dst, &b) != 0;
 }
 
+int stream_edge_masked_supported(int32_t state_dim, int32_t msg_dim) {
+  return edge_v2_shape(state_dim, msg_dim, 0, PTGNN_AMD_ACT_NONE) ? 1 : 0;
+}
+
 int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
                 int use_dst, int32_t msg_dim, int act, float *msg, int64_t ld_msg, int64_t msg_row_base,
-                hipStream_t st) {
+                hipStream_t st, const StreamEdgeMask *mask) {
   size_t slab = 0;
   const int kind = edge_plan(state_dim, msg_dim, use_dst, &slab);
+  const bool v2 = edge_v2_shape(state_dim, msg_dim, use_dst, act);
+  if (mask && mask->mode != 0 && (!v2 || use_dst)) return 0;        // the dropout forms exist in the fence-free kernel only
   if (kind == 0) return 0;
   const bool split = kind == 2;
   const int nb = msg_dim / 32;
@@ -1223,6 +1543,19 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   p.run_len = 0;
   p.lds_floats = (int)(slab / 4);
   const unsigned grid = (unsigned)p.tab.wg_off[tab.num_types];
+  if (v2) {
+    EdgeV2Args q;
+    q.e = p;
+    q.mask = mask ? mask->bits : nullptr; q.mask_ld = mask ? mask->ld : 0; q.mask_col0 = mask ? mask->col0 : 0;
+    q.scale = mask ? mask->scale : 1.f;
+    const int K = use_dst ? 2 * state_dim : state_dim;
+    const int mode = mask ? mask->mode : 0;
+    const int took = mode == 1 ? edge_v2_launch<1, 0>(q, K, msg_dim, grid, lds, st)
+                   : mode == 2 ? edge_v2_launch<2, 0>(q, K, msg_dim, grid, lds, st)
+                   : use_dst   ? edge_v2_launch<0, 2>(q, K, msg_dim, grid, lds, st)
+                               : edge_v2_launch<0, 0>(q, K, msg_dim, grid, lds, st);
+    if (took || mode != 0) return took;
+  }
 #define PTGNN_K(NBV, SP)                                      \
   do {                                                        \
     auto kern = k_stream_edge<NBV, SP, false>;                \
@@ -1256,6 +1589,11 @@ int stream_edge_indirect(const StreamEdgeTable *tab_dev, const float *const *w_p
   p.run_len = 0;
   p.lds_floats = (int)(slab / 4);
   const unsigned grid = (unsigned)edge_table_budget();
+  if (edge_v2_shape(state_dim, msg_dim, 0, act)) {
+    EdgeV2Args q;
+    q.e = p; q.mask = nullptr; q.mask_ld = 0; q.mask_col0 = 0; q.scale = 1.f;
+    if (edge_v2_launch<0, 1>(q, state_dim, msg_dim, grid, lds, st)) return 1;
+  }
 #define PTGNN_K(NBV, SP)                                      \
   do {                                                        \
     auto kern = k_stream_edge<NBV, SP, true>;                 \

@@ -20,6 +20,6 @@ size_t stream_wgrad_workspace_floats(int64_t num_edges, int num_types, int msg_d
 int stream_wgrad(const WsTable &tab, const float *x, int64_t ld_x, int64_t num_rows, int state_dim, int use_dst,
                  const float *gm, int64_t ld_gm, int64_t gm_row_base, int msg_dim, float dropout_p, uint64_t dropout_seed,
                  float *grad_w, int type_base, float *grad_b, float *workspace, size_t workspace_floats,
-                 hipStream_t st);
+                 hipStream_t st, const uint32_t *mask_bits = nullptr /* keep bits instead of the hash */);
 
 }  // namespace ptgnn_amd

@@ -44,6 +44,8 @@ struct WsArgs {
   float *partial;                // [workgroups][WA * WB]
   float *colsum_partial;         // [groups * mtiles][WA] (dense form, k-tile 0)
   DropoutParams drop;
+  const uint32_t *mask;          // DROP == 2: keep bits [d_msg rows][mask_ld] dwords (ptgnn_amd_dropout_bitmask)
+  int mask_ld;
 };
 
 template <int N> struct Vec;
@@ -71,7 +73,9 @@ __device__ __forceinline__ void store_vec(float *p, const float (&v)[N]) {
   else *p = v[0];
 }
 
-template <int NBA, int NBB, bool DROP, bool COLSUM, bool GATHER>
+// DROP: 0 none, 1 = keep mask from the hash of dense_common.h (~55 VALU instructions per step), 2 = keep mask as bits
+// (one dword load + ~13 VALU per step; fp32 MFMA shares the vector lanes with the VALU, so this is kernel time)
+template <int NBA, int NBB, int DROP, bool COLSUM, bool GATHER>
 __global__ __launch_bounds__(kWavesPerWg * 64, 1) void k_wgrad_stream(WsArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WA = 32 * NBA, WB = 32 * NBB, D = kDepth;
@@ -140,11 +144,27 @@ __global__ __launch_bounds__(kWavesPerWg * 64, 1) void k_wgrad_stream(WsArgs p) 
   if (nsteps > 0) {
     float a[D][NBA], b[D][NBB];
     int nid1[D], nid2[D];                                 // node ids of the next block and of the one after
+    uint32_t mw[D];                                       // DROP == 2: the mask dword of each row in flight
+    const int mword = colb >> 5, mshift = colb & 31;      // this lane's four columns inside the row's mask
+    auto mask_at = [&](int64_t e) -> const uint32_t * {
+      return p.mask + (uint64_t)(unsigned)(gm_row0 + e) * (unsigned)p.mask_ld + mword;
+    };
+    auto masked4 = [&](float (&bv)[NBB], uint32_t w) {
+      if constexpr (NBB == 4) {
+        const uint32_t m = w >> mshift;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = ((int)(m << (31 - i))) >> 31;
+          bv[i] = __uint_as_float(__float_as_uint(bv[i] * p.drop.scale) & (uint32_t)t);
+        }
+      }
+    };
 #pragma unroll
     for (int s = 0; s < D; ++s) {
       const int64_t e = edge_at(s);
       load_vec<NBA>(a_col + gm_off(e), a[s]);
       load_vec<NBB>(b_col + x_off(raw_id(e)), b[s]);
+      if constexpr (DROP == 2) mw[s] = *mask_at(e);
     }
 #pragma unroll
     for (int s = 0; s < D; ++s) nid1[s] = raw_id(edge_at(D + s));
@@ -167,6 +187,9 @@ __global__ __launch_bounds__(kWavesPerWg * 64, 1) void k_wgrad_stream(WsArgs p) 
       const char *const bbase = reinterpret_cast<const char *>(b_col);
       const char *pb = bbase + (uint64_t)(unsigned)(e0 + 2 * D + hi) * ldxb;                   // dense form: row e of x
       const uint64_t bstep = 2ull * ldxb;
+      const uint32_t *pm = nullptr;
+      if constexpr (DROP == 2) pm = mask_at(e0 + 2 * D + hi);
+      const unsigned mstep = 2u * (unsigned)p.mask_ld;
       const int *pid = nullptr;
       if constexpr (GATHER) pid = reinterpret_cast<const int *>(idx) + 2 * (e0 + hi) + 4 * (2 * D);   // block 2, slot 0
       for (; j < nfast; ++j) {
@@ -180,11 +203,12 @@ __global__ __launch_bounds__(kWavesPerWg * 64, 1) void k_wgrad_stream(WsArgs p) 
           float bv[NBB];
 #pragma unroll
           for (int i = 0; i < NBB; ++i) bv[i] = b[s][i];
-          if constexpr (DROP) {
+          if constexpr (DROP == 1) {
             const int64_t e = e0 + 2 * (int64_t)(j * D + s) + hi;
             const float4 m4 = dropout_apply4(p.drop, gm_row0 + e, colb, make_float4(bv[0], bv[1], bv[2], bv[3]));
             bv[0] = m4.x; bv[1] = m4.y; bv[2] = m4.z; bv[3] = m4.w;
           }
+          if constexpr (DROP == 2) masked4(bv, mw[s]);
           if constexpr (COLSUM) {
 #pragma unroll
             for (int i = 0; i < NBA; ++i) cs[i] += a[s][i];
@@ -209,6 +233,7 @@ __global__ __launch_bounds__(kWavesPerWg * 64, 1) void k_wgrad_stream(WsArgs p) 
             load_vec<NBB>(reinterpret_cast<const float *>(pb), b[s]);
             pb += bstep;
           }
+          if constexpr (DROP == 2) { mw[s] = *pm; pm += mstep; }
 #endif
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -236,12 +261,13 @@ __global__ __launch_bounds__(kWavesPerWg * 64, 1) void k_wgrad_stream(WsArgs p) 
         for (int i = 0; i < NBA; ++i) av[i] = valid ? a[s][i] : 0.f;
 #pragma unroll
         for (int i = 0; i < NBB; ++i) bv[i] = b[s][i];
-        if constexpr (DROP) {
-          static_assert(!DROP || NBB == 4, "dropout masks are generated per float4 of the input row");
+        static_assert(DROP == 0 || NBB == 4, "dropout masks are applied per float4 of the input row");
+        if constexpr (DROP == 1) {
           const float4 m4 = dropout_apply4(p.drop, gm_row0 + (valid ? e : e1 - 1), colb,
                                            make_float4(bv[0], bv[1], bv[2], bv[3]));
           bv[0] = m4.x; bv[1] = m4.y; bv[2] = m4.z; bv[3] = m4.w;
         }
+        if constexpr (DROP == 2) masked4(bv, mw[s]);
         if constexpr (COLSUM) {
 #pragma unroll
           for (int i = 0; i < NBA; ++i) cs[i] += av[i];
@@ -258,6 +284,7 @@ __global__ __launch_bounds__(kWavesPerWg * 64, 1) void k_wgrad_stream(WsArgs p) 
         const int64_t en = edge_at((j + 1) * D + s);
         load_vec<NBA>(a_col + gm_off(en), a[s]);
         load_vec<NBB>(b_col + x_off(nid1[s]), b[s]);
+        if constexpr (DROP == 2) mw[s] = *mask_at(en);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -393,7 +420,7 @@ size_t stream_wgrad_workspace_floats(int64_t num_edges, int num_types, int msg_d
 int stream_wgrad(const WsTable &tab_in, const float *x, int64_t ld_x, int64_t num_rows, int state_dim, int use_dst,
                  const float *gm, int64_t ld_gm, int64_t gm_row_base, int msg_dim, float dropout_p, uint64_t dropout_seed,
                  float *grad_w, int type_base, float *grad_b, float *workspace, size_t workspace_floats,
-                 hipStream_t st) {
+                 hipStream_t st, const uint32_t *mask_bits) {
   static const bool off = getenv("PTGNN_AMD_WGRAD_STREAM") && getenv("PTGNN_AMD_WGRAD_STREAM")[0] == '0';
   if (off) return 0;
   const DropoutParams drop = make_dropout(dropout_p, dropout_seed, state_dim);
@@ -403,6 +430,7 @@ int stream_wgrad(const WsTable &tab_in, const float *x, int64_t ld_x, int64_t nu
   // (a k-tile may straddle the [src ; dst] seam: which half -- table, id list -- a lane reads is decided per lane, and
   //  a lane's NBB columns never straddle it because state_dim % 4 == 0)
   if (drop.thr != 0 && nbb != 4) return 0;
+  if (mask_bits && (state_dim % 32 != 0 || use_dst)) return 0;
   if (ld_x >= ((int64_t)1 << 29) || ld_gm >= ((int64_t)1 << 29) || num_rows >= ((int64_t)1 << 31)) return 0;
   const int WA = 32 * nba, WB = 32 * nbb;
   const int mtiles = msg_dim / WA, ktiles = K / WB, tiles = mtiles * ktiles;
@@ -432,6 +460,7 @@ int stream_wgrad(const WsTable &tab_in, const float *x, int64_t ld_x, int64_t nu
   p.partial = workspace;
   p.colsum_partial = workspace + (size_t)total * WA * WB;
   p.drop = drop;
+  p.mask = mask_bits; p.mask_ld = state_dim / 32;
   size_t lds = (size_t)kWavesPerWg * nbb * 16 * 64 * sizeof(float);   // one row of C blocks per wave
   if (lds < (size_t)2 * kWavesPerWg * WA * sizeof(float)) lds = (size_t)2 * kWavesPerWg * WA * sizeof(float);
   const bool colsum = grad_b != nullptr, dropout = drop.thr != 0;
@@ -440,22 +469,23 @@ int stream_wgrad(const WsTable &tab_in, const float *x, int64_t ld_x, int64_t nu
 #define PTGNN_WS_LAUNCH(NBA_, NBB_, DROP_, CS_)                                      \
   do {                                                                               \
     auto kern = gather ? k_wgrad_stream<NBA_, NBB_, DROP_, false, true>              \
-                       : k_wgrad_stream<NBA_, NBB_, false, CS_, false>;              \
+                       : k_wgrad_stream<NBA_, NBB_, 0, CS_, false>;                  \
     if (!set_lds(kern, lds)) return 0;                                               \
     kern<<<(unsigned)xcd_padded_blocks(total), kWavesPerWg * 64, lds, st>>>(p);                         \
   } while (0)
 #define PTGNN_WS_NBB(NBA_)                                                           \
   do {                                                                               \
     if (nbb == 4) {                                                                  \
-      if (dropout) PTGNN_WS_LAUNCH(NBA_, 4, true, false);                            \
-      else if (colsum) PTGNN_WS_LAUNCH(NBA_, 4, false, true);                        \
-      else PTGNN_WS_LAUNCH(NBA_, 4, false, false);                                   \
+      if (dropout && mask_bits) PTGNN_WS_LAUNCH(NBA_, 4, 2, false);                  \
+      else if (dropout) PTGNN_WS_LAUNCH(NBA_, 4, 1, false);                          \
+      else if (colsum) PTGNN_WS_LAUNCH(NBA_, 4, 0, true);                            \
+      else PTGNN_WS_LAUNCH(NBA_, 4, 0, false);                                       \
     } else if (nbb == 2) {                                                           \
-      if (colsum) PTGNN_WS_LAUNCH(NBA_, 2, false, true);                             \
-      else PTGNN_WS_LAUNCH(NBA_, 2, false, false);                                   \
+      if (colsum) PTGNN_WS_LAUNCH(NBA_, 2, 0, true);                                 \
+      else PTGNN_WS_LAUNCH(NBA_, 2, 0, false);                                       \
     } else {                                                                         \
-      if (colsum) PTGNN_WS_LAUNCH(NBA_, 1, false, true);                             \
-      else PTGNN_WS_LAUNCH(NBA_, 1, false, false);                                   \
+      if (colsum) PTGNN_WS_LAUNCH(NBA_, 1, 0, true);                                 \
+      else PTGNN_WS_LAUNCH(NBA_, 1, 0, false);                                       \
     }                                                                                \
   } while (0)
   if (nba == 4) PTGNN_WS_NBB(4); else if (nba == 2) PTGNN_WS_NBB(2); else PTGNN_WS_NBB(1);

@@ -793,12 +793,37 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+def dropout_bitmask(rows: int, width: int, p: float, seed: int, device) -> Optional[torch.Tensor]:
+    """Keep mask of the per-edge dropout as one bit per element: int32 [rows, width / 32], bit b of word c = column
+    32 c + b (ptgnn_amd_dropout_bitmask; the same hash of (seed, row, column) the seed-taking entry points evaluate).
+    None when `width` is not a multiple of 32 (callers then stay on the hash form)."""
+    if width % 32 != 0 or rows <= 0 or p <= 0.0:
+        return None
+    lib = _lib.load()
+    bits = torch.empty(rows, width // 32, dtype=torch.int32, device=device)
+    with _timed("dropout_bitmask", bytes=rows * width / 8.0):
+        rc = lib.ptgnn_amd_dropout_bitmask(rows, width, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, bits.data_ptr(),
+                                           _stream(bits))
+    _lib.check(rc, "ptgnn_amd_dropout_bitmask")
+    return bits
+
+
+def edge_linear_masked_supported(state_dim: int, msg_dim: int, mode: int) -> bool:
+    return bool(_lib.load().ptgnn_amd_edge_linear_masked_supported(int(state_dim), int(msg_dim), int(mode)))
+
+
+def edge_weight_grad_masked_supported(state_dim: int, msg_dim: int) -> bool:
+    return bool(_lib.load().ptgnn_amd_edge_weight_grad_masked_supported(int(state_dim), int(msg_dim)))
+
+
 def edge_linear(x: torch.Tensor, adjacency_lists, weights: Sequence[torch.Tensor], use_dst: bool,
-                act: Optional[str] = None, dropout: Optional[Tuple[int, float, int]] = None) -> torch.Tensor:
+                act: Optional[str] = None, dropout: Optional[Tuple[int, float, int]] = None,
+                mask_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
     """msg[off_t + e] = act([x[src_t[e]] ; x[dst_t[e]] (if use_dst)] W_t^T) for every edge type in one
     launch; rows in type-major message order.  weights[t] is the type's nn.Linear weight.
     dropout = (mode, p, seed): nn.Dropout(p) on the gathered input rows (mode 1) or on the output rows
-    (mode 2, the input-gradient form) with the hash mask of ptgnn_amd_edge_linear_dropout_f32."""
+    (mode 2, the input-gradient form) with the hash mask of ptgnn_amd_edge_linear_dropout_f32; with
+    `mask_bits` (`dropout_bitmask` of the same p and seed) the streaming kernel applies the mask from its bits."""
     lib = _lib.load()
     _require_cuda_f32("x", x)
     x = _rowmajor(x)
@@ -824,6 +849,18 @@ def edge_linear(x: torch.Tensor, adjacency_lists, weights: Sequence[torch.Tensor
     if dropout is not None and dropout[0] != 0 and dropout[1] > 0.0:
         if use_dst or act is not None:
             raise _lib.PtgnnAmdError("edge_linear: dropout supports the GGNN form only (no target half, no act)")
+        if mask_bits is not None and E > 0 and edge_linear_masked_supported(H, M, dropout[0]):
+            words = (M if dropout[0] == 2 else H) // 32
+            if tuple(mask_bits.shape) != (E, words) or mask_bits.dtype != torch.int32 or not mask_bits.is_cuda:
+                raise _lib.PtgnnAmdError(f"edge_linear: mask_bits must be int32 [{E}, {words}] on the device")
+            mask_bits = mask_bits.contiguous()
+            with _timed("edge_linear", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
+                rc = lib.ptgnn_amd_edge_linear_masked_f32(
+                    x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),
+                    ctypes.cast(cn, ctypes.c_void_p), ctypes.cast(wp, ctypes.c_void_p), T, M, msg.data_ptr(), M,
+                    int(dropout[0]), float(dropout[1]), mask_bits.data_ptr(), _stream(msg))
+            _lib.check(rc, "ptgnn_amd_edge_linear_masked_f32")
+            return msg[:E]
         with _timed("edge_linear", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
             rc = lib.ptgnn_amd_edge_linear_dropout_f32(
                 x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),
@@ -843,8 +880,10 @@ def edge_linear(x: torch.Tensor, adjacency_lists, weights: Sequence[torch.Tensor
 
 
 def edge_weight_grad(x: torch.Tensor, adjacency_lists, grad_msg: torch.Tensor, use_dst: bool,
-                     dropout_p: float = 0.0, dropout_seed: int = 0) -> torch.Tensor:
-    """grad_w[t] = grad_msg_t^T . [x[src_t] ; x[dst_t] (if use_dst)]  for all types -> [T, M, K]."""
+                     dropout_p: float = 0.0, dropout_seed: int = 0,
+                     mask_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """grad_w[t] = grad_msg_t^T . [x[src_t] ; x[dst_t] (if use_dst)]  for all types -> [T, M, K].
+    `mask_bits`: the dropout keep mask as bits (`dropout_bitmask` of the same p and seed) instead of the hash."""
     lib = _lib.load()
     _require_cuda_f32("x", x)
     _require_cuda_f32("grad_msg", grad_msg)
@@ -865,6 +904,18 @@ def edge_weight_grad(x: torch.Tensor, adjacency_lists, grad_msg: torch.Tensor, u
     ws_bytes = lib.ptgnn_amd_edge_wgrad_workspace_bytes(E, T, M, K)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
     gm_ptr = grad_msg.data_ptr() if E > 0 else x.data_ptr()
+    if (mask_bits is not None and dropout_p > 0.0 and E > 0 and not use_dst
+            and edge_weight_grad_masked_supported(H, M)):
+        if tuple(mask_bits.shape) != (E, H // 32) or mask_bits.dtype != torch.int32 or not mask_bits.is_cuda:
+            raise _lib.PtgnnAmdError(f"edge_weight_grad: mask_bits must be int32 [{E}, {H // 32}] on the device")
+        mask_bits = mask_bits.contiguous()
+        with _timed("edge_weight_grad", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
+            rc = lib.ptgnn_amd_edge_weight_grad_masked_f32(
+                x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),
+                ctypes.cast(cn, ctypes.c_void_p), gm_ptr, _ld(grad_msg), T, M, float(dropout_p),
+                mask_bits.data_ptr(), grad_w.data_ptr(), ws.data_ptr(), ws_bytes, _stream(grad_w))
+        _lib.check(rc, "ptgnn_amd_edge_weight_grad_masked_f32")
+        return grad_w
     with _timed("edge_weight_grad", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
         rc = lib.ptgnn_amd_edge_weight_grad_f32(
             x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),

@@ -179,20 +179,27 @@ class _EdgeLinear(torch.autograd.Function):
     """Per-edge message Linear of ALL edge types as one differentiable op (training form of the fused
     edge path):  msg[off_t + e] = W_t . Dropout([x[src_t[e]] ; x[dst_t[e]]]).
 
-    forward : grouped per-edge GEMM (edge_gemm.hip), dropout mask regenerated from (seed, row, column);
+    forward : grouped per-edge GEMM (stream_gemm.hip / edge_gemm.hip); the dropout mask is a hash of (seed, row,
+              column), evaluated once per call into ONE BIT per element (`ops.dropout_bitmask`) and kept for the
+              backward (shapes outside the streaming kernels re-evaluate the hash inside the tile kernels);
     backward: d W_t  = d msg_t^T . in_t              grouped split-edge GEMM (edge_wgrad.hip)
               d in   = (d msg . W_t) * mask          the same grouped GEMM over an identity index
               d x    = segment-sum of d in over the source rows (+ over the destination rows for the
                        target-state half): the HIP segment reduce over the transposed / forward plan.
-    No [E, K] gathered input and no mask tensor is kept between forward and backward.
+    No [E, K] gathered input is kept between forward and backward, and the mask only as bits (E * K / 8 bytes).
     """
 
     @staticmethod
     def forward(ctx, x, plan, use_dst, dropout_p, dropout_seed, w_stack):
         adj = plan._adj
         drop = (1, dropout_p, dropout_seed) if dropout_p > 0.0 else None
-        msg = ops.edge_linear(x, adj, list(w_stack.unbind(0)), use_dst, dropout=drop)
-        ctx.plan, ctx.use_dst, ctx.drop = plan, use_dst, (dropout_p, dropout_seed)
+        # the keep mask as one bit per element (E * H / 8 bytes), generated once and shared by the forward, the input
+        # gradient and the weight gradient: the hash inside three GEMMs is kernel time (fp32 MFMA shares the VALU lanes)
+        bits = None
+        if drop is not None and not use_dst and plan.num_edges > 0:
+            bits = ops.dropout_bitmask(plan.num_edges, x.shape[1], dropout_p, dropout_seed, x.device)
+        msg = ops.edge_linear(x, adj, list(w_stack.unbind(0)), use_dst, dropout=drop, mask_bits=bits)
+        ctx.plan, ctx.use_dst, ctx.drop, ctx.bits = plan, use_dst, (dropout_p, dropout_seed), bits
         ctx.save_for_backward(x, w_stack)
         return msg
 
@@ -207,7 +214,7 @@ class _EdgeLinear(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         d_x = d_w = None
         if ctx.needs_input_grad[5]:
-            d_w = ops.edge_weight_grad(x, adj, gm, use_dst, p, seed)           # [T, M, K], one tensor
+            d_w = ops.edge_weight_grad(x, adj, gm, use_dst, p, seed, mask_bits=ctx.bits)   # [T, M, K], one tensor
         if need_x:
             if plan.num_edges == 0:
                 d_x = torch.zeros_like(x)
@@ -215,7 +222,7 @@ class _EdgeLinear(torch.autograd.Function):
                 wt = w_stack.detach().transpose(1, 2).contiguous()                             # [T, K, M]
                 drop = (2, p, seed) if p > 0.0 else None
                 g_in = ops.edge_linear(gm, [(i, i) for i in plan.identity_index()], list(wt.unbind(0)),
-                                       False, dropout=drop)                                   # [E, K]
+                                       False, dropout=drop, mask_bits=ctx.bits)               # [E, K]
                 tp = plan.transposed_plan()
                 d_x = ops.gather_reduce(g_in[:, :H] if use_dst else g_in, tp, H, "sum", type_bits=0,
                                         col=tp.perm)

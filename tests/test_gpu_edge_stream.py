@@ -1,0 +1,171 @@
+"""GPU tests of the fence-free streaming edge GEMM (`k_stream_edge_v2`) and of the per-edge dropout carried as a bit
+mask (round 4).  Through the C ABI, against (a) float64, (b) the tile kernels of GEMM mode 0, which accumulate K in the
+same order -- bit for bit --, and (c) the numpy restatement of the dropout hash in tests/helpers.py.
+Reference semantics: gatedmessagepassing.py:54-61 (`Linear(Dropout(x_src))` per edge type, messages in type-major
+order)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import dropout_keep_scale, to_cuda_adj
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+# ragged type sizes around the 32-edge unit: empty types, one edge, 31 / 32 / 33, and runs long enough that every
+# workgroup of a type walks several units
+COUNTS = [1000, 0, 129, 1, 128, 513, 31, 32, 33, 40000, 7]
+
+
+def _graph(n, counts, seed):
+    g = torch.Generator().manual_seed(seed)
+    adj = [(torch.randint(0, n, (c,), generator=g), torch.randint(0, n, (c,), generator=g)) for c in counts]
+    return g, adj
+
+
+def _bits_to_keep(bits: torch.Tensor, width: int) -> np.ndarray:
+    w = bits.cpu().numpy().view(np.uint32)
+    cols = np.arange(width)
+    return ((w[:, cols // 32] >> (cols % 32).astype(np.uint32)) & 1).astype(bool)
+
+
+@pytest.mark.parametrize("use_dst", [False, True])
+@pytest.mark.parametrize("H,M", [(128, 128), (64, 64), (256, 128), (64, 128), (128, 64), (32, 64), (128, 256)])
+def test_fence_free_edge_gemm_equals_tile_kernels_bitwise_and_fp64(use_dst, H, M):
+    from ptgnn_amd import ops
+    K = 2 * H if use_dst else H
+    if K > 256:
+        pytest.skip("K = 512 is outside the streaming edge GEMM")
+    n = 3000
+    g, adj = _graph(n, COUNTS, H * 7 + M + use_dst)
+    x = torch.randn(n, H, generator=g)
+    ws = [torch.randn(M, K, generator=g) / K ** 0.5 for _ in COUNTS]
+    want = torch.cat([(torch.cat([x[s], x[d]], -1) if use_dst else x[s]).double() @ w.double().t()
+                      for (s, d), w in zip(adj, ws)]).float()
+    cadj, cws, cx = to_cuda_adj(adj), [w.cuda() for w in ws], x.cuda()
+    got = ops.edge_linear(cx, cadj, cws, use_dst)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=TOL)
+    prev = ops.set_gemm_mode("tile")
+    try:
+        tile = ops.edge_linear(cx, cadj, cws, use_dst)
+    finally:
+        ops.set_gemm_mode(prev)
+    assert torch.equal(got, tile)          # one K accumulation order for every exact-fp32 kernel
+    assert torch.equal(got, ops.edge_linear(cx, cadj, cws, use_dst))   # deterministic
+
+
+@pytest.mark.parametrize("H,M", [(128, 128), (64, 64), (256, 128), (128, 64), (64, 128)])
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_bitmask_dropout_equals_the_hash_form_and_the_numpy_restatement(H, M, p):
+    """ptgnn_amd_dropout_bitmask == the restated hash, element for element; the masked forward / input-gradient /
+    weight-gradient entry points == their hash-evaluating twins bit for bit, and == float64 on the restated mask."""
+    from ptgnn_amd import ops
+    n, seed = 2000, 0x1234_5678_9ABC_DEF + H
+    counts = [700, 0, 130, 1, 33, 20000]
+    E = sum(counts)
+    g, adj = _graph(n, counts, H + M)
+    x = torch.randn(n, H, generator=g)
+    ws = [torch.randn(M, H, generator=g) / H ** 0.5 for _ in counts]
+    mask = dropout_keep_scale(seed, E, H, p)
+    bits = ops.dropout_bitmask(E, H, p, seed, "cuda")
+    assert bits is not None and tuple(bits.shape) == (E, H // 32)
+    np.testing.assert_array_equal(_bits_to_keep(bits, H), mask.numpy() != 0)
+
+    off = np.cumsum([0] + counts)
+    xin = torch.cat([x[s] for s, _ in adj]) * mask
+    cadj, cws, cx = to_cuda_adj(adj), [w.cuda() for w in ws], x.cuda()
+    # forward
+    assert ops.edge_linear_masked_supported(H, M, 1)
+    want = torch.cat([xin[off[t]:off[t + 1]].double() @ ws[t].double().t() for t in range(len(counts))]).float()
+    got = ops.edge_linear(cx, cadj, cws, False, dropout=(1, p, seed), mask_bits=bits)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=TOL)
+    assert torch.equal(got, ops.edge_linear(cx, cadj, cws, False, dropout=(1, p, seed)))       # hash form (tile kernel)
+    # input gradient: (d_msg . W_t) * mask over an identity index
+    assert ops.edge_linear_masked_supported(M, H, 2)
+    gm = torch.randn(E, M, generator=g)
+    want = torch.cat([gm[off[t]:off[t + 1]].double() @ ws[t].double() for t in range(len(counts))]).float() * mask
+    ident = torch.arange(E).cuda()
+    iadj = [(ident[off[t]:off[t + 1]], ident[off[t]:off[t + 1]]) for t in range(len(counts))]
+    wts = [w.t().contiguous().cuda() for w in ws]
+    got = ops.edge_linear(gm.cuda(), iadj, wts, False, dropout=(2, p, seed), mask_bits=bits)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=TOL)
+    assert torch.equal(got, ops.edge_linear(gm.cuda(), iadj, wts, False, dropout=(2, p, seed)))
+    # weight gradient
+    want = torch.stack([gm[off[t]:off[t + 1]].double().t() @ xin[off[t]:off[t + 1]].double()
+                        for t in range(len(counts))]).float()
+    got = ops.edge_weight_grad(cx, cadj, gm.cuda(), False, p, seed, mask_bits=bits)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0,
+                               atol=1e-5 * max(1.0, float(want.abs().max())))
+    if ops.edge_weight_grad_masked_supported(H, M):
+        assert torch.equal(got, ops.edge_weight_grad(cx, cadj, gm.cuda(), False, p, seed))
+
+
+def test_masked_entry_points_refuse_shapes_outside_the_streaming_kernels():
+    from ptgnn_amd import _lib, ops
+    assert not ops.edge_linear_masked_supported(96, 128, 1)
+    assert not ops.edge_linear_masked_supported(128, 96, 2)
+    assert not ops.edge_weight_grad_masked_supported(64, 128)
+    assert ops.dropout_bitmask(10, 48, 0.1, 1, "cuda") is None          # width % 32 != 0: callers stay on the hash form
+    lib = _lib.load()
+    x = torch.randn(8, 96, device="cuda")
+    bits = torch.zeros(4, 3, dtype=torch.int32, device="cuda")
+    msg = torch.empty(4, 128, device="cuda")
+    rc = lib.ptgnn_amd_edge_linear_masked_f32(x.data_ptr(), 96, 8, 96, None, None, None, 0, 128, msg.data_ptr(), 128, 1,
+                                              0.5, bits.data_ptr(), None)
+    assert rc != 0 and b"not a shape" in lib.ptgnn_amd_last_error()
+
+
+@pytest.mark.parametrize("agg", ["sum", "max"])
+@pytest.mark.parametrize("H", [128, 64])
+def test_ggnn_training_step_with_bitmask_dropout_matches_oracle_autograd(agg, H, monkeypatch):
+    """The shipped Typilus configuration (GGNN, hidden 128, per-edge dropout; typilus/train.py:39-65,
+    gatedmessagepassing.py:57-61) at widths the streaming kernels take: forward, d x, d W_t, d GRU against the oracle's
+    torch-CPU autograd with the restated mask, and the launches are the masked ones."""
+    from helpers import empty_feats
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, ops, workloads
+    mb = workloads.batched_graphs(4, 300, 4, 2.2, seed=5)
+    N, M, p, seed = mb["num_nodes"], H, 0.1, 987654321987
+    adj = O.augment_adjacency(mb["adjacency_lists"], N, True, True)
+    T = len(adj)
+    torch.manual_seed(3)
+    layer = L.GatedMessagePassingLayer(H, M, T, agg, dropout_rate=p).train()
+    monkeypatch.setattr(L, "_dropout_seed", lambda: seed)
+    x = workloads.node_states(N, H, seed=6)
+    gout = workloads.node_states(N, H, seed=7)
+    spec = layer.export_weights()
+    E = sum(int(a[0].shape[0]) for a in adj)
+    mask = dropout_keep_scale(seed, E, H, p)
+
+    xo = x.clone().requires_grad_(True)
+    ws = [w.clone().requires_grad_(True) for w in spec["edge_w"]]
+    gru = [spec[k].clone().requires_grad_(True) for k in ("w_ih", "w_hh", "b_ih", "b_hh")]
+    off = np.cumsum([0] + [int(a[0].shape[0]) for a in adj])
+    msgs = torch.cat([O.linear(xo[s] * mask[off[t]:off[t + 1]], ws[t]) for t, (s, _) in enumerate(adj)])
+    yo = O.gru_cell(O.aggregate_messages(msgs, torch.cat([d for _, d in adj]), N, agg), xo, *gru)
+    yo.backward(gout)
+
+    layer = layer.cuda()
+    xg = x.cuda().requires_grad_(True)
+    cadj = to_cuda_adj(adj)
+    ops.clear_plan_cache()
+    timer = ops.KernelTimer()
+    ops.set_kernel_timer(timer)
+    yg = layer(xg, cadj, None, {}, {}, empty_feats(cadj, "cuda"))
+    yg.backward(gout.cuda())
+    ops.set_kernel_timer(None)
+    used = timer.summary()
+    assert used["dropout_bitmask"]["calls"] == 1 and used["edge_linear"]["calls"] == 2 \
+        and used["edge_weight_grad"]["calls"] == 1, used
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yo.detach().numpy(), rtol=0, atol=TOL)
+    sc = max(1.0, float(xo.grad.abs().max()))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=0, atol=2e-5 * sc)
+    sd = layer.state_dict(keep_vars=True)
+    for t in range(T):
+        ours = sd[f"_GatedMessagePassingLayer__edge_message_transformation_layers.{t}.weight"].grad
+        sc = max(1.0, float(ws[t].grad.abs().max()))
+        np.testing.assert_allclose(ours.cpu().numpy(), ws[t].grad.numpy(), rtol=0, atol=2e-5 * sc)
+    ours = sd["_GatedMessagePassingLayer__state_update.weight_ih"].grad
+    np.testing.assert_allclose(ours.cpu().numpy(), gru[0].grad.numpy(), rtol=0,
+                               atol=2e-5 * max(1.0, float(gru[0].grad.abs().max())))
