@@ -976,34 +976,32 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
 }
 
 // ---------------------------------------------------------------------------------------------------
-// grouped per-edge GEMM, fence-free unit body (exact fp32, K in {64, 128, 256}, M in {64, 128}, no activation).
+// grouped per-edge GEMM with the reference's per-edge dropout (gatedmessagepassing.py:57-61, training): exact fp32,
+// K in {64, 128, 256}, M in {64, 128}, no activation.  The keep mask arrives as ONE BIT per element
+// (`ptgnn_amd_dropout_bitmask`: the hash of dense_common.h evaluated once per layer call instead of inside three GEMMs --
+// the hash costs ~55 VALU instructions per 16 MFMAs, and fp32 MFMA shares the vector lanes with the VALU):
+//   DROP 1  mask on the gathered INPUT rows (forward): one mask dword per (message row, 32-column chunk) rides with the
+//           chunk's four row pieces; 3-4 VALU per element (bit -> all-ones, scale, and);
+//   DROP 2  mask on the OUTPUT rows (input gradient, d in = (d msg . W) * mask): the row's mask dwords are fetched at the
+//           top of the unit and applied to the transposed float4 right before its store.
+// Same chunk order, k permutation and MFMA sequence per accumulator as k_stream_edge and the tile kernel: identical bits.
 //
-// k_stream_edge starts every unit from a drained memory queue (`unit_fence`): its epilogue stores are conditional (ragged
-// last unit of a type) and its K loop is a loop, and with either the compiler cannot count the loads that are in flight
-// across a unit boundary -- it falls back to waiting for everything, which includes the ACKNOWLEDGEMENT of the sixteen
-// row stores the previous unit issued a few hundred cycles earlier (~15 % of the kernel, profiles/r03_notes.md 12).
-// vmcnt retires in issue order, so a wait for loads that were issued BEFORE the stores (the next unit's first two chunks
-// are) never has to cover them -- if the compiler can prove what the queue holds.  Here it can:
-//   * the K loop is unrolled over a compile-time chunk count, so the unit loop is one straight-line body;
-//   * every store is issued unconditionally: lanes of rows past a type's end write to a sink buffer instead of being
-//     masked off (a store the program may skip cannot be counted);
-//   * the prologue of a segment leaves the queue in exactly the state the loop body leaves it in -- first two chunks,
-//     the id loads of the unit after, sixteen (sink) stores -- so both ways into the loop header agree.
-// The result: `s_waitcnt vmcnt(N)` with N >= 16 at the top of a unit, no drain anywhere in the loop.
-// Same chunk order, k permutation and MFMA sequence per accumulator as k_stream_edge: identical bits.
-//
-// DROP (the reference's per-edge dropout, gatedmessagepassing.py:57-61, training only): the keep mask arrives as ONE BIT
-// per element (`ptgnn_amd_dropout_bitmask`, the hash of dense_common.h evaluated once per layer call instead of inside
-// three GEMMs: the hash costs ~55 VALU instructions per 16 MFMAs, and fp32 MFMA shares the vector lanes with the VALU).
-//   1  mask on the gathered INPUT rows (forward):       one mask dword per (message row, 32-column chunk) rides with
-//      the chunk's four row pieces; 3 VALU per element (bit -> all-ones, scale, and);
-//   2  mask on the OUTPUT rows (input gradient, d in = (d msg . W) * mask): the row's mask dwords are fetched at the top
-//      of the unit and applied to the transposed float4 right before its store.
+// The unit body is straight-line -- the K loop is unrolled over a compile-time chunk count and every row store is issued
+// unconditionally (lanes of rows past a type's end write to a sink buffer instead of being masked off) -- so the
+// compiler counts every wait across the unit boundary: `s_waitcnt vmcnt(N)` per piece, no drain anywhere in the loop.
+// This was built as the "fence-free" form of k_stream_edge and MEASURED AS SUCH (DROP 0, same shapes,
+// alternating launches in one process, profiles/r04_notes.md 1): with the queue shape of the prologue matched to the
+// loop body (sixteen sink stores, so that the unit starts on `vmcnt(25)` and never waits for a store acknowledgement)
+// it is 4-7 % SLOWER than k_stream_edge with its per-unit drain; without them (a small `vmcnt` at the unit top that does
+// cover the previous unit's stores, like the drain) it is level with it; re-inserting the drain costs nothing; sending
+// every store to the cache-resident sink gains 2 %.  So the stores' acknowledgement was never what the edge GEMM waits
+// for (PMC: 6 % of wave cycles in s_waitcnt here against 11 % there, at MORE total cycles).  k_stream_edge therefore
+// stays the DROP 0 kernel and only the dropout forms are instantiated from this one.
 // ---------------------------------------------------------------------------------------------------
 }  // namespace
 
-// sink of the unconditional stores: external linkage, so the stores cannot be proven dead
-__device__ float4 ptgnn_amd_edge_store_sink[64 * 17];
+// sink of the unconditional stores (rows past a type's end): external linkage, so the stores cannot be proven dead
+__device__ float4 ptgnn_amd_edge_store_sink[64 + 32];
 
 namespace {
 
@@ -1167,14 +1165,6 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
       int64_t e_n = edge_of(nxt);
       int64_t s_n = src[e_n], d_n = dst[e_n];    // consumed inside the first unit
       __builtin_amdgcn_sched_barrier(0);
-      {                                          // the queue shape the loop body leaves behind: sixteen stores
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < 4 * NB; ++i) {
-          *reinterpret_cast<float4 *>(sink + (i + 1) * 256) = z;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
       f32x16 acc[NB];
 #pragma unroll
       for (int n = 0; n < NB; ++n) acc[n] = zero16();
@@ -1226,11 +1216,12 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
         // epilogue: C fragments -> rows through the wave's transposing slab, every store issued
         {
           float *const yp = p.msg + (out_row0 + srow) * p.ld_msg + scol;
+          // column block outer, row group inner (k_stream_edge's order; the other nesting measured 4 % slower)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float *const yr = 8 * r + srow < left ? yp + (int64_t)(8 * r) * p.ld_msg : sink;
+          for (int n = 0; n < NB; ++n) {
 #pragma unroll
-            for (int n = 0; n < NB; ++n) {
+            for (int r = 0; r < 4; ++r) {
+              float *const yr = 8 * r + srow < left ? yp + (int64_t)(8 * r) * p.ld_msg : sink;
               float4 o = tq_transpose(tq, lane, li, hi, acc[n][4 * r], acc[n][4 * r + 1], acc[n][4 * r + 2],
                                       acc[n][4 * r + 3]);
               if constexpr (DROP == 2) {
@@ -1429,22 +1420,20 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
   return 1;
 }
 
-// The fence-free kernel takes: exact fp32, no activation, K in {64, 128, 256}, message width 64 or 128.
+// The dropout forms take: exact fp32, no activation, no target-state half, K in {64, 128, 256}, message width 64 or 128.
 static bool edge_v2_shape(int32_t state_dim, int32_t msg_dim, int use_dst, int act) {
-  static int off = -1;
-  if (off < 0) { const char *e = getenv("PTGNN_AMD_EDGE_V2"); off = (e && e[0] == '0') ? 1 : 0; }   // A/B knob
-  if (off || stream_gemm_mode() != 1 || act != PTGNN_AMD_ACT_NONE) return false;
-  const int K = use_dst ? 2 * state_dim : state_dim;
-  if (!(K == 64 || K == 128 || K == 256) || state_dim % 32 != 0) return false;
+  if (stream_gemm_mode() != 1 || act != PTGNN_AMD_ACT_NONE || use_dst) return false;
+  const int K = state_dim;
+  if (!(K == 64 || K == 128 || K == 256)) return false;
   if (!(msg_dim == 64 || msg_dim == 128)) return false;
   return Slab<false>::bytes(K, msg_dim) + kEpiBytes <= (size_t)kLdsBudget;
 }
 
-template <int DROP, int VAR>
+template <int DROP>
 static int edge_v2_launch(const EdgeV2Args &q, int K, int msg_dim, unsigned grid, size_t lds, hipStream_t st) {
 #define PTGNN_K(NBV, NCHV)                                            \
   do {                                                                \
-    auto kern = k_stream_edge_v2<NBV, NCHV, DROP, VAR>;          \
+    auto kern = k_stream_edge_v2<NBV, NCHV, DROP, 0>;                 \
     if (!set_lds(kern, lds)) return 0;                                \
     kern<<<grid, 512, lds, st>>>(q);                                  \
     return 1;                                                         \
@@ -1497,7 +1486,7 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   size_t slab = 0;
   const int kind = edge_plan(state_dim, msg_dim, use_dst, &slab);
   const bool v2 = edge_v2_shape(state_dim, msg_dim, use_dst, act);
-  if (mask && mask->mode != 0 && (!v2 || use_dst)) return 0;        // the dropout forms exist in the fence-free kernel only
+  if (mask && mask->mode != 0 && !v2) return 0;        // the dropout forms exist in k_stream_edge_v2 only
   if (kind == 0) return 0;
   const bool split = kind == 2;
   const int nb = msg_dim / 32;
@@ -1543,18 +1532,12 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   p.run_len = 0;
   p.lds_floats = (int)(slab / 4);
   const unsigned grid = (unsigned)p.tab.wg_off[tab.num_types];
-  if (v2) {
+  if (mask && mask->mode != 0) {
     EdgeV2Args q;
     q.e = p;
-    q.mask = mask ? mask->bits : nullptr; q.mask_ld = mask ? mask->ld : 0; q.mask_col0 = mask ? mask->col0 : 0;
-    q.scale = mask ? mask->scale : 1.f;
-    const int K = use_dst ? 2 * state_dim : state_dim;
-    const int mode = mask ? mask->mode : 0;
-    const int took = mode == 1 ? edge_v2_launch<1, 0>(q, K, msg_dim, grid, lds, st)
-                   : mode == 2 ? edge_v2_launch<2, 0>(q, K, msg_dim, grid, lds, st)
-                   : use_dst   ? edge_v2_launch<0, 2>(q, K, msg_dim, grid, lds, st)
-                               : edge_v2_launch<0, 0>(q, K, msg_dim, grid, lds, st);
-    if (took || mode != 0) return took;
+    q.mask = mask->bits; q.mask_ld = mask->ld; q.mask_col0 = mask->col0; q.scale = mask->scale;
+    return mask->mode == 1 ? edge_v2_launch<1>(q, state_dim, msg_dim, grid, lds, st)
+                           : edge_v2_launch<2>(q, state_dim, msg_dim, grid, lds, st);
   }
 #define PTGNN_K(NBV, SP)                                      \
   do {                                                        \
@@ -1589,11 +1572,6 @@ int stream_edge_indirect(const StreamEdgeTable *tab_dev, const float *const *w_p
   p.run_len = 0;
   p.lds_floats = (int)(slab / 4);
   const unsigned grid = (unsigned)edge_table_budget();
-  if (edge_v2_shape(state_dim, msg_dim, 0, act)) {
-    EdgeV2Args q;
-    q.e = p; q.mask = nullptr; q.mask_ld = 0; q.mask_col0 = 0; q.scale = 1.f;
-    if (edge_v2_launch<0, 1>(q, state_dim, msg_dim, grid, lds, st)) return 1;
-  }
 #define PTGNN_K(NBV, SP)                                      \
   do {                                                        \
     auto kern = k_stream_edge<NBV, SP, true>;                 \

@@ -1,5 +1,5 @@
-"""GPU tests of the fence-free streaming edge GEMM (`k_stream_edge_v2`) and of the per-edge dropout carried as a bit
-mask (round 4).  Through the C ABI, against (a) float64, (b) the tile kernels of GEMM mode 0, which accumulate K in the
+"""GPU tests of the streaming edge GEMMs (`k_stream_edge`, and `k_stream_edge_v2` = its dropout forms) and of the
+per-edge dropout carried as a bit mask (round 4).  Through the C ABI, against (a) float64, (b) the tile kernels of GEMM mode 0, which accumulate K in the
 same order -- bit for bit --, and (c) the numpy restatement of the dropout hash in tests/helpers.py.
 Reference semantics: gatedmessagepassing.py:54-61 (`Linear(Dropout(x_src))` per edge type, messages in type-major
 order)."""
@@ -32,7 +32,8 @@ def _bits_to_keep(bits: torch.Tensor, width: int) -> np.ndarray:
 
 @pytest.mark.parametrize("use_dst", [False, True])
 @pytest.mark.parametrize("H,M", [(128, 128), (64, 64), (256, 128), (64, 128), (128, 64), (32, 64), (128, 256)])
-def test_fence_free_edge_gemm_equals_tile_kernels_bitwise_and_fp64(use_dst, H, M):
+def test_streaming_edge_gemm_equals_tile_kernels_bitwise_and_fp64(use_dst, H, M):
+    """incl. the 256-wide output (two column slabs of 128: the input gradient of the last Typilus layer)."""
     from ptgnn_amd import ops
     K = 2 * H if use_dst else H
     if K > 256:
