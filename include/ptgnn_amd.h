@@ -69,6 +69,33 @@ int ptgnn_amd_set_gemm_mode(int mode);
 int ptgnn_amd_get_gemm_mode(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Which kernel family served a call is decided per call from shape, size and GEMM mode (the streaming
+ * kernels take widths that are multiples of 64 and, for `linear`, enough rows to fill the chip).
+ * ptgnn_amd_launch_count(id) returns how many launches of family `id` this process has made
+ * (host-side relaxed counters; tests take differences around a call to assert the dispatch);
+ * ptgnn_amd_launch_name(id) names it (NULL past the last id).
+ * PTGNN_AMD_FORCE_STREAM=1 in the environment (read per call) lifts the SIZE thresholds of the
+ * streaming `linear` dispatch, so that small reference fixtures can be replayed on it.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+  PTGNN_AMD_KERNEL_STREAM_LINEAR = 0,
+  PTGNN_AMD_KERNEL_STREAM_LINEAR_RING,
+  PTGNN_AMD_KERNEL_STREAM_GRU,
+  PTGNN_AMD_KERNEL_STREAM_GRU_RING,
+  PTGNN_AMD_KERNEL_STREAM_EDGE,
+  PTGNN_AMD_KERNEL_STREAM_EDGE_SHARED,
+  PTGNN_AMD_KERNEL_STREAM_EDGE_V2,
+  PTGNN_AMD_KERNEL_WGRAD_STREAM,
+  PTGNN_AMD_KERNEL_TILE_LINEAR,
+  PTGNN_AMD_KERNEL_TILE_GRU,
+  PTGNN_AMD_KERNEL_TILE_EDGE,
+  PTGNN_AMD_KERNEL_TILE_WGRAD,
+  PTGNN_AMD_KERNEL_COUNT_
+};
+int64_t ptgnn_amd_launch_count(int kernel_id);
+const char *ptgnn_amd_launch_name(int kernel_id);
+
+/* ------------------------------------------------------------------------------------------
  * Graph plan: merge the per-edge-type adjacency lists of one minibatch into ONE
  * destination-sorted CSR that all L message-passing layers of a forward reuse.
  *

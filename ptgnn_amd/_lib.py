@@ -20,6 +20,8 @@ SIGNATURES = {
     "ptgnn_amd_last_error": (_c.c_char_p, []),
     "ptgnn_amd_set_gemm_mode": (_c.c_int, [_c.c_int]),
     "ptgnn_amd_get_gemm_mode": (_c.c_int, []),
+    "ptgnn_amd_launch_count": (_i64, [_c.c_int]),
+    "ptgnn_amd_launch_name": (_c.c_char_p, [_c.c_int]),
     "ptgnn_amd_csr_workspace_bytes": (_c.c_size_t, [_i64, _i64]),
     "ptgnn_amd_csr_control_bytes": (_c.c_size_t, []),
     "ptgnn_amd_set_plan_path": (_c.c_int, [_c.c_int]),

@@ -9,6 +9,7 @@
 namespace ptgnn_amd {
 
 void set_error(const char *fmt, ...);
+void count_launch(int kernel_id);   // PTGNN_AMD_KERNEL_* of include/ptgnn_amd.h
 
 #define PTGNN_REQUIRE(cond, code, ...)            \
   do {                                            \

@@ -434,6 +434,7 @@ extern "C" int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int
 #undef PTGNN_LINEAR_ACT
 #undef PTGNN_LINEAR_LAUNCH
   PTGNN_LAUNCH_CHECK();
+  count_launch(PTGNN_AMD_KERNEL_TILE_LINEAR);
   return PTGNN_AMD_OK;
 }
 
@@ -463,6 +464,7 @@ static int gru_launch(const float *a, int64_t ld_a, const float *h, int64_t ld_h
     k_gru<false><<<grid, 256, 0, (hipStream_t)stream_>>>(a, ld_a, h, ld_h, w_ih, w_hh, b_ih, b_hh, n, m, hd,
                                                          out, ld_out, num_tiles, col_tiles, gates);
   PTGNN_LAUNCH_CHECK();
+  count_launch(PTGNN_AMD_KERNEL_TILE_GRU);
   return PTGNN_AMD_OK;
 }
 

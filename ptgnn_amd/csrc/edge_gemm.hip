@@ -361,6 +361,7 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
       }
 #undef PTGNN_EDGE_LAUNCH
       PTGNN_LAUNCH_CHECK();
+      count_launch(PTGNN_AMD_KERNEL_TILE_EDGE);
     }
     row_base += tab.edge_off[tab.num_types];
   }

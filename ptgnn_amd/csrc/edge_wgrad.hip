@@ -386,6 +386,7 @@ static int weight_grad_launch(const float *x, int64_t ld_x, int64_t num_rows, in
       else PTGNN_WGRAD_LAUNCH(false, false);
 #undef PTGNN_WGRAD_LAUNCH
       PTGNN_LAUNCH_CHECK();
+      count_launch(PTGNN_AMD_KERNEL_TILE_WGRAD);
       if (grad_b) {
         k_colsum_reduce<<<(unsigned)((msg_dim * kSplit + 255) / 256), 256, 0, st>>>(
             colsum_ws, tab.chunk_off[tab.num_types], mtiles, msg_dim, grad_b);

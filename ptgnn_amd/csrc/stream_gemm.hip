@@ -1324,14 +1324,16 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   bool split = mode == 2;
   const char *ring_env = getenv("PTGNN_AMD_LINEAR_RING");                     // "1": force (A/B, parity tests at small K)
   const bool force_ring = ring_env && ring_env[0] == '1', no_ring = ring_env && ring_env[0] == '0';
-  const bool ring_shape = n_out % 128 == 0 && (int64_t)n_out * k < ((int64_t)1 << 30) && rows >= 32 * 64;
+  const char *force = getenv("PTGNN_AMD_FORCE_STREAM");        // tests: replay small reference fixtures on these kernels
+  const bool forced = force && force[0] == '1';
+  const bool ring_shape = n_out % 128 == 0 && (int64_t)n_out * k < ((int64_t)1 << 30) && (rows >= 32 * 64 || forced);
   const bool ring = ring_shape && (force_ring || (!no_ring && Slab<false>::bytes(k, bn) + kEpiBytes > (size_t)kLdsBudget));
   if (!ring) {
     // measured (profiles/r02_notes.md): the persistent kernel pays one slab copy per workgroup and re-reads
     // A once per column slab, so in exact fp32 it only beats the tile kernel with >= 3 units per wave and
     // few slabs; the split mode has no tile counterpart and always streams
     const int64_t units = (rows + 31) / 32 * ((n_out + bn - 1) / bn);
-    if (!split && (units < (int64_t)num_compute_units() * 8 * 3 || (n_out + bn - 1) / bn > 4)) return 0;
+    if (!split && !forced && (units < (int64_t)num_compute_units() * 8 * 3 || (n_out + bn - 1) / bn > 4)) return 0;
   }
   size_t slab = split ? Slab<true>::bytes(k, bn) : Slab<false>::bytes(k, bn);
   if (split && slab + kEpiBytes > (size_t)kLdsBudget) {   // three bf16 planes do not fit: this shape stays exact fp32
@@ -1353,6 +1355,7 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
     auto kern = k_stream_linear_ring;
     if (!set_lds(kern, rlds)) return 0;
     kern<<<(unsigned)(p.ncs * p.rps), kRingWaves * 64, rlds, st>>>(p);
+    count_launch(PTGNN_AMD_KERNEL_STREAM_LINEAR_RING);
     return 1;
   }
   if (lds > (size_t)kLdsBudget) return 0;
@@ -1367,6 +1370,7 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   } while (0)
   if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
 #undef PTGNN_K
+  count_launch(PTGNN_AMD_KERNEL_STREAM_LINEAR);
   return 1;
 }
 
@@ -1403,6 +1407,7 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
     auto kern = k_stream_gru_ring;
     if (!set_lds(kern, rlds)) return 0;
     kern<<<(unsigned)(p.ncs * p.rps), kRingWaves * 64, rlds, st>>>(p);
+    count_launch(PTGNN_AMD_KERNEL_STREAM_GRU_RING);
     return 1;
   }
   if (lds > (size_t)kLdsBudget) return 0;
@@ -1417,6 +1422,7 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
   } while (0)
   if (split) PTGNN_K(true); else PTGNN_K(false);
 #undef PTGNN_K
+  count_launch(PTGNN_AMD_KERNEL_STREAM_GRU);
   return 1;
 }
 
@@ -1436,6 +1442,7 @@ static int edge_v2_launch(const EdgeV2Args &q, int K, int msg_dim, unsigned grid
     auto kern = k_stream_edge_v2<NBV, NCHV, DROP, 0>;                 \
     if (!set_lds(kern, lds)) return 0;                                \
     kern<<<grid, 512, lds, st>>>(q);                                  \
+    count_launch(PTGNN_AMD_KERNEL_STREAM_EDGE_V2);                    \
     return 1;                                                         \
   } while (0)
   if (msg_dim == 128) {
@@ -1547,6 +1554,7 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   } while (0)
   if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
 #undef PTGNN_K
+  count_launch(PTGNN_AMD_KERNEL_STREAM_EDGE);
   return 1;
 }
 
@@ -1580,6 +1588,7 @@ int stream_edge_indirect(const StreamEdgeTable *tab_dev, const float *const *w_p
   } while (0)
   if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
 #undef PTGNN_K
+  count_launch(PTGNN_AMD_KERNEL_STREAM_EDGE_SHARED);
   return 1;
 }
 

@@ -492,6 +492,7 @@ int stream_wgrad(const WsTable &tab_in, const float *x, int64_t ld_x, int64_t nu
 #undef PTGNN_WS_NBB
 #undef PTGNN_WS_LAUNCH
   if (hipGetLastError() != hipSuccess) return -1;
+  count_launch(PTGNN_AMD_KERNEL_WGRAD_STREAM);
   const int64_t outs = (int64_t)p.tab.num_types * tiles * (WA * WB / 4) * kSplit;
   k_wgrad_stream_reduce<<<(unsigned)((outs + 255) / 256), 256, 0, st>>>(p.tab, p.partial, mtiles, ktiles, WA, WB,
                                                                          msg_dim, K, grad_w, type_base);

@@ -36,6 +36,25 @@ def get_gemm_mode() -> int:
     return _lib.load().ptgnn_amd_get_gemm_mode()
 
 
+def launch_counts() -> dict:
+    """{kernel family: launches made by this process} (ptgnn_amd_launch_count): tests take differences around a call
+    to assert which kernel a shape / size / mode was dispatched to."""
+    lib = _lib.load()
+    out, i = {}, 0
+    while True:
+        name = lib.ptgnn_amd_launch_name(i)
+        if name is None:
+            return out
+        out[name.decode()] = int(lib.ptgnn_amd_launch_count(i))
+        i += 1
+
+
+def launches_since(before: dict) -> dict:
+    """Kernel families launched since `before = launch_counts()` -> {name: count}, zero entries dropped."""
+    now = launch_counts()
+    return {k: v - before.get(k, 0) for k, v in now.items() if v != before.get(k, 0)}
+
+
 def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 

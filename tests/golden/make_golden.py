@@ -314,10 +314,91 @@ def batcher():
     save("batcher", **arrays)
 
 
+def wide_layers():
+    """Round 4: fixtures at the widths the SHIPPED fast kernels take (K % 64 == 0: k_stream_gru, k_stream_edge incl. the
+    shared-row form, k_stream_linear, k_wgrad_stream), so that those kernels are compared with the reference's own
+    output directly and not only through the oracle.  Own generators: the fixtures above stay bit-identical."""
+    gen = torch.Generator().manual_seed(20260926)
+    n, H = 600, 128
+    # one GGNN and one MLP-MP layer at H = M = 128 on the tricky adjacency (gatedmessagepassing.py:37-69,
+    # mlpmessagepassing.py:68-117)
+    torch.manual_seed(501)
+    adj = tricky_adj(gen, n)
+    x = torch.randn(n, H, generator=gen)
+    layer = GatedMessagePassingLayer(H, H, 3, "max").eval()
+    with torch.no_grad():
+        y = layer(x, adj, None, {}, {}, empty_feats(adj))
+    save("ggnn_layer_max_w128", x=x, y=y, **pack_adj(adj), **pack_specs([weights_from_reference_layer(layer)]))
+
+    torch.manual_seed(502)
+    adj = tricky_adj(gen, n)
+    x = torch.randn(n, H, generator=gen)
+    layer = MlpMessagePassingLayer(H, H, H, 3, "sum").eval()
+    with torch.no_grad():
+        for p_name, p in layer.named_parameters():
+            if "state_update" in p_name and p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+        y = layer(x, adj, None, {}, {}, empty_feats(adj))
+    save("mlp_layer_sum_target_w128", x=x, y=y, **pack_adj(adj), **pack_specs([weights_from_reference_layer(layer)]))
+
+    # Typilus GGNN architecture (typilus/train.py:39-65) at hidden 64, T0 = 3 -> T = 7, three graphs of 400 nodes; few
+    # enough edges per type that the per-edge form with shared message rows is what the layers choose (E 1.25 < N T)
+    n, H, T = 1200, 64, 7
+    node_to_graph = torch.repeat_interleave(torch.arange(3), 400)
+    refs = {"supernodes": torch.tensor([0, 5, 421, 840, 1199])}
+    ref_g = {"supernodes": torch.tensor([0, 0, 1, 2, 2])}
+    torch.manual_seed(503)
+    ggnn = GatedMessagePassingLayer(H, H, T, "max", dropout_rate=0.1)
+    r1 = ConcatResidualLayer(H)
+    last = GatedMessagePassingLayer(2 * H, H, T, "max", dropout_rate=0.1)
+    layers = [r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last]
+    net = GraphNeuralNetwork(layers, _Identity(), introduce_backwards_edges=True, add_self_edges=True).eval()
+    adj = []
+    for c in (1300, 0, 900):        # edges stay inside their graph, like a real disjoint-union batch
+        gidx = torch.randint(0, 3, (c,), generator=gen)
+        s = torch.randint(0, 400, (c,), generator=gen, dtype=torch.int64) + 400 * gidx
+        d = torch.randint(0, 400, (c,), generator=gen, dtype=torch.int64) + 400 * gidx
+        adj.append((s, d))
+    x = torch.randn(n, H, generator=gen)
+    with torch.no_grad():
+        out = net(node_data={"x": x}, adjacency_lists=[a for a in adj], edge_feature_data=[],
+                  node_to_graph_idx=node_to_graph, reference_node_ids=refs,
+                  reference_node_graph_idx=ref_g, num_graphs=3)
+    s_ggnn, s_last = weights_from_reference_layer(ggnn), weights_from_reference_layer(last)
+    specs = ([{"kind": "residual_origin", "name": "r1"}] + [s_ggnn] * 7
+             + [{"kind": "residual_concat", "name": "r1"}, s_last])
+    save("gnn_stack_ggnn_typilus_w64", x=x, y=out.output_node_representations,
+         num_edges=np.asarray(net.report_metrics()["num_edges"]),
+         node_to_graph_idx=node_to_graph, **pack_adj(adj), **pack_specs(specs))
+
+    # training gradients of the reference's own layers at H = M = 64 (and one GGNN at 128, the width of the streaming
+    # weight-gradient kernel's dropout / 128-column tiles)
+    n, T = 300, 4
+    for name, H, make in (
+            ("train_ggnn_max_w64", 64, lambda: GatedMessagePassingLayer(64, 64, T, "max")),
+            ("train_mlp_sum_target_w64", 64, lambda: MlpMessagePassingLayer(64, 64, 64, T, "sum")),
+            ("train_ggnn_sum_w128", 128, lambda: GatedMessagePassingLayer(128, 128, T, "sum"))):
+        torch.manual_seed(600 + len(name))
+        adj = rand_adj(gen, n, [500, 0, 37, 260])
+        x = torch.randn(n, H, generator=gen).requires_grad_(True)
+        layer = make().train()
+        with torch.no_grad():
+            for p_name, p_ in layer.named_parameters():
+                if "state_update" in p_name and p_.dim() == 1:
+                    p_.add_(0.1 * torch.randn(p_.shape, generator=gen))
+        y = layer(x, adj, None, {}, {}, empty_feats(adj))
+        gout = torch.randn(y.shape, generator=gen)
+        y.backward(gout)
+        grads = {"g.x": x.grad}
+        for p_name, p_ in layer.named_parameters():
+            grads["g." + p_name] = p_.grad
+        save(name, x=x.detach(), y=y.detach(), gout=gout, **pack_adj(adj),
+             **pack_specs([weights_from_reference_layer(layer)]), **grads)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    single_layers()
-    training_gradients()
-    containers()
-    varmisuse_ggnn()
-    batcher()
+    only = sys.argv[1:]
+    for fn in (single_layers, training_gradients, containers, varmisuse_ggnn, batcher, wide_layers):
+        if not only or fn.__name__ in only:
+            fn()

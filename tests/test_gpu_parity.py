@@ -458,7 +458,8 @@ def test_gather_rows():
 # ------------------------------------------------------------------------------------------------
 LAYER_CASES = ["ggnn_layer_sum", "ggnn_layer_mean", "ggnn_layer_max", "ggnn_layer_min",
                "mlp_layer_sum_target", "mlp_layer_max_target", "mlp_layer_mean_notarget",
-               "mlp_layer_sum_hidden1", "mlp_layer_max_noln_nodense"]
+               "mlp_layer_sum_hidden1", "mlp_layer_max_noln_nodense",
+               "ggnn_layer_max_w128", "mlp_layer_sum_target_w128"]   # round 4: K % 64 widths (tests/test_gpu_golden_wide.py)
 
 
 @pytest.mark.parametrize("name", LAYER_CASES)
@@ -1612,7 +1613,8 @@ def test_global_exchange_training_gradients_match_oracle_autograd(pool, sizes):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("path", ["edge", "table"])
 @pytest.mark.parametrize("name", ["train_ggnn_max", "train_ggnn_sum", "train_mlp_sum_target",
-                                  "train_mlp_max_notarget"])
+                                  "train_mlp_max_notarget", "train_ggnn_max_w64", "train_mlp_sum_target_w64",
+                                  "train_ggnn_sum_w128"])
 def test_training_gradients_match_reference_golden(name, path, monkeypatch):
     """The HIP training paths (edge form and table form) reproduce the output, d x and every parameter
     gradient the reference's own layer produced under torch autograd on CPU."""

@@ -10,7 +10,9 @@ from oracle.fixtures import unpack_adj, unpack_specs
 
 LAYER_CASES = ["ggnn_layer_sum", "ggnn_layer_mean", "ggnn_layer_max", "ggnn_layer_min",
                "mlp_layer_sum_target", "mlp_layer_max_target", "mlp_layer_mean_notarget",
-               "mlp_layer_sum_hidden1", "mlp_layer_max_noln_nodense"]
+               "mlp_layer_sum_hidden1", "mlp_layer_max_noln_nodense",
+               # round 4: the widths the shipped streaming kernels take (K % 64 == 0)
+               "ggnn_layer_max_w128", "mlp_layer_sum_target_w128"]
 TOL = 2e-6  # explicit-formula LayerNorm/GRU vs torch's fused CPU kernels
 
 
@@ -27,7 +29,8 @@ def test_single_layer_matches_reference(name):
 
 
 @pytest.mark.parametrize("name,bwd,selfe", [("gnn_stack_ggnn_typilus", True, True),
-                                            ("gnn_stack_mlp_varmisuse", True, True)])
+                                            ("gnn_stack_mlp_varmisuse", True, True),
+                                            ("gnn_stack_ggnn_typilus_w64", True, True)])
 def test_container_matches_reference(name, bwd, selfe):
     g = load_golden(name)
     adj, specs = unpack_adj(g), unpack_specs(g)
@@ -84,7 +87,8 @@ def test_batcher_bit_exact():
                                           g[f"mb{bi}.ref_gidx.{k}"])
 
 
-TRAIN_CASES = ["train_ggnn_max", "train_ggnn_sum", "train_mlp_sum_target", "train_mlp_max_notarget"]
+TRAIN_CASES = ["train_ggnn_max", "train_ggnn_sum", "train_mlp_sum_target", "train_mlp_max_notarget",
+               "train_ggnn_max_w64", "train_mlp_sum_target_w64", "train_ggnn_sum_w128"]
 
 
 def _grad_pairs(spec, g):
