@@ -16,8 +16,24 @@
  *   - return value: 0 = ok, <0 = PTGNN_AMD_E*; ptgnn_amd_last_error() returns a thread-local
  *     message for the last failure on the calling thread;
  *   - fp32 row-major matrices; a leading dimension `ld*` is counted in floats;
- *   - kernels are stateless and re-entrant; the only global state is an immutable per-process
- *     device-property cache.
+ *   - entry points are re-entrant: any number of host threads may call them concurrently, on the
+ *     same or on different streams.  What the library keeps per process, and how it is guarded:
+ *       * an immutable device-property cache and the per-(kernel, device) dynamic-LDS attribute
+ *         (hipFuncSetAttribute, set once under a mutex; not legal inside a stream capture, so the
+ *         first use of a streaming kernel has to happen outside one -- inside, the call falls back to
+ *         the tile kernel or, where there is none, returns EUNSUPPORTED);
+ *       * side streams + fork / join events of the aggregation (plans of >= 2 M edges with hub rows):
+ *         one set per (device, caller stream), created on first use outside a capture, looked up and
+ *         used under mutexes -- two caller streams never share an event; at most 64 sets, beyond that
+ *         the launches stay on the caller's stream;
+ *       * launch counters (ptgnn_amd_launch_count): relaxed atomics, never read by the library;
+ *       * PROCESS-WIDE knobs, meant to be set once at start-up and not while other threads are inside
+ *         the library: ptgnn_amd_set_gemm_mode (which arithmetic the GEMMs use) and
+ *         ptgnn_amd_set_plan_path (developer A/B of the plan build).  Environment variables
+ *         (PTGNN_AMD_*) are read per call or once at first use; they are developer / test switches.
+ *     Caller-owned state with an ownership rule: the plan build's `control` block and the hub
+ *     `hub_tickets` counters are ZERO AT REST and belong to the launches of ONE stream at a time --
+ *     give every stream that builds plans / aggregates concurrently its own.
  */
 #ifndef PTGNN_AMD_H_
 #define PTGNN_AMD_H_
@@ -171,13 +187,19 @@ int ptgnn_amd_validate_indices(const int64_t *idx, int64_t n, int64_t num_nodes,
  *   stats (device int64 [world + 2 + num_types], zeroed here): [0, world) halo rows per owner |
  *   [world] edges with a remote source | [world + 1] halo rows in all | then own-source edges per edge type.
  * need_capacity >= min(num_edges, total_nodes - (hi - lo)).  Nothing synchronises with the host.
+ * A source id outside [0, total_nodes) is clamped into the id space and COUNTED in *bad_index_count (after the remap
+ * it would be an ordinary own / halo row: the plan build's range guard cannot see it any more); a destination
+ * outside [lo, hi) leaves as a local id outside [0, hi - lo), which ptgnn_amd_csr_build counts.
  * ---------------------------------------------------------------------------------------- */
 size_t ptgnn_amd_shard_index_workspace_bytes(int64_t total_nodes);
 int ptgnn_amd_shard_index(const int64_t *const *src_per_type, const int64_t *const *dst_per_type,
                           const int64_t *edges_per_type, int32_t num_types, int64_t lo, int64_t hi,
                           const int64_t *bounds /* device [world + 1] */, int32_t world, int64_t total_nodes,
                           int64_t *local_src, int64_t *local_dst, int64_t *need_ids, int64_t need_capacity,
-                          int64_t *stats, void *workspace, size_t workspace_bytes, void *stream);
+                          int64_t *stats,
+                          int32_t *bad_index_count /* nullable; device int32, NOT zeroed here: += number of
+                                                    * global source ids outside [0, total_nodes) (they are
+                                                    * clamped; the reference device-asserts on them) */, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Unique (edge type, source) pairs of a forward plan.  A GGNN message is W_t . x[src]
@@ -239,7 +261,8 @@ int ptgnn_amd_edge_linear_shared_f32(const float *x, int64_t ld_x, int64_t num_r
  * 10^5-edge destination does not serialise on one lane group.  Needs `hub_ws` of
  * ptgnn_amd_hub_workspace_bytes(num_edges, msg_dim, argout != 0) bytes (scratch) and `hub_tickets`,
  * int32[ptgnn_amd_hub_ticket_count(num_edges, msg_dim)] that is ZERO on entry (the kernel leaves it
- * zero again, so one zeroed buffer per plan serves every call on a stream); with either NULL every
+ * zero again, so one zeroed buffer per plan AND STREAM serves every call on that stream: two streams
+ * aggregating over one plan concurrently need a buffer each); with either NULL every
  * row takes the serial path.  Deterministic; a hub row's fp32 fold order differs from the serial
  * order (max/min and argout are exact).
  * ---------------------------------------------------------------------------------------- */

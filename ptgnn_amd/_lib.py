@@ -34,7 +34,7 @@ SIGNATURES = {
     "ptgnn_amd_validate_indices": (_c.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "ptgnn_amd_shard_index_workspace_bytes": (_c.c_size_t, [_i64]),
     "ptgnn_amd_shard_index": (_c.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _vp,
-                                         _vp, _c.c_size_t, _vp]),
+                                         _vp, _vp, _c.c_size_t, _vp]),
     "ptgnn_amd_unique_sources_workspace_bytes": (_c.c_size_t, [_i64, _i32]),
     "ptgnn_amd_edge_table_bytes": (_c.c_size_t, []),
     "ptgnn_amd_unique_sources": (_c.c_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _c.c_size_t,

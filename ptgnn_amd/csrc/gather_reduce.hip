@@ -28,6 +28,8 @@
 
 #include <type_traits>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace ptgnn_amd {
@@ -537,37 +539,55 @@ __global__ __launch_bounds__(256) void k_hub_chunks(Args a) {
 // hub kernel runs on a SIDE stream of the library, forked from and joined back into the caller's stream with events
 // (the fork-join pattern that is also legal under stream capture): the two overlap instead of queueing.
 // PTGNN_AMD_HUB_STREAM=0 keeps both on the caller's stream (A/B).
+// One set of side streams + events per (device, CALLER STREAM): two caller streams on one device -- or two host threads --
+// never share a fork / join event (a shared set let one caller's join wait on the other's record and read its output
+// before its hub rows were written; ADVICE / VERDICT r03).  `mu` serialises the fork .. join enqueue sequence of callers
+// that do use the same stream from two threads; the pool is looked up under `g_side_mu`.  Entries are created on first
+// use OUTSIDE a stream capture (creating streams / events is not capturable: a first use inside a capture stays on one
+// stream) and live for the process; beyond kSidePool distinct caller streams the launches stay on the caller's stream.
 struct SideStream {
+  int dev = -1;
+  hipStream_t owner = nullptr;     // the caller's stream this set belongs to
   hipStream_t stream = nullptr;    // hub chunks
   hipStream_t stream2 = nullptr;   // long rows
   hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
+  std::mutex mu;
 };
 
-SideStream *side_stream() {
-  static SideStream per_device[16];
-  static int enabled = -1;
-  if (enabled < 0) {
+constexpr int kSidePool = 64;
+std::mutex g_side_mu;
+SideStream g_side[kSidePool];
+int g_side_used = 0;
+
+bool side_streams_enabled() {
+  static const bool enabled = [] {
     const char *e = getenv("PTGNN_AMD_HUB_STREAM");
-    enabled = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (!enabled) return nullptr;
+    return !(e && e[0] == '0');
+  }();
+  return enabled;
+}
+
+// the caller stream's set, created if `may_create` (not capturing) and there is room; else nullptr
+SideStream *side_stream(hipStream_t caller, bool may_create) {
+  if (!side_streams_enabled()) return nullptr;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  SideStream &s = per_device[dev];
-  if (s.stream == nullptr) {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    // creating streams / events is not a capturable operation: a first use inside a capture stays on one stream
-    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s.join2, hipEventDisableTiming) != hipSuccess) {
-      (void)hipGetLastError();
-      s.stream = nullptr;
-      return nullptr;
-    }
-    (void)st;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_side_mu);
+  for (int i = 0; i < g_side_used; ++i)
+    if (g_side[i].dev == dev && g_side[i].owner == caller) return &g_side[i];
+  if (!may_create || g_side_used == kSidePool) return nullptr;
+  SideStream &s = g_side[g_side_used];
+  if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s.join2, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;                // a half-created set is never published (its handles leak once, on a failing device)
   }
+  s.dev = dev;
+  s.owner = caller;
+  ++g_side_used;
   return &s;
 }
 
@@ -587,11 +607,11 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
   if (a.hub_threshold > 0 && a.num_edges >= side_min_edges) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cs);
-    static bool created_outside_capture = false;
-    if (cs == hipStreamCaptureStatusNone || created_outside_capture) side = side_stream();
-    if (side && cs == hipStreamCaptureStatusNone) created_outside_capture = true;
+    side = side_stream(stream, cs == hipStreamCaptureStatusNone);
   }
   bool long_launch = false;
+  std::unique_lock<std::mutex> side_lock;
+  if (side) side_lock = std::unique_lock<std::mutex>(side->mu);   // fork .. join is one critical section per caller stream
   if (side) {   // fork: hub chunks and long rows each on a side stream of their own, next to the main launch
     PTGNN_HIP(hipEventRecord(side->fork, stream));
     PTGNN_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));

@@ -44,11 +44,13 @@ __device__ __forceinline__ int shard_type_of(const ShardTable &tab, int64_t e) {
 __global__ __launch_bounds__(256) void k_shard_mark(ShardTable tab, int64_t edge_base, int64_t lo, int64_t hi,
                                                     int64_t total_nodes, uint32_t *__restrict__ bitmap,
                                                     int64_t *__restrict__ local_src, int64_t *__restrict__ local_dst,
-                                                    unsigned long long *__restrict__ stats, int world) {
+                                                    unsigned long long *__restrict__ stats, int world,
+                                                    int32_t *__restrict__ bad_index_count) {
   __shared__ int own_cnt[kShardTypes];
   __shared__ int remote_cnt;
+  __shared__ int bad_cnt;
   if (threadIdx.x < kShardTypes) own_cnt[threadIdx.x] = 0;
-  if (threadIdx.x == 0) remote_cnt = 0;
+  if (threadIdx.x == 0) { remote_cnt = 0; bad_cnt = 0; }
   __syncthreads();
   const int64_t n = tab.offset[tab.num_types];
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -56,8 +58,14 @@ __global__ __launch_bounds__(256) void k_shard_mark(ShardTable tab, int64_t edge
     const int64_t i = e - tab.offset[t];
     int64_t s = tab.src[t][i];
     const int64_t d = tab.dst[t][i];
-    s = s < 0 ? 0 : (s < total_nodes ? s : total_nodes - 1);     // a bad id must not leave the bitmap (the plan
-    local_dst[edge_base + e] = d - lo;                           // build's range guard reports it)
+    // A global source id outside [0, total_nodes) must not leave the bitmap: it is clamped -- and COUNTED here, because
+    // after the remap it is a valid own or halo row that the plan build's range guard can no longer tell from a good one
+    // (the reference device-asserts on it in F.embedding, gatedmessagepassing.py:54-56).  Destinations outside [lo, hi)
+    // become local ids outside [0, hi - lo), which the plan build does count.
+    const bool bad = s < 0 || s >= total_nodes;
+    if (bad) atomicAdd(&bad_cnt, 1);
+    s = s < 0 ? 0 : (s < total_nodes ? s : total_nodes - 1);
+    local_dst[edge_base + e] = d - lo;
     const bool own = s >= lo && s < hi;
     if (own) local_src[edge_base + e] = s - lo;
     else atomicOr(&bitmap[s >> 5], 1u << (s & 31));
@@ -76,6 +84,7 @@ __global__ __launch_bounds__(256) void k_shard_mark(ShardTable tab, int64_t edge
   if ((int)threadIdx.x < tab.num_types && own_cnt[threadIdx.x])
     atomicAdd(&stats[world + 2 + tab.type_base + threadIdx.x], (unsigned long long)own_cnt[threadIdx.x]);
   if (threadIdx.x == 0 && remote_cnt) atomicAdd(&stats[world], (unsigned long long)remote_cnt);
+  if (threadIdx.x == 0 && bad_cnt && bad_index_count) atomicAdd(bad_index_count, bad_cnt);
 }
 
 __global__ __launch_bounds__(256) void k_shard_blocks(const uint32_t *__restrict__ bitmap, int64_t words,
@@ -361,7 +370,7 @@ extern "C" int ptgnn_amd_shard_index(const int64_t *const *src_per_type, const i
                                      const int64_t *edges_per_type, int32_t num_types, int64_t lo, int64_t hi,
                                      const int64_t *bounds, int32_t world, int64_t total_nodes, int64_t *local_src,
                                      int64_t *local_dst, int64_t *need_ids, int64_t need_capacity, int64_t *stats,
-                                     void *workspace, size_t workspace_bytes, void *stream_) {
+                                     int32_t *bad_index_count, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   PTGNN_REQUIRE(num_types > 0 && world > 0 && lo >= 0 && hi >= lo && total_nodes >= hi, PTGNN_AMD_EINVAL,
                 "shard_index: bad sizes");
@@ -411,7 +420,7 @@ extern "C" int ptgnn_amd_shard_index(const int64_t *const *src_per_type, const i
   };
   int rc = for_each_table([&](const ShardTable &tab, int64_t base, unsigned grid) {
     k_shard_mark<<<grid, 256, 0, st>>>(tab, base, lo, hi, total_nodes, bitmap, local_src, local_dst,
-                                      (unsigned long long *)stats, world);
+                                      (unsigned long long *)stats, world, bad_index_count);
   });
   if (rc != PTGNN_AMD_OK) return rc;
   k_shard_blocks<<<(unsigned)nblocks, 256, 0, st>>>(bitmap, words, block_sum);

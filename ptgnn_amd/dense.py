@@ -28,23 +28,31 @@ def _pad4(t: torch.Tensor) -> torch.Tensor:
     return t if extra == 0 and t.stride(0) % 4 == 0 else torch.nn.functional.pad(t, (0, extra)).contiguous()
 
 
-_WT_CACHE = {}   # id(weight) -> (weakref, version, transposed copy)
+_WT_CACHE = {}   # id(weight) -> (weakref, version, storage pointer, device, transposed copy)
 
 
 def _transposed(weight: torch.Tensor) -> torch.Tensor:
-    """`weight.t().contiguous()` for the input-gradient GEMMs, kept per (tensor, version): a tied layer (the Typilus
-    stack applies one GGNN layer seven times) transposes its GRU / Linear weights once per backward pass instead of
-    once per use; an optimizer step bumps the version, so a stale copy can never be used."""
+    """`weight.t().contiguous()` for the input-gradient GEMMs, kept per (tensor, version, storage, device): a tied layer
+    (the Typilus stack applies one GGNN layer seven times) transposes its GRU / Linear weights once per backward pass
+    instead of once per use.  An optimizer step bumps the version; `param.data = ...` (module.to() / .cuda() / .float()
+    after a backward, EMA weight swaps) does not, but moves the storage or the device, which the key also holds.  An
+    in-place edit through `p.data` changes neither, so the cache is additionally dropped at the start of every
+    forward (`clear_transposed_cache`, called by `layers.forward_scope`): a copy lives for one forward / backward."""
     import weakref
     key = id(weight)
     hit = _WT_CACHE.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
-        return hit[2]
+    if (hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr()
+            and hit[3] == weight.device):
+        return hit[4]
     wt = weight.detach().t().contiguous()
     if len(_WT_CACHE) > 64:
         _WT_CACHE.clear()
-    _WT_CACHE[key] = (weakref.ref(weight), weight._version, wt)
+    _WT_CACHE[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), weight.device, wt)
     return wt
+
+
+def clear_transposed_cache() -> None:
+    _WT_CACHE.clear()
 
 
 class _Linear(torch.autograd.Function):

@@ -151,12 +151,14 @@ class GraphNeuralNetwork(ModuleWithMetrics):
                     out_dim = mp_layer.output_state_dimension
                     buf = nxt.make_result_buffer(node_representations.shape[0], out_dim, node_representations)
                     set_output_hint(buf[:, buf.shape[1] - out_dim:])
-                node_representations = mp_layer(
-                    node_states=node_representations, adjacency_lists=adjacency_lists,
-                    node_to_graph_idx=node_to_graph_idx, reference_node_ids=reference_node_ids,
-                    reference_node_graph_idx=reference_node_graph_idx,
-                    edge_features=edge_feature_embeddings)
-                set_output_hint(None)
+                try:
+                    node_representations = mp_layer(
+                        node_states=node_representations, adjacency_lists=adjacency_lists,
+                        node_to_graph_idx=node_to_graph_idx, reference_node_ids=reference_node_ids,
+                        reference_node_graph_idx=reference_node_graph_idx,
+                        edge_features=edge_feature_embeddings)
+                finally:   # a layer that raises must not leave its hint to an unrelated forward
+                    set_output_hint(None)
                 if buf is not None and node_representations.data_ptr() == buf[:, buf.shape[1] - out_dim:].data_ptr():
                     node_representations._ptgnn_amd_concat_buffer = buf
                 all_states.append(node_representations)

@@ -90,6 +90,8 @@ def forward_scope():
     outer = getattr(_SCOPE, "cache", None)
     if outer is None:
         _SCOPE.cache = {}
+        from ptgnn_amd import dense
+        dense.clear_transposed_cache()   # W^T copies of the previous backward: valid for one forward / backward pair
     try:
         yield
     finally:

@@ -168,12 +168,16 @@ class GraphPlan:
         return self.hub_entries is not None
 
     def hub_tickets(self, msg_dim: int) -> torch.Tensor:
-        """Arrival counters of the hub chunks: zeroed once per plan, left zero by every launch."""
+        """Arrival counters of the hub chunks: zeroed once, left zero by every launch -- and owned by the launches of ONE
+        stream at a time (include/ptgnn_amd.h), so they are kept per (size, current stream): two streams that
+        aggregate over the same plan concurrently must not count each other's chunks."""
         n = _lib.load().ptgnn_amd_hub_ticket_count(self.num_edges, msg_dim)
-        t = self._hub_tickets.get(n)
+        dev = self.rowptr.device
+        key = (n, torch.cuda.current_stream(dev).cuda_stream)
+        t = self._hub_tickets.get(key)
         if t is None:
-            t = torch.zeros(max(n, 1), dtype=torch.int32, device=self.rowptr.device)
-            self._hub_tickets[n] = t
+            t = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+            self._hub_tickets[key] = t
         return t
 
     def wait(self) -> None:
@@ -587,12 +591,21 @@ def shard_index(adjacency_lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], lo
     sp = PtrArr(*[s_.data_ptr() if s_.numel() else None for s_ in srcs])
     dp = PtrArr(*[d_.data_ptr() if d_.numel() else None for d_ in dsts])
     cn = CntArr(*counts)
+    # global source ids outside [0, total_nodes) are counted like the plan build's bad ids (after the remap they are
+    # ordinary own / halo rows, which that guard can no longer see)
+    bad = _bad_state(dev) if VALIDATE_INDICES != "off" else None
     with _timed("shard_index", bytes=E * 32.0 + total_nodes / 4.0):
         rc = lib.ptgnn_amd_shard_index(ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p),
                                        ctypes.cast(cn, ctypes.c_void_p), T, int(lo), int(hi), bounds.data_ptr(), world,
                                        int(total_nodes), local_src.data_ptr(), local_dst.data_ptr(), need.data_ptr(),
-                                       cap, stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream(local_src))
+                                       cap, stats.data_ptr(), bad["dev"].data_ptr() if bad is not None else None,
+                                       ws.data_ptr(), ws_bytes, _stream(local_src))
     _lib.check(rc, "ptgnn_amd_shard_index")
+    if bad is not None and not torch.cuda.is_current_stream_capturing():
+        if VALIDATE_INDICES == "sync":
+            check_indices(dev, sync=True)
+        else:
+            _post_plan_readback(bad)
     return local_src[:E], local_dst[:E], counts, need, stats
 
 

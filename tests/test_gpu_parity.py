@@ -2358,6 +2358,32 @@ def test_split_gemm_mode_parity_matrix(case, monkeypatch):
         ops.set_gemm_mode(prev)
 
 
+def test_shard_index_counts_global_source_ids_outside_the_id_space():
+    """a corrupt GLOBAL source id is clamped by the shard index pass into a valid own / halo row, which the
+    plan build's range guard can no longer see; the index pass itself counts it and the count surfaces as a
+    PtgnnAmdError (the reference device-asserts in F.embedding, gatedmessagepassing.py:54-56)."""
+    from ptgnn_amd import _lib, ops, sharded
+    ops.check_indices(sync=True)
+    g = torch.Generator().manual_seed(4)
+    n = 3000
+    ranges = [(0, 1000), (1000, 2000), (2000, 3000)]
+    s = torch.randint(0, n, (5000,), generator=g)
+    d = torch.randint(1000, 2000, (5000,), generator=g)
+    good = sharded.ShardedGraph.build_local([(s.cuda(), d.cuda())], ranges, 1, use_hip_index=True)
+    ops.check_indices(sync=True)                                   # a clean shard raises nothing
+    s_bad = s.clone()
+    s_bad[[3, 77, 4001]] = torch.tensor([n + 5, -2, 1 << 40])
+    ls, ld, _, _, stats = ops.shard_index([(s_bad.cuda(), d.cuda())], 1000, 2000, good.bounds, n)
+    assert int(ls.max()) < 1000 + int(stats[3 + 1])                # nothing points outside the local [own | halo] table
+    with pytest.raises(_lib.PtgnnAmdError, match="3 node id"):
+        ops.check_indices(sync=True)
+    with pytest.raises(_lib.PtgnnAmdError, match="3 node id"):     # ... and through the sharded build: raised by the plan
+        sharded.ShardedGraph.build_local([(s_bad.cuda(), d.cuda())], ranges, 1, use_hip_index=True)   # build's poll or
+        ops.check_indices(sync=True)                                                                   # at the latest here
+    ops.check_indices(sync=True)                                   # the counter was cleared by the raise
+    assert good.n_halo > 0
+
+
 @pytest.mark.parametrize("case", ["cfg4_like_T21", "one_type_random", "no_remote", "types_over_table"])
 def test_shard_index_kernels_equal_the_torch_bookkeeping(case):
     """csrc/shard_index.hip (bitmap mark / compact / remap) against the torch-op chain it replaces (and which the
