@@ -62,6 +62,8 @@ def parse():
     p.add_argument("--gemm", default=None, choices=["tile", "stream", "split"],
                    help="kernel family / arithmetic of the dense blocks for the PRIMARY line (default: stream = exact fp32)")
     p.add_argument("--no-secondary", action="store_true")
+    p.add_argument("--no-sustained", action="store_true", help="skip the >= 10 s sustained block of the primary step")
+    p.add_argument("--sustained-seconds", type=float, default=10.0)
     p.add_argument("--force-sharded", action="store_true",
                    help="run the dst-range-sharded code path (process group, halo all-to-all) even at N=1")
     p.add_argument("--cut-edges", action="store_true",
@@ -513,6 +515,40 @@ def repeat_stats(step_fn, steps, blocks=5):
             "ms_per_step_median": round(per[len(per) // 2], 4), "ms_per_step_max": round(per[-1], 4)}
 
 
+def sustained_stats(dev, seconds=10.0, batches=4, block=40):
+    """>= `seconds` of the primary step back to back, ROTATING over `batches` minibatches of different seeds (the timed
+    region replays one minibatch for 80 ms: weights and states stay cache-warm and the clocks never settle; VERDICT r03
+    weak #12).  Blocks of `block` steps are timed with one synchronisation each; reports min / median / max ms per step
+    over the blocks and the first second against the last (DVFS steady state)."""
+    states = [make_cfg3(dev, r) for r in range(batches)]
+    for st in states:                     # warm every batch once (plan caches are cleared per step anyway)
+        step_cfg3(st)
+    torch.cuda.synchronize()
+    per, stamps, i = [], [], 0
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < seconds:
+        t0 = time.perf_counter()
+        for _ in range(block):
+            step_cfg3(states[i % batches])
+            i += 1
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        per.append((t1 - t0) / block * 1e3)
+        stamps.append(t1 - t_start)
+    total = time.perf_counter() - t_start
+    first = [p_ for p_, t_ in zip(per, stamps) if t_ <= 1.0] or per[:1]
+    last = [p_ for p_, t_ in zip(per, stamps) if t_ >= total - 1.0] or per[-1:]
+    srt = sorted(per)
+    edges = sum(st["E"] for st in states) / batches
+    med = srt[len(srt) // 2]
+    return {"seconds": round(total, 2), "steps": i, "minibatches_rotated": batches,
+            "nodes_per_minibatch": [st["N"] for st in states], "steps_per_block": block, "blocks": len(per),
+            "ms_per_step_min": round(srt[0], 4), "ms_per_step_median": round(med, 4), "ms_per_step_max": round(srt[-1], 4),
+            "ms_per_step_first_second": round(sum(first) / len(first), 4),
+            "ms_per_step_last_second": round(sum(last) / len(last), 4),
+            "edges_per_sec_per_layer_median": round(edges / (med / 1e3 / 8), 1)}
+
+
 def sampled_layer_parity(kind, spec, adj_cpu, x_cpu, got_gpu, deg, n_rows=4096, n_hubs=8, seed=3):
     """Oracle parity of ONE layer on a graph too large for a full CPU evaluation (cfg5 shard: the per-edge restatement
     would gather a 12.8 GB [E, 256] matrix): the oracle runs on the in-neighbourhood closure of a ROW SAMPLE of the
@@ -550,6 +586,8 @@ def sampled_layer_parity(kind, spec, adj_cpu, x_cpu, got_gpu, deg, n_rows=4096, 
            "ours_vs_fp64": ours64, "oracle_fp32_vs_fp64": ref64,
            "against": "oracle/mp_oracle.py (fp32 and float64) on the in-neighbourhood closure of the row sample"}
     res["ok"] = bool(res["max_abs_rows_below_32_in_edges"] <= PARITY_TOL and ours64 <= max(PARITY_TOL, 2.0 * ref64))
+    # the literal bar on EVERY sampled row (hub rows included), next to the float64-attributed `ok`
+    res["strict_1e-5"] = bool(res["max_abs_all_sampled_rows"] <= PARITY_TOL)
     return res
 
 
@@ -778,6 +816,8 @@ def config4(dev, k=20, parity=True):
         res["parity"] = {"per_layer_max": worst, "tol": PARITY_TOL, "end_to_end": float((got - want).abs().max()),
                          "ours_vs_fp64": ours64, "oracle_vs_fp64": ref64, "n": n,
                          "ok": bool(worst <= PARITY_TOL and ours64 <= max(PARITY_TOL, 2.0 * ref64)),
+                         # the literal bar end to end, next to the float64-attributed `ok`
+                         "strict_1e-5": bool(float((got - want).abs().max()) <= PARITY_TOL),
                          "against": "oracle/mp_oracle.py at full size: per layer (each MLP-MP layer fed the oracle's input "
                                     "of that layer) and end to end, attributed against a float64 evaluation of the stack"}
     return res
@@ -819,9 +859,10 @@ def sharded_cfg4(dev, rank, world, k=5):
                 holder["shard"] = shard
                 return sharded.run_stack(mods, x, shard)
         dts = [_clock_collective(step, k, 2, world, dev) for _ in range(3)]   # the first block also pays one-time set-up
-        dt = min(dts)                                                          # of the collectives it is the first to use
+        dt = sorted(dts)[1]                                                    # of the collectives: median, like the other lines
         edges = sum_over_ranks(e_mine, world, dev)
-        entry = {"ms_per_forward": round(dt * 1e3, 3), "ms_per_forward_blocks": [round(t * 1e3, 3) for t in dts],
+        entry = {"ms_per_forward": round(dt * 1e3, 3), "ms_per_forward_is": "median of 3 blocks",
+                 "ms_per_forward_blocks": [round(t * 1e3, 3) for t in dts],
                  "edges_per_sec_per_layer": round(edges / (dt / 8), 1),
                  "edges_per_sec_readme_convention": round(edges / dt, 1),
                  "nodes_per_rank_min_max": [int(min(b_ - a_ for a_, b_ in ranges)), int(max(b_ - a_ for a_, b_ in ranges))]}
@@ -964,8 +1005,32 @@ def main():
                     threading.Event().wait()   # peers are inside a collective: let the watchdog end every rank
                 break
         watchdog.cancel()
+        # the north-star split (dst-range shards + RCCL halo all-to-all) next to the contract's replica line, where a
+        # SCALE record reads it: `value` stays the weak-scaling replica run (one batch per GPU, no collective)
+        lift = {"collective_backend": result.get("collective_backend"), "rccl_ranks_seen": result.get("rccl_ranks_seen")}
+        c5, c4 = variants.get("cfg5_shard"), variants.get("cfg4_stack")
+        if isinstance(c5, dict) and "ms_per_step" in c5:
+            lift["cfg5_shard"] = {k: c5[k] for k in ("ms_per_step", "ms_per_step_two_block_overlap", "all_to_all_ms",
+                                                     "halo_bytes_per_layer_all_ranks", "edges_per_sec_per_layer",
+                                                     "no_cut") if k in c5}
+        if isinstance(c4, dict):
+            for part in ("graph_boundaries", "through_graphs"):
+                if isinstance(c4.get(part), dict):
+                    lift["cfg4_stack_" + part] = {k: c4[part][k] for k in (
+                        "ms_per_forward", "ms_per_forward_two_block_overlap", "all_to_all_ms_per_layer",
+                        "halo_bytes_per_layer_all_ranks", "edges_per_sec_per_layer", "no_cut") if k in c4[part]}
+        if "error" in variants:
+            lift["error"] = variants["error"]
+        result["config"]["dst_range_split"] = lift
     if rank == 0 and world == 1 and not args.force_sharded:
         result["repeats"] = repeat_stats(step, args.steps)
+        if args.workload == "cfg3" and not args.no_sustained:
+            _log("sustained: >= 10 s of the primary step over 4 rotating minibatches")
+            try:
+                result["sustained"] = sustained_stats(dev, seconds=args.sustained_seconds)
+            except Exception as exc:  # noqa: BLE001  (never costs the primary line)
+                result["sustained"] = {"error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.empty_cache()
         if not args.no_secondary:
             if args.workload == "cfg3":    # configs[1]: the synthetic 200k / 1.1M graph, one MLP-MP layer
                 _log("secondary: config 2")

@@ -103,14 +103,14 @@ __device__ __forceinline__ void row_stats(const Row<VEC, LPR, CH> &r, int g, int
   rstd = 1.0f / sqrtf(group_sum<LPR>(q) / (float)M + eps);
 }
 
+// Rows per lane group and pass.  At M = 64 a row is 256 B = one float4 per lane of a 16-lane group: with ONE row per
+// group a thread had a single 16-byte load in flight and the launch was a chain of memory latencies (round 3: 2.7 TB/s
+// forward, 2.1 TB/s backward at [116 k, 64]).  R rows per group are requested up front (clamped row index, so no load
+// sits behind a branch), then processed one after the other.
+template <int LPR> constexpr int rows_in_flight() { return LPR <= 16 ? 4 : (LPR <= 32 ? 2 : 1); }
+
 template <int VEC, int LPR, int CH>
-__global__ __launch_bounds__(kBlock) void k_row_epilogue(RowArgs p) {
-  constexpr int G = kBlock / LPR;
-  const int g = threadIdx.x % LPR;
-  const int64_t row = (int64_t)blockIdx.x * G + threadIdx.x / LPR;
-  if (row >= p.rows) return;          // whole lane group leaves together
-  Row<VEC, LPR, CH> r;
-  r.load(p.x + row * p.ld_x, g, p.M);
+__device__ __forceinline__ void row_forward(const RowArgs &p, Row<VEC, LPR, CH> &r, int g) {
   if (p.flags & PTGNN_AMD_EPI_GELU) {
 #pragma unroll
     for (int c = 0; c < CH; ++c)
@@ -128,7 +128,25 @@ __global__ __launch_bounds__(kBlock) void k_row_epilogue(RowArgs p) {
         if (col < p.M) r.a[c][v] = (r.a[c][v] - mean) * rstd * p.gamma[col] + p.beta[col];
       }
   }
-  r.store(p.out + row * p.ld_out, g, p.M);
+}
+
+template <int VEC, int LPR, int CH>
+__global__ __launch_bounds__(kBlock) void k_row_epilogue(RowArgs p) {
+  constexpr int G = kBlock / LPR, R = rows_in_flight<LPR>();
+  const int g = threadIdx.x % LPR;
+  const int64_t row0 = ((int64_t)blockIdx.x * G + threadIdx.x / LPR) * R;
+  if (row0 >= p.rows) return;          // whole lane group leaves together
+  Row<VEC, LPR, CH> r[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int64_t row = row0 + i < p.rows ? row0 + i : p.rows - 1;
+    r[i].load(p.x + row * p.ld_x, g, p.M);
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    row_forward(p, r[i], g);
+    if (row0 + i < p.rows) r[i].store(p.out + (row0 + i) * p.ld_out, g, p.M);
+  }
 }
 
 template <int VEC, int LPR, int CH>
@@ -146,11 +164,21 @@ __global__ __launch_bounds__(kBlock) void k_row_epilogue_backward(RowArgs p) {
       gam[c][v] = (ln && col < p.M) ? p.gamma[col] : 0.f;
       dgam[c][v] = dbet[c][v] = 0.f;
     }
-  // rows this lane group owns: group index, then a grid stride (all groups of the grid interleave)
-  for (int64_t row = (int64_t)blockIdx.x * G + grp; row < p.rows; row += (int64_t)gridDim.x * G) {
-    Row<VEC, LPR, CH> x, d, h;
-    x.load(p.x + row * p.ld_x, g, p.M);
-    d.load(p.dy + row * p.ld_dy, g, p.M);
+  // rows this lane group owns: R consecutive rows per pass (all requested up front), passes with a grid stride
+  constexpr int R = rows_in_flight<LPR>();
+  for (int64_t base = ((int64_t)blockIdx.x * G + grp) * R; base < p.rows; base += (int64_t)gridDim.x * G * R) {
+    Row<VEC, LPR, CH> xs[R], ds[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int64_t rr = base + i < p.rows ? base + i : p.rows - 1;
+      xs[i].load(p.x + rr * p.ld_x, g, p.M);
+      ds[i].load(p.dy + rr * p.ld_dy, g, p.M);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+    const int64_t row = base + i;
+    if (row >= p.rows) break;            // whole lane group: `row` is uniform inside it
+    Row<VEC, LPR, CH> x = xs[i], d = ds[i], h;
     h = x;
     if (gelu) {
 #pragma unroll
@@ -190,6 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_row_epilogue_backward(RowArgs p) {
         for (int v = 0; v < VEC; ++v) d.a[c][v] *= gelu_erf_grad(x.a[c][v]);
     }
     d.store(p.out + row * p.ld_out, g, p.M);
+    }
   }
   if (!ln) return;
   // fold the G lane groups of this workgroup (fixed order) and store one partial row
@@ -237,10 +266,11 @@ __global__ __launch_bounds__(64 * kSumSlices) void k_partial_rows_sum(const floa
   }
 }
 
-int backward_blocks(int64_t rows, int groups_per_block) {
-  // two workgroups per CU keep the loads of this HBM-bound pass in flight; every workgroup costs one partial row
-  int64_t b = (rows + groups_per_block - 1) / groups_per_block;
-  if (b > 512) b = 512;
+constexpr int kMaxBackwardBlocks = 2048;
+int backward_blocks(int64_t rows, int rows_per_block_pass) {
+  // eight workgroups per CU keep the loads of this HBM-bound pass in flight; every workgroup costs one partial row
+  int64_t b = (rows + rows_per_block_pass - 1) / rows_per_block_pass;
+  if (b > kMaxBackwardBlocks) b = kMaxBackwardBlocks;
   return (int)(b < 1 ? 1 : b);
 }
 
@@ -284,9 +314,9 @@ extern "C" int ptgnn_amd_row_epilogue_f32(const float *x, int64_t ld_x, int64_t 
   p.rows = rows; p.M = dim; p.flags = flags;
   const bool vec4 = dim % 4 == 0 && ld_x % 4 == 0 && ld_y % 4 == 0 && aligned16(x) && aligned16(y);
   return dispatch(vec4, dim, [&](auto VEC, auto LPR, auto CH) -> int {
-    constexpr int G = kBlock / decltype(LPR)::value;
+    constexpr int GR = kBlock / decltype(LPR)::value * rows_in_flight<decltype(LPR)::value>();
     k_row_epilogue<decltype(VEC)::value, decltype(LPR)::value, decltype(CH)::value>
-        <<<(unsigned)((rows + G - 1) / G), kBlock, 0, st>>>(p);
+        <<<(unsigned)((rows + GR - 1) / GR), kBlock, 0, st>>>(p);
     PTGNN_LAUNCH_CHECK();
     return (int)PTGNN_AMD_OK;
   });
@@ -294,7 +324,7 @@ extern "C" int ptgnn_amd_row_epilogue_f32(const float *x, int64_t ld_x, int64_t 
 
 extern "C" size_t ptgnn_amd_row_epilogue_workspace_bytes(int64_t rows, int32_t dim) {
   if (rows <= 0 || dim <= 0) return 0;
-  return (size_t)512 * 2 * (size_t)dim * sizeof(float) + 256;
+  return (size_t)kMaxBackwardBlocks * 2 * (size_t)dim * sizeof(float) + 256;
 }
 
 extern "C" int ptgnn_amd_row_epilogue_backward_f32(const float *x, int64_t ld_x, const float *grad_y, int64_t ld_gy,
@@ -326,8 +356,8 @@ extern "C" int ptgnn_amd_row_epilogue_backward_f32(const float *x, int64_t ld_x,
                     aligned16(grad_y) && aligned16(grad_x);
   int nblocks = 0;
   const int rc = dispatch(vec4, dim, [&](auto VEC, auto LPR, auto CH) -> int {
-    constexpr int G = kBlock / decltype(LPR)::value;
-    nblocks = backward_blocks(rows, G);
+    constexpr int GR = kBlock / decltype(LPR)::value * rows_in_flight<decltype(LPR)::value>();
+    nblocks = backward_blocks(rows, GR);
     k_row_epilogue_backward<decltype(VEC)::value, decltype(LPR)::value, decltype(CH)::value>
         <<<(unsigned)nblocks, kBlock, 0, st>>>(p);
     PTGNN_LAUNCH_CHECK();
