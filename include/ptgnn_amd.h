@@ -280,6 +280,18 @@ int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_ysrc,
                                 size_t hub_ws_bytes, int32_t *hub_tickets /* nullable */,
                                 void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * reduce = "mul" of the scatter seam: abstractmessagepassing.py:44-50 hands the aggregation name to
+ * torch_scatter.scatter, whose reduce set also holds "mul" (no shipped ptgnn configuration uses it).
+ *   out[v, :] = product over the CSR slots i of row v of msg[perm[i], :], folded in slot order (= edge
+ *   order: the plan's sort is stable); rows without in-edges are 1, like torch_scatter's scatter_mul
+ *   (Reducer<MUL>::init(), no masked fill).  msg rows in the type-major message order, `perm` and
+ *   `rowptr` from ptgnn_amd_csr_build.  Deterministic; a plain HBM-bound kernel (hub rows are serial).
+ * ---------------------------------------------------------------------------------------- */
+int ptgnn_amd_segment_mul_f32(const float *msg, int64_t ld_msg, const int32_t *rowptr, const int32_t *perm,
+                              int64_t num_rows, int64_t num_edges, int32_t dim, float *out, int64_t ld_out,
+                              void *stream);
+
 /* Backward of the max/min aggregation w.r.t. the message table, over the BACKWARD plan (rows =
  * src * T + type, col = dst, built by ptgnn_amd_csr_build mode 2):
  *   out[r, c] = sum_{i in row r}  [ arg[col_i, c] == slot_of[i] ] * grad[col_i, c]

@@ -5,7 +5,7 @@
  * path uses (abstractmessagepassing.py:44-50): src [E, D] row-major fp32, index int64 [E]
  * broadcast along dim 0, out [N, D].
  *
- *   reduce: 0 = sum, 1 = mean, 2 = max, 3 = min
+ *   reduce: 0 = sum, 1 = mean, 2 = max, 3 = min, 4 = mul (init 1, product in edge order, empty segments stay 1)
  *   out is initialised to 0 (sum/mean) or the dtype's lowest/highest (max/min); elements are
  *   folded in edge order; mean divides by max(count, 1); for max/min, segments that received no
  *   element are written as 0 and arg (nullable) = E for them, else the winning edge position.
@@ -19,8 +19,8 @@
 
 int ptgnn_oracle_scatter_f32(const float *src, const int64_t *index, int64_t E, int64_t D,
                              int64_t N, int reduce, float *out, int64_t *arg) {
-  if (reduce < 0 || reduce > 3) return -1;
-  const float init = reduce == 2 ? -FLT_MAX : (reduce == 3 ? FLT_MAX : 0.0f);
+  if (reduce < 0 || reduce > 4) return -1;
+  const float init = reduce == 2 ? -FLT_MAX : (reduce == 3 ? FLT_MAX : (reduce == 4 ? 1.0f : 0.0f));
   for (int64_t i = 0; i < N * D; ++i) out[i] = init;
   if (arg) for (int64_t i = 0; i < N * D; ++i) arg[i] = E;
   int64_t *count = NULL;
@@ -33,6 +33,8 @@ int ptgnn_oracle_scatter_f32(const float *src, const int64_t *index, int64_t E, 
     if (reduce <= 1) {
       for (int64_t d = 0; d < D; ++d) o[d] += s[d];
       if (count) count[v]++;
+    } else if (reduce == 4) {
+      for (int64_t d = 0; d < D; ++d) o[d] *= s[d];
     } else if (reduce == 2) {
       for (int64_t d = 0; d < D; ++d)
         if (s[d] > o[d]) { o[d] = s[d]; if (arg) arg[v * D + d] = e; }
@@ -47,7 +49,7 @@ int ptgnn_oracle_scatter_f32(const float *src, const int64_t *index, int64_t E, 
       for (int64_t d = 0; d < D; ++d) out[v * D + d] /= c;
     }
     free(count);
-  } else if (reduce >= 2) {
+  } else if (reduce == 2 || reduce == 3) {
     /* torch_scatter: out.masked_fill_(arg_out == src.size(dim), 0) */
     char *touched = (char *)calloc((size_t)(N > 0 ? N : 1), 1);
     for (int64_t e = 0; e < E; ++e) touched[index[e]] = 1;

@@ -12,6 +12,8 @@ restates torch_scatter/scatter.py + csrc/cpu/scatter_cpu.cpp (2.0.x):
   * mean: sum; count = scatter_sum(ones); count[count < 1] = 1; out /= count
   * max/min: reduce; segments that receive no element are 0; arg = winning position,
     src.size(dim) for empty segments; ``scatter(reduce="max")`` returns values only
+  * mul : ones(dim_size).scatter_(dim, index, src, reduce="multiply"): the product in edge order; a segment that
+    receives no element stays 1 (Reducer<MUL>::init() and no masked_fill afterwards, unlike max/min)
   * scatter_log_softmax: src - max_seg - log(sum_seg exp(src - max_seg) + eps)
 
 PARITY STATUS: the reference's own tests hold no golden vectors for this path
@@ -72,6 +74,17 @@ def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
     return out
 
 
+def scatter_mul(src, index, dim=-1, out=None, dim_size=None):
+    """torch_scatter.scatter_mul (torch_scatter/scatter.py: `torch.ops.torch_scatter.scatter_mul`; csrc/cpu/reducer.h
+    MUL: init 1, update `*val *= new_val`), folded in edge order like the serial CPU kernel."""
+    index = _broadcast(index, src, dim)
+    if out is None:
+        size = list(src.size())
+        size[dim] = _dim_size(index, dim_size)
+        out = torch.ones(size, dtype=src.dtype, device=src.device)
+    return out.scatter_reduce_(dim, index, src, reduce="prod", include_self=True)
+
+
 def _scatter_minmax(src, index, dim, dim_size, is_max):
     """Serial restatement of torch_scatter csrc/cpu/scatter_cpu.cpp for max/min (+arg)."""
     if dim < 0:
@@ -113,6 +126,8 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
         return scatter_max(src, index, dim, out, dim_size)[0]
     if reduce == "min":
         return scatter_min(src, index, dim, out, dim_size)[0]
+    if reduce == "mul":
+        return scatter_mul(src, index, dim, out, dim_size)
     raise ValueError(reduce)
 
 

@@ -276,6 +276,8 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
             return False
         if self.training and self.__dropout.p > 0:
             return False
+        if self.__aggregation_fn not in ops.REDUCE_IDS:   # "mul": the scatter seam's own kernel (general path)
+            return False
         return node_states.dtype == torch.float32
 
     def _fused_ok(self, node_states, edge_features) -> bool:
@@ -513,8 +515,8 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
         return torch.cat(parts, dim=0).contiguous()
 
     def _table_ok(self, node_states, edge_features) -> bool:
-        if not isinstance(self.__aggregation_fn, str):
-            return False
+        if not isinstance(self.__aggregation_fn, str) or self.__aggregation_fn not in ops.REDUCE_IDS:
+            return False                                     # aggregation modules; "mul": the seam's own kernel
         if self._features_dimension != 0 or any(f is not None and f.shape[-1] != 0 for f in edge_features):
             return False
         if not all(m.is_single_linear for m in self.__edge_message_transformation_layers):

@@ -802,6 +802,27 @@ def segment_reduce(messages: torch.Tensor, plan: GraphPlan, reduce: str, return_
                          type_bits=0, col=plan.perm)
 
 
+def segment_mul(messages: torch.Tensor, plan: GraphPlan) -> torch.Tensor:
+    """reduce="mul" of the torch_scatter seam over a plan (ptgnn_amd_segment_mul_f32): per destination row the product
+    of its messages in edge order; rows without in-edges are 1, like torch_scatter's scatter_mul."""
+    lib = _lib.load()
+    _require_cuda_f32("messages", messages)
+    if messages.shape[0] != plan.num_edges:
+        raise _lib.PtgnnAmdError("segment_mul: messages rows != number of edges in the plan")
+    if plan.perm is None:
+        raise _lib.PtgnnAmdError("segment_mul: plan was built without perm")
+    plan.wait()
+    msg = _rowmajor(messages)
+    n, d, E = plan.num_nodes, messages.shape[1], plan.num_edges
+    out = torch.empty(n, d, dtype=torch.float32, device=messages.device)
+    with _timed("segment_mul", bytes=E * (4.0 * d + 4) + n * 4.0 * d):
+        rc = lib.ptgnn_amd_segment_mul_f32(msg.data_ptr() if E > 0 else None, _ld(msg) if E > 0 else d,
+                                           plan.rowptr.data_ptr(), plan.perm.data_ptr(), n, E, d, out.data_ptr(), d,
+                                           _stream(out))
+    _lib.check(rc, "ptgnn_amd_segment_mul_f32")
+    return out
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            act: Optional[str] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = act(x W^T + b) on fp32 MFMA.  weight is nn.Linear layout [n_out, k]."""

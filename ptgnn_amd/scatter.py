@@ -4,8 +4,9 @@ Mirrors the call the reference makes at its single hot-path scatter site
 (ptgnn/neuralmodels/gnn/messagepassing/abstractmessagepassing.py:44-50):
 ``scatter(src, index=targets, dim=0, dim_size=num_nodes, reduce=fn)`` with `src` [E, D] and a 1-D
 int64 `index`.  Semantics follow torch_scatter 2.0.x: sum/mean/max/min, empty segments -> 0,
-mean divides by max(count, 1); backward: sum -> gather, mean -> gather / count, max/min -> the
-gradient flows only to the arg-max/min source element.
+mean divides by max(count, 1); mul: product in edge order, empty segments -> 1; backward: sum -> gather,
+mean -> gather / count, max/min -> the gradient flows only to the arg-max/min source element,
+mul -> (grad * out)[index] / src.
 """
 from typing import Optional
 
@@ -49,8 +50,37 @@ class _SegmentReduce(torch.autograd.Function):
         return ops.segment_spread(grad_out, arg, plan), None, None
 
 
+class _SegmentMul(torch.autograd.Function):
+    """reduce="mul" (torch_scatter.scatter_mul): out = product per destination in edge order, empty rows 1;
+    backward as torch_scatter's ScatterMul: grad_src = (grad_out * out)[index] / src, NaN (0 / 0) -> 0."""
+
+    @staticmethod
+    def forward(ctx, messages, plan):
+        out = ops.segment_mul(messages, plan)
+        ctx.plan = plan
+        ctx.save_for_backward(messages, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        messages, out = ctx.saved_tensors
+        plan = ctx.plan
+        E = plan.num_edges
+        if E == 0:
+            return torch.zeros_like(messages), None
+        deg = (plan.rowptr[1:] - plan.rowptr[:-1]).to(torch.int64)
+        row_of_slot = torch.repeat_interleave(torch.arange(plan.num_nodes, device=out.device), deg, output_size=E)
+        targets = torch.empty(E, dtype=torch.int64, device=out.device)
+        targets[plan.perm[:E].to(torch.int64)] = row_of_slot                  # destination of every message row
+        g = ops.gather_rows((grad_out * out).contiguous(), targets) / messages
+        return g.masked_fill(g.isnan(), 0.0), None
+
+
 def segment_reduce(messages: torch.Tensor, plan: "ops.GraphPlan", reduce: str) -> torch.Tensor:
-    """Differentiable `_aggregate_messages` over a prebuilt plan."""
+    """Differentiable `_aggregate_messages` over a prebuilt plan (torch_scatter's reduce set: sum / add / mean / max /
+    min on the fused HIP segment reduce, mul on its own kernel)."""
+    if reduce == "mul":
+        return _SegmentMul.apply(messages, plan)
     if reduce not in ops.REDUCE_IDS:
         raise ValueError(f"unknown aggregation function {reduce!r}")
     return _SegmentReduce.apply(messages, plan, reduce)
@@ -91,6 +121,11 @@ def scatter_sum(src, index, dim: int = -1, out=None, dim_size: Optional[int] = N
 
 
 scatter_add = scatter_sum
+
+
+def scatter_mul(src, index, dim: int = -1, out=None, dim_size: Optional[int] = None) -> torch.Tensor:
+    """torch_scatter.scatter_mul."""
+    return scatter(src, index, dim, out, dim_size, "mul")
 
 
 def scatter_mean(src, index, dim: int = -1, out=None, dim_size: Optional[int] = None) -> torch.Tensor:

@@ -305,6 +305,60 @@ def test_scatter_facade_family_matches_oracle(shape):
         np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("shape", [(3000, 48), (3000, 7), (500,)])
+def test_scatter_mul_matches_oracle_forward_and_backward(shape):
+    """reduce="mul" of the scatter seam (torch_scatter.scatter_mul; abstractmessagepassing.py:44-50 passes any of
+    torch_scatter's reduce names through): product in edge order, empty segments 1, backward
+    (grad * out)[index] / src -- vs oracle/scatter_ref.py (restated + KATs in tests/test_oracle_kat.py)."""
+    from oracle import scatter_ref as R
+    from ptgnn_amd import scatter as S
+    g = torch.Generator().manual_seed(sum(shape))
+    E, segs = shape[0], 257
+    src = 1.0 + 0.25 * torch.randn(*shape, generator=g)            # products of ~12 factors near 1
+    idx = torch.randint(0, segs - 4, (E,), generator=g)            # trailing segments stay empty -> 1
+    go = torch.randn(segs, *shape[1:], generator=g)
+    a = src.clone().requires_grad_(True)
+    want = R.scatter(a, idx, dim=0, dim_size=segs, reduce="mul")
+    want.backward(go)
+    b = src.clone().cuda().requires_grad_(True)
+    got = S.scatter(b, idx.cuda(), dim=0, dim_size=segs, reduce="mul")
+    got.backward(go.cuda())
+    assert torch.equal(got[segs - 4:].cpu(), torch.ones_like(want[segs - 4:]))
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(S.scatter_mul(b.detach(), idx.cuda(), dim=0, dim_size=segs).cpu().numpy(),
+                               want.detach().numpy(), rtol=2e-6, atol=1e-6)
+
+
+def test_ggnn_layer_with_mul_aggregation_matches_oracle():
+    """A GGNN layer whose `message_aggregation_function` is "mul" (legal in the reference: the name goes straight to
+    torch_scatter) runs on the HIP GEMMs + the seam's product kernel, inference and training, vs the oracle."""
+    from oracle import mp_oracle as O
+    from ptgnn_amd import layers as L, ops, workloads
+    mb = workloads.batched_graphs(3, 200, 3, 1.2, seed=15)
+    N, H = mb["num_nodes"], 32
+    adj = O.augment_adjacency(mb["adjacency_lists"], N, True, True)
+    T = len(adj)
+    torch.manual_seed(4)
+    layer = L.GatedMessagePassingLayer(H, H, T, "mul")
+    x = workloads.node_states(N, H, seed=9)
+    spec = layer.export_weights()
+    xo = x.clone().requires_grad_(True)
+    want = O.ggnn_layer(xo, adj, [torch.empty(a[0].shape[0], 0) for a in adj], spec)
+    gout = workloads.node_states(N, H, seed=10)
+    want.backward(gout)
+    layer = layer.cuda()
+    cadj = to_cuda_adj(adj)
+    ops.clear_plan_cache()
+    with torch.no_grad():
+        got = layer.eval()(x.cuda(), cadj, None, {}, {}, empty_feats(cadj, "cuda"))
+    np.testing.assert_allclose(got.cpu().numpy(), want.detach().numpy(), rtol=0, atol=TOL)
+    xg = x.cuda().requires_grad_(True)
+    layer.train()(xg, cadj, None, {}, {}, empty_feats(cadj, "cuda")).backward(gout.cuda())
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=0,
+                               atol=2e-5 * max(1.0, float(xo.grad.abs().max())))
+
+
 @pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
 def test_scatter_backward_matches_oracle_autograd(reduce):
     from oracle import scatter_ref

@@ -38,6 +38,25 @@ def test_sharded_paths_over_real_process_group(world):
     assert len(re.findall(r"rank \d+ ok ", r.stdout)) == 13 * world, tail
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_powerlaw_shard_with_hub_rows_at_4_and_8_ranks(world):
+    """SURVEY.md 8e at the rank counts BASELINE configs 4 and 5 name (no multi-GPU box behind `gpurun`: 4 and 8 REAL
+    processes share cuda:0 over gloo): a cfg5-shaped power-law graph whose hub rows have sources on every rank, through
+    the HIP index pass, the halo all-to-all(v) and the hub / long-row aggregation -- see `case_powerlaw_hubs`."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "two_rank_gpu_check.py")]
+    # processes that share one GPU turn every cross-stream event wait into a scheduling quantum: one stream per process
+    env = dict(os.environ, OMP_NUM_THREADS="2", TWO_RANK_CASES="powerlaw", PTGNN_AMD_HUB_STREAM="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + "\n" + r.stderr)[-6000:]
+    assert r.returncode == 0, tail
+    assert len(re.findall(r"rank \d+ ok powerlaw_", r.stdout)) == 3 * world, tail
+    assert sum(int(m) for m in re.findall(r"powerlaw_ggnn_sum hubs_here=(\d+)", r.stdout)) > 0, tail
+
+
 def test_bench_watchdog_emits_the_primary_line_when_a_rank_stalls():
     """bench.py --gpus 2 (gloo, both ranks on cuda:0 -- the validation hook for 1-GPU boxes) with rank 1 stalled right
     before the sharded cut-edge variants: rank 0 blocks in their first collective, the per-rank watchdog ends every

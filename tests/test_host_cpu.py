@@ -126,7 +126,7 @@ def test_scatter_facade_rejects_unsupported_layouts():
         scatter(torch.randn(4, 3), torch.tensor([0, 1, 0, 1]), dim=0, out=torch.zeros(2, 3))
     with pytest.raises(ValueError):
         from ptgnn_amd.scatter import segment_reduce
-        segment_reduce(torch.randn(2, 2), None, "mul")
+        segment_reduce(torch.randn(2, 2), None, "median")      # not one of torch_scatter's reduce names
 
 
 def test_product_package_never_imports_the_oracle():
@@ -306,3 +306,25 @@ def test_library_carries_no_vendor_sort_or_scan(lib):
     assert b"rocprim" not in blob, "a rocPRIM kernel or symbol is linked into libptgnn_amd.so"
     src = open(os.path.join(os.path.dirname(_lib.LIB_PATH), "csr_build.hip")).read()
     assert "#include <rocprim" not in src and "hipcub" not in src
+
+
+def test_plan_build_refuses_sizes_beyond_the_int32_plan_format(lib):
+    """`E < 2^31`, `num_src_rows * 2^type_bits < 2^31` per GPU.  The check is an argument check: it answers
+    with PTGNN_AMD_EUNSUPPORTED (and a message naming the numbers) before anything touches the device, so it runs
+    here without a GPU; the pointers are never dereferenced."""
+    import ctypes
+    fake = ctypes.c_void_p(0x1000)
+
+    def build(counts, num_nodes, num_src_rows=0):
+        T = len(counts)
+        ptrs = (ctypes.c_void_p * T)(*[0x1000] * T)
+        cnts = (ctypes.c_int64 * T)(*counts)
+        return lib.ptgnn_amd_csr_build(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(ptrs, ctypes.c_void_p),
+                                       ctypes.cast(cnts, ctypes.c_void_p), T, num_nodes, num_src_rows, 0, fake, fake,
+                                       fake, None, 0, None, None, None, None, fake, 1 << 20, None)
+
+    assert build([1 << 30, 1 << 30], 1000) == -2                      # E = 2^31
+    assert b"exceed the int32 plan format" in lib.ptgnn_amd_last_error()
+    assert build([10] * 32, 1 << 26) == -2                             # rows * 2^type_bits = 2^26 * 2^5 = 2^31
+    assert build([10], 1 << 31) == -2                                  # rows = 2^31
+    assert build([10] * 17, 1000, num_src_rows=1 << 27) == -2          # halo table: source rows * 2^5 >= 2^31

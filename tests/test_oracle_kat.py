@@ -23,10 +23,11 @@ EXPECT = {
     "mean": [[1.75, 2.125], [0, 0], [-1.0 / 3.0, 0.0], [0, 0]],
     "max": [[3.0, 4.0], [0, 0], [5.0, 8.0], [0, 0]],
     "min": [[0.5, 0.25], [0, 0], [-7.0, -6.0], [0, 0]],
+    "mul": [[1.5, 1.0], [1, 1], [-35.0, 96.0], [1, 1]],        # empty segments stay 1 (Reducer<MUL>::init)
 }
 
 
-@pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min", "mul"])
 def test_scatter_known_answers(reduce):
     out = sr.scatter(SRC, IDX, dim=0, dim_size=N, reduce=reduce)
     assert out.dtype == torch.float32 and tuple(out.shape) == (N, 2)
@@ -83,18 +84,20 @@ def c_scatter(lib, src, idx, n, reduce):
     out = np.empty((n, src.shape[1]), np.float32)
     arg = np.empty((n, src.shape[1]), np.int64)
     rc = lib.ptgnn_oracle_scatter_f32(src.ctypes.data, idx.ctypes.data, src.shape[0], src.shape[1],
-                                      n, ["sum", "mean", "max", "min"].index(reduce),
+                                      n, ["sum", "mean", "max", "min", "mul"].index(reduce),
                                       out.ctypes.data, arg.ctypes.data)
     assert rc == 0
     return out, arg
 
 
-@pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min", "mul"])
 def test_c_restatement_matches_known_answers_and_torch_restatement(clib, reduce):
     out, _ = c_scatter(clib, SRC.numpy(), IDX.numpy(), N, reduce)
     np.testing.assert_allclose(out, np.asarray(EXPECT[reduce], np.float32), rtol=0, atol=1e-7)
     rng = np.random.RandomState(7)
     src = rng.randn(5000, 33).astype(np.float32)
+    if reduce == "mul":
+        src = (1.0 + 0.2 * src).astype(np.float32)           # products of ~7 factors near 1
     idx = rng.randint(0, 700, size=5000)
     idx[idx == 13] = 14  # guarantee an empty segment
     out, arg = c_scatter(clib, src, idx, 701, reduce)
@@ -108,4 +111,4 @@ def test_c_restatement_matches_known_answers_and_torch_restatement(clib, reduce)
         np.testing.assert_array_equal(out, ref.numpy())      # same edge order -> bit exact
     else:
         np.testing.assert_allclose(out, ref.numpy(), rtol=1e-6, atol=1e-7)
-    assert np.all(out[13] == 0)
+    assert np.all(out[13] == (1 if reduce == "mul" else 0))

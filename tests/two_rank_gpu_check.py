@@ -208,12 +208,61 @@ def case_graph_boundaries(rank, world):
     ops.check_indices(sync=True)     # the range guard saw no source outside the own rows
 
 
+def case_powerlaw_hubs(rank, world):
+    """BASELINE config 5's shape, scaled: ONE power-law graph (Zipf-0.8 destinations => hub rows of > 2048 in-edges,
+    long rows of 257..2048) whose sources are uniform over ALL ranks' nodes, so every hub row has in-edges from every
+    rank and (world - 1) / world of the edges are cut; one GGNN layer (T = 1: table form, message rows travel) and one
+    MLP-MP layer, H = 64.  max is bit-identical to the unsharded layer on every row; a sum is bit-identical on ordinary
+    rows and within 5e-6 (1 + row mass) on hub rows (a hub row folds chunk-wise, and a shard's chunk boundaries sit
+    elsewhere: gather_reduce.hip)."""
+    from ptgnn_amd import layers as L, ops, sharded, workloads
+    H, n, E = 64, 160_000, 1_600_000
+    adj = workloads.power_law_graph(n, E, alpha=0.8, seed=71)
+    g = torch.Generator().manual_seed(72)
+    adj = [(torch.randint(0, n, (E,), generator=g), adj[0][1])]        # sources uniform over every rank's range
+    indeg = torch.bincount(adj[0][1], minlength=n)
+    assert int(indeg.max()) > ops.HUB_THRESHOLD
+    x = workloads.node_states(n, H, seed=73).cuda()
+    L.EDGE_PATH_BIAS = 1.25
+    ranges = _ranges(adj, n, world)
+    lo, hi = ranges[rank]
+    hubs = (indeg[lo:hi] > ops.HUB_THRESHOLD).cuda()
+    cadj = _cuda_adj(adj)
+    src_owner = torch.bucketize(adj[0][0], torch.tensor([r[1] for r in ranges]), right=True)
+    for name, make in (("ggnn_sum", lambda: L.GatedMessagePassingLayer(H, H, 1, "sum")),
+                       ("ggnn_max", lambda: L.GatedMessagePassingLayer(H, H, 1, "max")),
+                       ("mlp_max", lambda: L.MlpMessagePassingLayer(H, H, H, 1, "max"))):
+        torch.manual_seed(74)
+        layer = make().cuda().eval()
+        ops.clear_plan_cache()
+        with torch.no_grad():
+            want = layer(x, cadj, None, {}, {}, [None])[lo:hi]
+        shard = sharded.ShardedGraph.build(_mine(adj, lo, hi), (lo, hi), all_ranges=ranges)
+        assert not shard.no_cut and shard.n_halo > 0
+        if bool(hubs.any()):      # the largest hub of this rank has sources on every rank
+            hub = lo + int(torch.argmax(indeg[lo:hi]))
+            assert len(torch.unique(src_owner[adj[0][1] == hub])) == world
+        with torch.no_grad():
+            got = layer.forward_sharded(x[lo:hi].contiguous(), shard)
+        if name.endswith("max"):
+            np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
+        else:
+            assert torch.equal(got[~hubs], want[~hubs])
+            if bool(hubs.any()):
+                err = float((got[hubs] - want[hubs]).abs().max())
+                assert err <= 1e-5, err       # GRU output of a hub row (the aggregate itself moves by ~1e-6 relative)
+        _ok(rank, f"powerlaw_{name} hubs_here={int(hubs.sum())} halo={shard.n_halo}")
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    which = os.environ.get("TWO_RANK_CASES", "default")
+    cases = {"default": (case_layers, case_stack, case_training, case_graph_boundaries),
+             "powerlaw": (case_powerlaw_hubs,)}[which]
     try:
-        for case in (case_layers, case_stack, case_training, case_graph_boundaries):
+        for case in cases:
             case(rank, world)
             dist.barrier()
     finally:
