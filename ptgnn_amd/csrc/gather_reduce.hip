@@ -904,6 +904,47 @@ __global__ __launch_bounds__(256) void k_segment_spread(const float *__restrict_
     }
   }
 }
+
+// The widths the layers use (dim = 4 LPR, LPR in {16, 32, 64}; float4 rows): one slot per group of LPR lanes, SPG slots
+// per group and pass with all their loads requested up front.  The generic kernel above spends a 64-bit division per
+// item and has one dependent chain (slot -> row index -> gradient row -> store) per thread in flight: 0.46-0.50 of HBM
+// on the training step's [625 k, 128] / [625 k, 64] spreads (profiles/r03_notes.md).
+template <int LPR, int SPG, bool HAS_ARG>
+__global__ __launch_bounds__(256) void k_segment_spread_rows(const float *__restrict__ grad, int64_t ld_grad,
+                                                             const int32_t *__restrict__ arg,
+                                                             const int32_t *__restrict__ slot_row,
+                                                             const int32_t *__restrict__ perm, int64_t num_slots,
+                                                             float *__restrict__ out, int64_t ld_out) {
+  constexpr int G = 256 / LPR, DIM = 4 * LPR;
+  const int g = threadIdx.x % LPR, c = 4 * g;
+  const int64_t s0 = ((int64_t)blockIdx.x * G + threadIdx.x / LPR) * SPG;
+  if (s0 >= num_slots) return;
+  int64_t row[SPG], e[SPG];
+#pragma unroll
+  for (int k = 0; k < SPG; ++k) {
+    const int64_t s = s0 + k < num_slots ? s0 + k : num_slots - 1;
+    row[k] = slot_row[s];
+    e[k] = perm[s];
+  }
+  float4 v[SPG];
+  int4 a[SPG];
+#pragma unroll
+  for (int k = 0; k < SPG; ++k) {
+    v[k] = *reinterpret_cast<const float4 *>(grad + row[k] * ld_grad + c);
+    if constexpr (HAS_ARG) a[k] = *reinterpret_cast<const int4 *>(arg + row[k] * DIM + c);
+  }
+#pragma unroll
+  for (int k = 0; k < SPG; ++k) {
+    if (s0 + k >= num_slots) break;                   // uniform inside the lane group
+    float4 o = v[k];
+    if constexpr (HAS_ARG) {
+      const int32_t si = (int32_t)(s0 + k);
+      o.x = a[k].x == si ? o.x : 0.f; o.y = a[k].y == si ? o.y : 0.f;
+      o.z = a[k].z == si ? o.z : 0.f; o.w = a[k].w == si ? o.w : 0.f;
+    }
+    *reinterpret_cast<float4 *>(out + e[k] * ld_out + c) = o;
+  }
+}
 }  // namespace
 }  // namespace ptgnn_amd
 
@@ -917,6 +958,24 @@ extern "C" int ptgnn_amd_segment_spread_f32(const float *grad, int64_t ld_grad, 
   PTGNN_REQUIRE(ld_grad >= dim && ld_out >= dim, PTGNN_AMD_EINVAL, "segment_spread: bad leading dimension");
   const bool vec4 = (dim % 4 == 0) && (ld_grad % 4 == 0) && (ld_out % 4 == 0) && aligned16(grad) &&
                     aligned16(out) && (!arg || aligned16(arg));
+  if (vec4 && (dim == 64 || dim == 128 || dim == 256) && num_slots < ((int64_t)1 << 31)) {
+#ifndef PTGNN_SPREAD_SPG
+#define PTGNN_SPREAD_SPG 2   // measured at [625 k, 128] max: 1 -> 112 us, 2 -> 92, 4 -> 95 (generic kernel: 120)
+#endif
+    constexpr int SPG = PTGNN_SPREAD_SPG;
+    hipStream_t st = (hipStream_t)stream_;
+#define PTGNN_SPREAD(LPRV)                                                                                     \
+  do {                                                                                                         \
+    const int64_t per_block = (256 / LPRV) * SPG;                                                              \
+    const unsigned grid = (unsigned)((num_slots + per_block - 1) / per_block);                                 \
+    if (arg) k_segment_spread_rows<LPRV, SPG, true><<<grid, 256, 0, st>>>(grad, ld_grad, arg, slot_row, perm, num_slots, out, ld_out); \
+    else k_segment_spread_rows<LPRV, SPG, false><<<grid, 256, 0, st>>>(grad, ld_grad, arg, slot_row, perm, num_slots, out, ld_out);    \
+  } while (0)
+    if (dim == 64) PTGNN_SPREAD(16); else if (dim == 128) PTGNN_SPREAD(32); else PTGNN_SPREAD(64);
+#undef PTGNN_SPREAD
+    PTGNN_LAUNCH_CHECK();
+    return PTGNN_AMD_OK;
+  }
   const int64_t items = num_slots * (vec4 ? dim / 4 : dim);
   int64_t blocks = (items + 255) / 256;
   if (blocks > 65536) blocks = 65536;

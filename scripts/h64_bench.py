@@ -31,7 +31,25 @@ def forced(flag, fn):
     return run
 
 
+from ptgnn_amd import workloads  # noqa: E402
+mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234)
+adj = [(s_.cuda(), d_.cuda()) for s_, d_ in mb["adjacency_lists"]]
+adj = adj + [(d_, s_) for s_, d_ in adj]
+ar = torch.arange(N, device="cuda")
+adj.append((ar, ar))
+plan = ops.plan_for(adj, N)
+E = plan.num_edges
+m64, m128 = rnd(E, 64), rnd(E, 128)
+_, arg64 = ops.segment_reduce(m64, plan, "max", return_arg=True)
+_, arg128 = ops.segment_reduce(m128, plan, "max", return_arg=True)
+
 cases = {
+    "spread_max_128": lambda: ops.segment_spread(g128, arg128, plan),
+    "spread_sum_128": lambda: ops.segment_spread(g128, None, plan),
+    "spread_max_64": lambda: ops.segment_spread(g64, arg64, plan),
+    "segreduce_max_128": lambda: ops.segment_reduce(m128, plan, "max"),
+    "segreduce_max_64": lambda: ops.segment_reduce(m64, plan, "max"),
+    "copy_E128": lambda: m128.copy_(m128),
     "linear_64_64_tanh_tile": forced("0", lambda: ops.linear(x64, w6464, b64, act="tanh")),
     "linear_64_64_tanh_stream": forced("1", lambda: ops.linear(x64, w6464, b64, act="tanh")),
     "linear_64_64_tile": forced("0", lambda: ops.linear(g64, w6464)),
