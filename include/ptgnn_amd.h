@@ -489,6 +489,13 @@ int ptgnn_amd_row_epilogue_f32(const float *x, int64_t ld_x, int64_t rows, int32
                                const float *ln_beta /* nullable without LayerNorm */, float ln_eps, float *y,
                                int64_t ld_y, void *stream);
 size_t ptgnn_amd_row_epilogue_workspace_bytes(int64_t rows, int32_t dim);
+
+/* Backward of the node update's activation + dropout (mlpmessagepassing.py:62-66: Linear -> Tanh -> Dropout) in one
+ * pass: out[i] = grad[i] * (keep[i] ? scale : 0) * act'(y[i]) with y = the activation's OUTPUT (tanh': 1 - y^2,
+ * relu': y > 0, none: 1), keep = the dropout's boolean mask (one byte per element; NULL = no dropout), scale = 1/(1-p).
+ * Contiguous arrays of n elements, n % 4 == 0, 16-byte aligned (else EUNSUPPORTED). */
+int ptgnn_amd_act_dropout_backward_f32(const float *grad, const float *y, const uint8_t *keep, float scale, int act,
+                                       int64_t n, float *out, void *stream);
 int ptgnn_amd_row_epilogue_backward_f32(const float *x, int64_t ld_x, const float *grad_y, int64_t ld_gy,
                                         int64_t rows, int32_t dim, int32_t flags, const float *ln_gamma,
                                         float ln_eps, float *grad_x, int64_t ld_gx,

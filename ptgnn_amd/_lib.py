@@ -71,6 +71,7 @@ SIGNATURES = {
     "ptgnn_amd_segment_spread_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "ptgnn_amd_row_epilogue_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _c.c_float, _vp, _i64, _vp]),
     "ptgnn_amd_row_epilogue_workspace_bytes": (_c.c_size_t, [_i64, _i32]),
+    "ptgnn_amd_act_dropout_backward_f32": (_c.c_int, [_vp, _vp, _vp, _c.c_float, _c.c_int, _i64, _vp, _vp]),
     "ptgnn_amd_row_epilogue_backward_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _c.c_float, _vp,
                                                        _i64, _vp, _vp, _vp, _c.c_size_t, _vp]),
     "ptgnn_amd_gru_cell_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,

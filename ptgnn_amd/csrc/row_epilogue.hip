@@ -323,6 +323,59 @@ extern "C" int ptgnn_amd_row_epilogue_f32(const float *x, int64_t ld_x, int64_t 
   });
 }
 
+namespace ptgnn_amd {
+namespace {
+// out = grad * (keep ? scale : 0) * act'(y), y = act(.) the forward output BEFORE dropout: the backward of the MLP-MP
+// node update's Tanh + Dropout (mlpmessagepassing.py:62-66) as one pass instead of torch's two elementwise kernels
+template <int ACT, bool KEEP>
+__global__ __launch_bounds__(256) void k_act_dropout_backward(const float *__restrict__ grad, const float *__restrict__ y,
+                                                              const uint8_t *__restrict__ keep, float scale, int64_t n4,
+                                                              float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 g = reinterpret_cast<const float4 *>(grad)[i];
+  const float4 v = reinterpret_cast<const float4 *>(y)[i];
+  float m[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (KEEP) {
+    const uchar4 k = reinterpret_cast<const uchar4 *>(keep)[i];
+    m[0] = k.x ? scale : 0.f; m[1] = k.y ? scale : 0.f; m[2] = k.z ? scale : 0.f; m[3] = k.w ? scale : 0.f;
+  }
+  auto d = [](float yv) {
+    if constexpr (ACT == PTGNN_AMD_ACT_TANH) return 1.0f - yv * yv;
+    if constexpr (ACT == PTGNN_AMD_ACT_RELU) return yv > 0.f ? 1.0f : 0.f;
+    return 1.0f;
+  };
+  reinterpret_cast<float4 *>(out)[i] = make_float4(g.x * m[0] * d(v.x), g.y * m[1] * d(v.y), g.z * m[2] * d(v.z),
+                                                   g.w * m[3] * d(v.w));
+}
+}  // namespace
+}  // namespace ptgnn_amd
+
+extern "C" int ptgnn_amd_act_dropout_backward_f32(const float *grad, const float *y, const uint8_t *keep, float scale,
+                                                  int act, int64_t n, float *out, void *stream_) {
+  PTGNN_REQUIRE(n >= 0 && act >= PTGNN_AMD_ACT_NONE && act <= PTGNN_AMD_ACT_RELU, PTGNN_AMD_EINVAL,
+                "act_dropout_backward: bad arguments");
+  if (n == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(grad && y && out, PTGNN_AMD_EINVAL, "act_dropout_backward: null pointer");
+  PTGNN_REQUIRE(n % 4 == 0 && aligned16(grad) && aligned16(y) && aligned16(out) && (!keep || ((uintptr_t)keep & 3u) == 0),
+                PTGNN_AMD_EUNSUPPORTED, "act_dropout_backward: needs n %% 4 == 0 and 16-byte aligned arrays");
+  const int64_t n4 = n / 4;
+  PTGNN_REQUIRE((n4 + 255) / 256 < ((int64_t)1 << 31), PTGNN_AMD_EUNSUPPORTED, "act_dropout_backward: too many elements");
+  const unsigned grid = (unsigned)((n4 + 255) / 256);
+  hipStream_t st = (hipStream_t)stream_;
+#define PTGNN_ADB(ACTV)                                                                                   \
+  do {                                                                                                    \
+    if (keep) k_act_dropout_backward<ACTV, true><<<grid, 256, 0, st>>>(grad, y, keep, scale, n4, out);    \
+    else k_act_dropout_backward<ACTV, false><<<grid, 256, 0, st>>>(grad, y, keep, scale, n4, out);        \
+  } while (0)
+  if (act == PTGNN_AMD_ACT_TANH) PTGNN_ADB(PTGNN_AMD_ACT_TANH);
+  else if (act == PTGNN_AMD_ACT_RELU) PTGNN_ADB(PTGNN_AMD_ACT_RELU);
+  else PTGNN_ADB(PTGNN_AMD_ACT_NONE);
+#undef PTGNN_ADB
+  PTGNN_LAUNCH_CHECK();
+  return PTGNN_AMD_OK;
+}
+
 extern "C" size_t ptgnn_amd_row_epilogue_workspace_bytes(int64_t rows, int32_t dim) {
   if (rows <= 0 || dim <= 0) return 0;
   return (size_t)kMaxBackwardBlocks * 2 * (size_t)dim * sizeof(float) + 256;

@@ -84,6 +84,52 @@ class _Linear(torch.autograd.Function):
         return d_x, d_w, d_b
 
 
+class _LinearActDropout(torch.autograd.Function):
+    """Dropout(act(x W^T + b)) -- the node update of mlpmessagepassing.py:60-66 -- as ONE autograd node: forward = the
+    GEMM with the activation in its epilogue (what inference runs) + torch's dropout kernel (its mask is kept: same
+    generator stream as nn.Dropout); backward = one elementwise HIP pass (mask, scale, act') in front of `_Linear`'s
+    GEMMs.  Torch ran five kernels around the GEMMs here (tanh, dropout, their two backwards, ...), each a full pass
+    over [N, H] -- a fifth of the README architecture's step was such passes."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, p, training):
+        y = ops.linear(x, weight, bias, act=act)
+        keep = None
+        out = y
+        if training and p > 0.0:
+            out, keep = torch.ops.aten.native_dropout(y, p, True)
+        ctx.save_for_backward(x, weight, y, keep)
+        ctx.has_bias, ctx.act, ctx.scale = bias is not None, act, (1.0 / (1.0 - p) if keep is not None else 1.0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y, keep = ctx.saved_tensors
+        g = g.contiguous()
+        if keep is not None or ctx.act is not None:
+            g = ops.act_dropout_backward(g, y, keep, ctx.scale, ctx.act)
+        d_x = d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_x = ops.linear(g, _transposed(weight))
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            res = ops.linear_weight_grad(x, g, want_bias=want_b)
+            d_w, d_b = res if want_b else (res, None)
+        elif want_b:
+            d_b = g.sum(dim=0)
+        return d_x, d_w, d_b, None, None, None
+
+
+def linear_act_dropout(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: Optional[str],
+                       p: float, training: bool) -> Optional[torch.Tensor]:
+    """Dropout(act(Linear(x))) as one autograd node, or None when the shape is not the fused node's (widths that are not
+    multiples of 4, non-fp32): the caller then composes `linear` with torch's activation / dropout modules."""
+    n_out, k = weight.shape
+    if not _kernel_dims_ok(x, weight) or k % 4 != 0 or n_out % 4 != 0 or x.stride(0) % 4 != 0 or p >= 1.0:
+        return None
+    return _LinearActDropout.apply(x, weight, bias, act, float(p), bool(training))
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Differentiable nn.Linear on the HIP kernels, any widths (odd ones take the kernels' unaligned staging
     path; the weight-gradient kernel sees them zero-padded to float4 rows).  There is no vendor-BLAS or CPU

@@ -651,9 +651,17 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
                 if self._dense_act is not None and not tanh:
                     x = self._dense_act(x)
             else:
+                act = self._dense_act
+                name = "tanh" if isinstance(act, nn.Tanh) else ("relu" if isinstance(act, nn.ReLU) else None)
+                if (act is None or name is not None) and isinstance(self._dropout, nn.Dropout):
+                    # training: Dropout(act(Linear(x))) as one autograd node (dense._LinearActDropout)
+                    fused = dense.linear_act_dropout(x, self._dense.weight, self._dense.bias, name, self._dropout.p,
+                                                     self.training)
+                    if fused is not None:
+                        return fused
                 x = dense.linear(x, self._dense.weight, self._dense.bias)
-                if self._dense_act is not None:
-                    x = self._dense_act(x)
+                if act is not None:
+                    x = act(x)
         return self._dropout(x)
 
     def forward(self, node_states: torch.Tensor, adjacency_lists: Adj, node_to_graph_idx,

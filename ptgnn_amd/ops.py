@@ -1076,6 +1076,27 @@ def row_epilogue_backward(x: torch.Tensor, grad_y: torch.Tensor, flags: int, ln_
     return gx, gg, gb
 
 
+def act_dropout_backward(grad: torch.Tensor, y: torch.Tensor, keep: Optional[torch.Tensor], scale: float,
+                         act: Optional[str]) -> torch.Tensor:
+    """grad * (keep ? scale : 0) * act'(y) in one pass (ptgnn_amd_act_dropout_backward_f32); `y` is the activation's
+    output, `keep` the dropout's bool mask or None."""
+    lib = _lib.load()
+    _require_cuda_f32("grad", grad)
+    grad, y = grad.contiguous(), y.contiguous()
+    out = torch.empty_like(grad)
+    n = grad.numel()
+    if keep is not None:
+        keep = keep.contiguous()
+        if keep.dtype != torch.bool or keep.numel() != n:
+            raise _lib.PtgnnAmdError("act_dropout_backward: keep must be a bool mask of grad's shape")
+    with _timed("act_dropout_backward", bytes=(12.0 + (1.0 if keep is not None else 0.0)) * n):
+        rc = lib.ptgnn_amd_act_dropout_backward_f32(grad.data_ptr(), y.data_ptr(),
+                                                    keep.data_ptr() if keep is not None else None, float(scale),
+                                                    ACT_IDS[act], n, out.data_ptr(), _stream(out))
+    _lib.check(rc, "ptgnn_amd_act_dropout_backward_f32")
+    return out
+
+
 def gru_cell(a: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`out`: optional caller-owned [n, hd] fp32 destination with unit inner stride (e.g. the right half of the
     buffer a concat residual returns)."""

@@ -212,3 +212,37 @@ def test_gather_reduce_from_two_host_threads_on_two_streams_is_bit_identical():
         assert len(results[i]) == 20
         for s, m in results[i]:
             assert torch.equal(s, want[i][0]) and torch.equal(m, want[i][1])
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu", None])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_fused_linear_act_dropout_node_matches_torch_autograd(act, p):
+    """dense._LinearActDropout (the MLP-MP node update Linear -> Tanh -> Dropout of mlpmessagepassing.py:60-66 as one
+    autograd node) against torch autograd in float64 on the SAME dropout mask (recovered from the output's zeros)."""
+    from ptgnn_amd import dense
+    g = torch.Generator().manual_seed(5)
+    n, k, m = 3001, 64, 64
+    x = torch.randn(n, k, generator=g)
+    w = torch.randn(m, k, generator=g) / k ** 0.5
+    b = torch.randn(m, generator=g)
+    gout = torch.randn(n, m, generator=g)
+    xc, wc, bc = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    torch.manual_seed(11)
+    out = dense.linear_act_dropout(xc, wc, bc, act, p, True)
+    assert out is not None
+    out.backward(gout.cuda())
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    y = x64 @ w64.t() + b64
+    y = torch.tanh(y) if act == "tanh" else (torch.relu(y) if act == "relu" else y)
+    if p > 0:
+        keep = (out.detach().cpu() != 0) | (y.detach().abs() < 1e-12)     # relu zeros are not drops: see below
+        if act == "relu":
+            keep = (out.detach().cpu() != 0) | (y.detach() <= 0)
+        frac = 1.0 - float(keep.double().mean())
+        assert act == "relu" or abs(frac - p) < 0.02
+        y = y * keep.double() / (1.0 - p)
+    y.backward(gout.double())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), y.detach().float().numpy(), rtol=0, atol=TOL)
+    for got, want in ((xc.grad, x64.grad), (wc.grad, w64.grad), (bc.grad, b64.grad)):
+        sc = max(1.0, float(want.abs().max()))
+        np.testing.assert_allclose(got.cpu().numpy(), want.float().numpy(), rtol=0, atol=2e-5 * sc)
