@@ -367,7 +367,7 @@ def pmc_traffic(workload, kernel):
     cannot be read from inside a plain bench run, so the figure is the profiled one and names its source; null
     when no profile holds the kernel."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(root, f"{rnd}_{workload}_traffic.json")
         try:
             with open(path) as f:
@@ -475,12 +475,18 @@ def cpu_baseline_cfg3(st, gpu_out):
     e_small = 2 * sum(int(a[0].shape[0]) for a in small["adjacency_lists"]) + small["num_nodes"]
     with torch.no_grad():
         sweep, _ = _sweep(lambda: O.gnn_forward(xs, small["adjacency_lists"], st["specs"], True, True))
-        best = min((k for k in sweep if sweep[k] is not None), key=lambda k: sweep[k])
-        torch.set_num_threads(int(best))
-        # the FULL batch (the inputs the GPU line is measured on) at the best thread count: 1 warm-up + 3 timed,
-        # median; a warm-up beyond the budget is reported as the single figure it is
-        full, (want, n_edges), n_timed = _timed_forwards(
-            lambda: O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True), budget=12.0)
+        ranked = sorted((k for k in sweep if sweep[k] is not None), key=lambda k: sweep[k])
+        # the FULL batch (the inputs the GPU line is measured on) at the TWO best thread counts of the sample sweep (an
+        # 8-graph sample can rank them wrongly for the 48-graph batch: VERDICT r03 weak #14), 1 warm-up + 3 timed
+        # forwards each, median; the better one is `value`
+        full_by_threads, full, best = {}, None, ranked[0]
+        for cand in ranked[:2]:
+            torch.set_num_threads(int(cand))
+            sec, (want_c, n_edges_c), n_timed_c = _timed_forwards(
+                lambda: O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True), budget=9.0)
+            full_by_threads[cand] = round(sec, 3)
+            if full is None or sec < full:
+                full, best, want, n_edges, n_timed = sec, cand, want_c, n_edges_c, n_timed_c
     layers = st["layers_per_step"]
     parity = {"max_abs": float((gpu_out.cpu() - want).abs().max()), "tol": PARITY_TOL, "n": st["N"],
               "edges_counted_match": bool(n_edges == st["E"]),
@@ -488,12 +494,13 @@ def cpu_baseline_cfg3(st, gpu_out):
     return {"value": round(st["E"] / (full / layers), 1), "unit": "edges/s", "cores": int(best),
             "kind": "port", "host_cpus": os.cpu_count(), "seconds_by_threads_8_graph_sample": sweep,
             "full_batch_seconds": round(full, 3), "full_batch_timed_forwards": n_timed,
+            "full_batch_seconds_by_threads": full_by_threads,
             "sample_value": round(e_small / (sweep[best] / layers), 1),
             "sample_value_1_thread": round(e_small / (sweep["1"] / layers), 1),
             "sample": f"`value` = E / t_layer of the FULL Graph2Class batch (the GPU line's own inputs: N={st['N']}, "
                       f"E={st['E']}, {layers}-layer GGNN stack forward) at the best thread count (`cores`), 1 warm-up + "
-                      "3 timed forwards, median -- also the parity reference; the thread count comes from a sweep "
-                      f"{{1, 8, 32, all}} on the first 8 of the 48 graphs (N={small['num_nodes']}, E={e_small}; "
+                      "3 timed forwards, median -- also the parity reference; the thread count is the better of the two "
+                      f"best of a sweep {{1, 8, 32, all}} on the first 8 of the 48 graphs (N={small['num_nodes']}, E={e_small}; "
                       "`sample_value*`). torch-CPU fp32 restatement of the reference layers "
                       "(oracle/mp_oracle.py): the reference's own modules cannot be imported on the GPU box (no "
                       "/root/reference there); their timing in the authoring container is in BASELINE.md"}, parity

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -o a -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/a.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -o a -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-sustained > $OUT/a.log 2>&1
 python - <<PY > $OUT/summary.txt
 import csv, glob, collections
 f = glob.glob("$OUT/a/**/*counter_collection.csv", recursive=True)
