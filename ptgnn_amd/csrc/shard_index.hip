@@ -107,9 +107,13 @@ __global__ __launch_bounds__(256) void k_shard_blocks(const uint32_t *__restrict
 // one workgroup per kBlockWords-word block; thread t owns word t of the block (at one word per thread the serial part --
 // a store per set bit -- is 4x shorter than with the four words a thread of the first version owned: 19.4 -> 8.6 us on
 // the 2 M-bit map of BASELINE config 3's (type, source) pairs, every fourth bit set)
+// KEY_MOD: the ids are (edge type, source) keys t * num_src_rows + src of the shared-message bookkeeping and leave as the
+// source id (what the grouped GEMM gathers by) -- round 3 rewrote the list in a launch of its own (k_uniq_sources)
+template <bool KEY_MOD>
 __global__ __launch_bounds__(256) void k_shard_compact(const uint32_t *__restrict__ bitmap, int64_t words,
                                                        const int32_t *__restrict__ block_sum,
-                                                       int32_t *__restrict__ word_slot, int64_t *__restrict__ need_ids) {
+                                                       int32_t *__restrict__ word_slot, int64_t *__restrict__ need_ids,
+                                                       int64_t num_src_rows, int64_t capacity) {
   static_assert(kBlockWords == 256, "one bitmap word per thread");
   __shared__ int wsum[4];
   __shared__ int base_s;
@@ -143,7 +147,12 @@ __global__ __launch_bounds__(256) void k_shard_compact(const uint32_t *__restric
     while (bits) {
       const int b = __ffs((int)bits) - 1;
       bits &= bits - 1;
-      need_ids[run++] = w * 32 + b;
+      int64_t id = w * 32 + b;
+      if constexpr (KEY_MOD) {
+        id -= (id / num_src_rows) * num_src_rows;
+        if (run >= capacity) break;        // never happens for a plan's own keys (capacity = min(E, rows * T))
+      }
+      need_ids[run++] = id;
     }
   }
 }
@@ -197,10 +206,11 @@ __global__ __launch_bounds__(256) void k_shard_remap(ShardTable tab, int64_t edg
 // ascending in src inside a type -- and gives every CSR slot the row of its pair.  Integer bookkeeping only; which edges
 // share a row never changes a value (a message row is the same fmaf chain wherever it is computed).
 //   k_uniq_mark     one pass over the plan's col array ((src << type_bits) | type): a bit per pair that occurs
-//   k_shard_blocks / k_shard_compact  (above): rank of every set bit, the sorted key list
-//   k_uniq_counts   rows per edge type (+ the total) for the one host read-back
-//   k_uniq_sources  key -> source node id, in place (the "adjacency list" of the de-duplicated GEMM)
-//   k_uniq_remap    CSR slot -> message row
+//   k_uniq_pack / k_shard_compact<true>  rank of every set bit; the sorted keys leave as source node ids (the "adjacency
+//                   list" of the de-duplicated GEMM)
+//   k_uniq_remap    CSR slot -> message row; its last workgroup computes the rows per edge type (+ the total, for the one
+//                   host read-back) and the grouped GEMM's launch table
+// (round 4: five launches incl. the flag memset, where round 3 ran seven -- at this size every launch is ~4 us of ramp)
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int64_t uniq_key(int32_t c, int type_bits, int num_types, int64_t num_src_rows) {
   const uint32_t u = (uint32_t)c;
@@ -243,13 +253,14 @@ __global__ __launch_bounds__(256) void k_uniq_pack(const uint8_t *__restrict__ f
   if (threadIdx.x == 0) block_sum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-__global__ __launch_bounds__(64) void k_uniq_counts(const uint32_t *__restrict__ bitmap,
-                                                    const int32_t *__restrict__ word_slot, int64_t words,
-                                                    const int32_t *__restrict__ block_sum, int nblocks, int num_types,
-                                                    int64_t num_src_rows, int64_t *__restrict__ counts,
-                                                    const int64_t *unique_src, StreamEdgeTable *__restrict__ table,
-                                                    int budget_cus) {
-  const int lane = threadIdx.x;
+// one wave: rows per edge type (+ total) and the grouped GEMM's launch table
+__device__ __forceinline__ void uniq_counts_wave(const uint32_t *__restrict__ bitmap,
+                                                 const int32_t *__restrict__ word_slot, int64_t words,
+                                                 const int32_t *__restrict__ block_sum, int nblocks, int num_types,
+                                                 int64_t num_src_rows, int64_t *__restrict__ counts,
+                                                 const int64_t *unique_src, StreamEdgeTable *__restrict__ table,
+                                                 int budget_cus) {
+  const int lane = threadIdx.x & 63;
   int c = 0;
   for (int j = lane; j < nblocks; j += 64) c += block_sum[j];
 #pragma unroll
@@ -330,22 +341,25 @@ __global__ __launch_bounds__(64) void k_uniq_counts(const uint32_t *__restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void k_uniq_sources(int64_t *__restrict__ ids, int64_t capacity,
-                                                      const int64_t *__restrict__ counts, int num_types,
-                                                      int64_t num_src_rows) {
-  const int64_t total = counts[num_types] < capacity ? counts[num_types] : capacity;
-  for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < total; u += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t key = ids[u];
-    ids[u] = key - (key / num_src_rows) * num_src_rows;
-  }
-}
-
+// CSR slot -> message row for every edge; the LAST workgroup's first wave does not remap but runs the one-wave count /
+// launch-table pass (round 3: a launch of its own, 8.7 us of dependent latency in front of the remap -- the two only
+// share their inputs, so they run side by side now)
 __global__ __launch_bounds__(256) void k_uniq_remap(const int32_t *__restrict__ col, int64_t num_edges, int type_bits,
                                                     int num_types, int64_t num_src_rows,
                                                     const uint32_t *__restrict__ bitmap,
-                                                    const int32_t *__restrict__ word_slot,
-                                                    int32_t *__restrict__ slot_row) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < num_edges; i += (int64_t)gridDim.x * blockDim.x) {
+                                                    const int32_t *__restrict__ word_slot, int64_t words,
+                                                    int32_t *__restrict__ slot_row,
+                                                    const int32_t *__restrict__ block_sum, int nblocks,
+                                                    int64_t *__restrict__ counts, const int64_t *unique_src,
+                                                    StreamEdgeTable *__restrict__ table, int budget_cus) {
+  if (blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x < 64)
+      uniq_counts_wave(bitmap, word_slot, words, block_sum, nblocks, num_types, num_src_rows, counts, unique_src, table,
+                       budget_cus);
+    return;
+  }
+  const int64_t stride = (int64_t)(gridDim.x - 1) * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < num_edges; i += stride) {
     const int64_t key = uniq_key(col[i], type_bits, num_types, num_src_rows);
     const int64_t w = key >> 5;
     slot_row[i] = word_slot[w] + __popc(bitmap[w] & ((1u << (key & 31)) - 1u));
@@ -425,7 +439,7 @@ extern "C" int ptgnn_amd_shard_index(const int64_t *const *src_per_type, const i
   if (rc != PTGNN_AMD_OK) return rc;
   k_shard_blocks<<<(unsigned)nblocks, 256, 0, st>>>(bitmap, words, block_sum);
   PTGNN_LAUNCH_CHECK();
-  k_shard_compact<<<(unsigned)nblocks, 256, 0, st>>>(bitmap, words, block_sum, word_slot, need_ids);
+  k_shard_compact<false><<<(unsigned)nblocks, 256, 0, st>>>(bitmap, words, block_sum, word_slot, need_ids, 1, 0);
   PTGNN_LAUNCH_CHECK();
   k_shard_counts<<<1, 64, 0, st>>>(bitmap, word_slot, words, block_sum, nblocks, bounds, world,
                                    (unsigned long long *)stats);
@@ -479,20 +493,15 @@ extern "C" int ptgnn_amd_unique_sources(const int32_t *col, int64_t num_edges, i
   }
   k_uniq_pack<<<(unsigned)nblocks, 256, 0, st>>>(flags, words, bitmap, block_sum);
   PTGNN_LAUNCH_CHECK();
-  k_shard_compact<<<(unsigned)nblocks, 256, 0, st>>>(bitmap, words, block_sum, word_slot, unique_src);
+  k_shard_compact<true><<<(unsigned)nblocks, 256, 0, st>>>(bitmap, words, block_sum, word_slot, unique_src, num_src_rows,
+                                                           capacity);
   PTGNN_LAUNCH_CHECK();
   PTGNN_REQUIRE(!edge_table || num_types <= kStreamMaxTypes, PTGNN_AMD_EUNSUPPORTED,
                 "unique_sources: an edge table holds at most %d edge types", kStreamMaxTypes);
-  k_uniq_counts<<<1, 64, 0, st>>>(bitmap, word_slot, words, block_sum, nblocks, num_types, num_src_rows, counts,
-                                  unique_src, (StreamEdgeTable *)edge_table, edge_table_budget());
+  // remap over the edges + (last workgroup) the counts / launch table: one launch; with no edges only the counts run
+  k_uniq_remap<<<egrid + 1, 256, 0, st>>>(col, num_edges, type_bits, num_types, num_src_rows, bitmap, word_slot, words,
+                                          slot_row, block_sum, nblocks, counts, unique_src,
+                                          (StreamEdgeTable *)edge_table, edge_table_budget());
   PTGNN_LAUNCH_CHECK();
-  if (num_edges > 0) {
-    const int64_t ublocks = (most + 255) / 256;
-    k_uniq_sources<<<(unsigned)(ublocks < 8192 ? ublocks : 8192), 256, 0, st>>>(unique_src, capacity, counts, num_types,
-                                                                                  num_src_rows);
-    PTGNN_LAUNCH_CHECK();
-    k_uniq_remap<<<egrid, 256, 0, st>>>(col, num_edges, type_bits, num_types, num_src_rows, bitmap, word_slot, slot_row);
-    PTGNN_LAUNCH_CHECK();
-  }
   return PTGNN_AMD_OK;
 }
