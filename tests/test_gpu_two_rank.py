@@ -111,3 +111,8 @@ def test_bench_two_ranks_runs_the_sharded_variants_end_to_end():
     assert c4["graph_boundaries"]["ms_per_forward"] > 0
     tg = c4["through_graphs"]
     assert tg["ms_per_forward"] > 0 and not tg["no_cut"] and tg["halo_rows_all_ranks"] > 0
+    # round 4: the split's key figures also sit in `config`, where a SCALE record of the driver reads them
+    lift = res["config"]["dst_range_split"]
+    assert lift["cfg5_shard"]["ms_per_step"] == c5["ms_per_step"] and lift["cfg5_shard"]["all_to_all_ms"] > 0
+    assert lift["cfg4_stack_through_graphs"]["ms_per_forward"] == tg["ms_per_forward"]
+    assert lift["cfg4_stack_graph_boundaries"]["ms_per_forward"] > 0 and lift["collective_backend"] == "gloo"
