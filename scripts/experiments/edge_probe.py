@@ -1,6 +1,9 @@
-"""Time the shared-row / per-edge edge GEMM (fence-free kernel on and off, alternating in ONE process) and the fused GRU
-on the cfg3 batch: HIP events, min and median over interleaved repetitions after a clock-ramping burn.  PTGNN_AMD_LIB
-selects a probe build (scripts/build_variant.sh <tag> stream_gemm.hip -D...).  Run ON THE GPU BOX."""
+"""Time the shared-row / per-edge edge GEMM and the fused GRU on the cfg3 batch: HIP events, min and median over
+interleaved repetitions after a clock-ramping burn.  PTGNN_AMD_LIB selects a probe build (scripts/build_variant.sh <tag>
+stream_gemm.hip -D...).  Run ON THE GPU BOX.
+(The `*_v2` / `*_old` pairs alternated the round-4 fence-free kernel with k_stream_edge through the PTGNN_AMD_EDGE_V2 knob
+of the probe builds of profiles/r04_notes.md section 1; the shipped library ignores the knob -- k_stream_edge_v2 is only
+instantiated for the dropout forms -- so both names time k_stream_edge there.)"""
 import json
 import os
 import sys
