@@ -315,21 +315,54 @@ __device__ __forceinline__ void tq_untranspose(float *tq, int lane, int li, int 
   __builtin_amdgcn_wave_barrier();
 }
 
+// Row stores of the epilogues go out as BUFFER stores (descriptor in SGPRs + a 32-bit byte offset per lane), not as
+// global_store_dwordx4 with a 64-bit address per lane.  Measured under an fp32-MFMA stream (scripts/experiments/
+// vmem_issue_probe.py, profiles/r04_notes.md 7): a wave-wide `global_store_dwordx4` to memory that is not cache-resident
+// costs the issuing wave ~190-210 cycles, the same store as `buffer_store_dwordx4` ~15-30 -- and a unit issues sixteen.
+// The descriptor's base is the unit's first row (wave-uniform) and its size ends with the unit's last VALID row, so the
+// hardware drops the lanes of rows past a type's / the matrix's end: no per-lane condition, no branch around the store.
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_descriptor(float *base /* wave-uniform */, int64_t ld, int64_t rows_left,
+                                                                  int width /* columns the unit writes from `base` */) {
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  const int64_t rows = rows_left < 32 ? rows_left : 32;
+  const int64_t bytes = rows > 0 ? ((rows - 1) * ld + width) * 4 : 0;       // ends behind the last valid row's columns
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(((uint64_t)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
+// (the whole offset travels in the VGPR operand: the hardware range-checks voffset + the immediate against the
+//  descriptor's size and adds the scalar offset AFTER the check, so a row term passed as soffset would escape it)
+__device__ __forceinline__ void store_row4(__amdgpu_buffer_rsrc_t rsrc, int lane_bytes, int uniform_bytes, float4 o) {
+  const u32x4 v = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane_bytes + uniform_bytes, 0, 0);
+}
+
 // one 32 x 32 C block -> y (bias + activation on the way), 4 dwordx4 stores per lane
 template <int ACT>
 __device__ __forceinline__ void store_block_tq(const f32x16 &c, float *tq, float *yblk /* row0, col0 of the block */,
                                                int64_t ld_y, float bv, int64_t rows_left, int lane, int li, int hi) {
+#ifdef PTGNN_GLOBAL_STORES   // A/B (scripts/build_variant.sh): the round-1..3 form, global_store_dwordx4 per lane
   float *yp = yblk + (int64_t)(lane >> 3) * ld_y + (lane & 7) * 4;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float4 o = tq_transpose(tq, lane, li, hi, act_apply<ACT>(c[4 * q] + bv), act_apply<ACT>(c[4 * q + 1] + bv),
                                   act_apply<ACT>(c[4 * q + 2] + bv), act_apply<ACT>(c[4 * q + 3] + bv));
-#ifdef PTGNN_PROBE_NOSTORE   // timing probe only (scripts/build_variant.sh): everything but the global store
-    if (o.x == 12345.678f) *reinterpret_cast<float4 *>(yp + (int64_t)(8 * q) * ld_y) = o;
-#else
     if (8 * q + (lane >> 3) < rows_left) *reinterpret_cast<float4 *>(yp + (int64_t)(8 * q) * ld_y) = o;
-#endif
   }
+#else
+  const __amdgpu_buffer_rsrc_t rsrc = rows_descriptor(yblk, ld_y, rows_left, 32);
+  const int ldb = (int)ld_y * 4;
+  const int lane_bytes = (lane >> 3) * ldb + (lane & 7) * 16;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 o = tq_transpose(tq, lane, li, hi, act_apply<ACT>(c[4 * q] + bv), act_apply<ACT>(c[4 * q + 1] + bv),
+                                  act_apply<ACT>(c[4 * q + 2] + bv), act_apply<ACT>(c[4 * q + 3] + bv));
+    store_row4(rsrc, lane_bytes, 8 * q * ldb, o);
+  }
+#endif
 }
 
 struct LinearArgs {
@@ -481,6 +514,12 @@ __device__ __forceinline__ void gru_epilogue(const GruArgs &p, const f32x16 (&ac
                                              int j0, int lane, int li, int hi, float bir, float biz, float bin,
                                              float bhr, float bhz, float bhn) {
   const int trow = lane >> 3, tcol = (lane & 7) * 4;
+#ifndef PTGNN_GLOBAL_STORES
+  // the unit's output rows (and, in training, its gate rows) through buffer descriptors that end with the last valid row
+  const __amdgpu_buffer_rsrc_t out_rsrc = rows_descriptor(p.out + row0 * p.ld_out + j0, p.ld_out, p.n - row0, 32);
+  const __amdgpu_buffer_rsrc_t gate_rsrc =
+      rows_descriptor(p.gates ? p.gates + row0 * (int64_t)(4 * p.H) + j0 : p.out, 4 * (int64_t)p.H, p.n - row0, 3 * p.H + 32);
+#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     int64_t hrow = row0 + 8 * q + trow;
@@ -502,19 +541,31 @@ __device__ __forceinline__ void gru_epilogue(const GruArgs &p, const f32x16 (&ac
       }
     }
     const float4 o = tq_transpose(tq, lane, li, hi, res[0], res[1], res[2], res[3]);
+#ifdef PTGNN_GLOBAL_STORES
     if (rvalid) *reinterpret_cast<float4 *>(p.out + hrow * p.ld_out + j0 + tcol) = o;
+#else
+    store_row4(out_rsrc, trow * (int)p.ld_out * 4 + tcol * 4, 8 * q * (int)p.ld_out * 4, o);   // rows past n: dropped
+#endif
     if (p.gates) {   // training: r, z, n, gh_n for the backward ([n, 4H], gate-major)
-      float *gp = p.gates + hrow * (int64_t)(4 * p.H) + j0 + tcol;
       const float4 o_r = tq_transpose(tq, lane, li, hi, rg[0], rg[1], rg[2], rg[3]);
       const float4 o_z = tq_transpose(tq, lane, li, hi, zg[0], zg[1], zg[2], zg[3]);
       const float4 o_n = tq_transpose(tq, lane, li, hi, ng[0], ng[1], ng[2], ng[3]);
       const float4 o_h = tq_transpose(tq, lane, li, hi, hn[0], hn[1], hn[2], hn[3]);
+#ifdef PTGNN_GLOBAL_STORES
+      float *gp = p.gates + hrow * (int64_t)(4 * p.H) + j0 + tcol;
       if (rvalid) {
         *reinterpret_cast<float4 *>(gp) = o_r;
         *reinterpret_cast<float4 *>(gp + p.H) = o_z;
         *reinterpret_cast<float4 *>(gp + 2 * p.H) = o_n;
         *reinterpret_cast<float4 *>(gp + 3 * p.H) = o_h;
       }
+#else
+      const int gl = trow * 16 * p.H + tcol * 4, gu = 8 * q * 16 * p.H;       // bytes: lane part, uniform part
+      store_row4(gate_rsrc, gl, gu, o_r);
+      store_row4(gate_rsrc, gl, gu + 4 * p.H, o_z);
+      store_row4(gate_rsrc, gl, gu + 8 * p.H, o_n);
+      store_row4(gate_rsrc, gl, gu + 12 * p.H, o_h);
+#endif
     }
   }
 }
@@ -1216,12 +1267,19 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
         // epilogue: C fragments -> rows through the wave's transposing slab, every store issued
         {
           float *const yp = p.msg + (out_row0 + srow) * p.ld_msg + scol;
+          (void)yp;
+#ifndef PTGNN_GLOBAL_STORES
+          const __amdgpu_buffer_rsrc_t msg_rsrc = rows_descriptor(p.msg + out_row0 * p.ld_msg, p.ld_msg, left, 32 * NB);
+          const int ldb = (int)p.ld_msg * 4;
+#endif
           // column block outer, row group inner (k_stream_edge's order; the other nesting measured 4 % slower)
 #pragma unroll
           for (int n = 0; n < NB; ++n) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+#ifdef PTGNN_GLOBAL_STORES
               float *const yr = 8 * r + srow < left ? yp + (int64_t)(8 * r) * p.ld_msg : sink;
+#endif
               float4 o = tq_transpose(tq, lane, li, hi, acc[n][4 * r], acc[n][4 * r + 1], acc[n][4 * r + 2],
                                       acc[n][4 * r + 3]);
               if constexpr (DROP == 2) {
@@ -1230,7 +1288,11 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
                 o.x = keep_scaled(o.x, m, 0, q.scale); o.y = keep_scaled(o.y, m, 1, q.scale);
                 o.z = keep_scaled(o.z, m, 2, q.scale); o.w = keep_scaled(o.w, m, 3, q.scale);
               }
+#ifdef PTGNN_GLOBAL_STORES
               *reinterpret_cast<float4 *>(yr + n * 32) = o;
+#else
+              store_row4(msg_rsrc, srow * ldb + (scol + n * 32) * 4, 8 * r * ldb, o);   // rows past the type's end: dropped
+#endif
               __builtin_amdgcn_sched_barrier(0);
             }
           }
