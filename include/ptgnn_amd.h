@@ -355,6 +355,24 @@ int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x,
                               int32_t num_types, int32_t msg_dim, int act, float *msg,
                               int64_t ld_msg, void *stream);
 
+/* The same launch with per-edge FEATURE rows behind the gathered halves (layers built with
+ * `edge_feature_dimension` / `features_dimension`): gatedmessagepassing.py:57-61
+ * `edge_transformation_layer(cat([edge_source_states, features], -1))`, mlpmessagepassing.py:90-98
+ * `cat([message_input, features], -1)`, the features coming from graphneuralnetwork.py:162-186:
+ *   msg[off_t + e, :] = act( [ x[src_t[e]] ; x[dst_t[e]] (if dst) ; feat_t[e, :feat_dim] ] W_t^T )
+ * without materialising the [E, state_dim (+ state_dim) + feat_dim] input matrix.
+ *   feat_per_type: HOST array of device pointers, feat_t = [E_t, feat_dim] with row stride ld_feat;
+ *   w_per_type[t]: [msg_dim, state_dim * (dst ? 2 : 1) + feat_dim] row-major contiguous.
+ * Requires feat_dim > 0, feat_dim % 4 == 0, ld_feat % 4 == 0 and 16-byte aligned feature rows (callers zero-pad odd
+ * widths, and the weight columns with them: the padded products are exact zeros) next to the requirements above. */
+int ptgnn_amd_edge_linear_feat_f32(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
+                                   const int64_t *const *src_per_type,
+                                   const int64_t *const *dst_per_type /* nullable */,
+                                   const float *const *feat_per_type, int64_t ld_feat, int32_t feat_dim,
+                                   const int64_t *edges_per_type, const float *const *w_per_type,
+                                   int32_t num_types, int32_t msg_dim, int act, float *msg,
+                                   int64_t ld_msg, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training variants of the per-edge message GEMM (GGNN, gatedmessagepassing.py:57-61:
  * `edge_transformation_layer(self.__dropout(cat([edge_source_states, features])))`).

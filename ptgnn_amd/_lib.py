@@ -53,6 +53,8 @@ SIGNATURES = {
     "ptgnn_amd_batch_offsets_i64": (_c.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _vp, _vp]),
     "ptgnn_amd_edge_linear_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _c.c_int, _vp,
                                              _i64, _vp]),
+    "ptgnn_amd_edge_linear_feat_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32,
+                                                  _c.c_int, _vp, _i64, _vp]),
     "ptgnn_amd_edge_linear_dropout_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i64,
                                                      _c.c_int, _c.c_float, _c.c_uint64, _vp]),
     "ptgnn_amd_dropout_bitmask_bytes": (_c.c_size_t, [_i64, _i32]),

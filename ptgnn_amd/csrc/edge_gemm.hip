@@ -24,6 +24,8 @@
 // Bound: MFMA fp32 for the math; the gather reads E*H*4 bytes of L2/MALL-resident node states.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dense_common.h"
 #include "stream_gemm.h"
 
@@ -41,6 +43,16 @@ struct EdgeTypeTable {
   int32_t num_types;
 };
 
+// FEAT kernels: per-edge feature rows that extend the A operand behind the gathered state halves
+// (gatedmessagepassing.py:57-61 `cat([edge_source_states, features], -1)`, mlpmessagepassing.py:96-98): row e of
+// feat[t] belongs to edge e of type t, F columns (F % 4 == 0; the chunk tail is zeroed on the way into LDS)
+struct EdgeFeat {
+  const float *feat[kMaxTypes];
+  int64_t ld;
+  int F;
+};
+struct NoFeat {};
+
 struct GatherRows {  // tile row r -> node id of edge (e0 + r); rows past the type's end repeat its last edge
   int64_t idx[4];
   // indexed by the staging part (a compile-time constant after unrolling): `idx[row >> 5]` is a
@@ -52,10 +64,11 @@ struct GatherRows {  // tile row r -> node id of edge (e0 + r); rows past the ty
 // 2 = dropout on the OUTPUT rows (training backward: d x_gathered = (d msg . W_t) * mask, with x = d msg
 // read through an identity index and w = W_t^T).  Both index the mask by (global message row, column
 // of the forward input), see DropoutParams.
-template <int ACT, int NJ, int DROP>
+template <int ACT, int NJ, int DROP, bool FEAT = false>
 __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
     EdgeTypeTable tab, const float *__restrict__ x, int64_t ld_x, int64_t num_rows, int H, int use_dst, int n_out,
-    float *__restrict__ msg, int64_t ld_msg, int64_t msg_row_base, int col_tiles, DropoutParams drop) {
+    float *__restrict__ msg, int64_t ld_msg, int64_t msg_row_base, int col_tiles, DropoutParams drop,
+    std::conditional_t<FEAT, EdgeFeat, NoFeat> ef) {
   constexpr int BN = 64 * NJ;
   constexpr int B_FLOATS = BN * LDS_LD;
   constexpr int SLAB_LD = 32 * NJ + 4;
@@ -80,7 +93,9 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
   const int64_t e0 = (int64_t)(etile - tab.tile_off[t]) * 128;
   const int64_t n_edges = tab.edge_off[t + 1] - tab.edge_off[t];   // > 0: empty types own no tiles
   const int64_t out_row0 = msg_row_base + tab.edge_off[t] + e0;
-  const int K = use_dst ? 2 * H : H;
+  const int Hs = use_dst ? 2 * H : H;
+  int K = Hs;                                   // row stride of w = the whole message input
+  if constexpr (FEAT) K += ef.F;
   const float *__restrict__ w = tab.w[t];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -89,10 +104,12 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
 
   // the node ids of this thread's four staging rows, read once per tile
   GatherRows gs, gd;
+  [[maybe_unused]] GatherRows ge;               // FEAT: the edge's own row of the type's feature matrix
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     int64_t e = e0 + (threadIdx.x >> 3) + r * 32;
     e = e < n_edges ? e : n_edges - 1;
+    if constexpr (FEAT) ge.idx[r] = e;
     // ids were range-checked by the plan build (ptgnn_amd_csr_build); clamp anyway so a bad id can never fault
     int64_t si = tab.src[t][e], di = use_dst ? tab.dst[t][e] : 0;
     si = si < 0 ? 0 : (si < num_rows ? si : num_rows - 1);
@@ -113,10 +130,14 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 3)) void k_edge_linear(
   Stager<BN, true, RowClamp> sb;
   const RowClamp rb{col0, n_out};
   const int hchunks = H / BK;               // host guarantees H % 32 == 0
-  const int nchunks = K / BK;
+  const int schunks = Hs / BK;
+  const int nchunks = (K + BK - 1) / BK;    // (K % 32 != 0 only with features: the feature chunks carry the tail)
   auto issue = [&](int c) {
     if (c < hchunks) sa.load(x, ld_x, c * BK, H, gs);
-    else sa.load(x, ld_x, (c - hchunks) * BK, H, gd);
+    else if (!FEAT || c < schunks) sa.load(x, ld_x, (c - hchunks) * BK, H, gd);
+    if constexpr (FEAT) {
+      if (c >= schunks) sa.load(ef.feat[t], ef.ld, (c - schunks) * BK, ef.F, ge);
+    }
     sb.load(w, K, c * BK, K, rb);
   };
   issue(0);
@@ -238,7 +259,8 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
                               const int64_t *edges_per_type, const float *const *w_per_type,
                               int32_t num_types, int32_t msg_dim, int act, float *msg, int64_t ld_msg,
                               int dropout_mode, float dropout_p, uint64_t dropout_seed, void *stream_,
-                              const uint32_t *mask_bits = nullptr) {
+                              const uint32_t *mask_bits = nullptr, const float *const *feat_per_type = nullptr,
+                              int64_t ld_feat = 0, int32_t feat_dim = 0) {
   PTGNN_REQUIRE(num_types >= 0 && state_dim > 0 && msg_dim > 0, PTGNN_AMD_EINVAL, "edge_linear: bad sizes");
   PTGNN_REQUIRE(act >= 0 && act <= PTGNN_AMD_ACT_RELU, PTGNN_AMD_EINVAL, "edge_linear: bad act");
   PTGNN_REQUIRE(state_dim % 32 == 0 && msg_dim % 4 == 0, PTGNN_AMD_EUNSUPPORTED,
@@ -249,6 +271,10 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
   if (dropout_p == 0.f) dropout_mode = 0;
   PTGNN_REQUIRE(dropout_mode == 0 || (act == PTGNN_AMD_ACT_NONE && dst_per_type == nullptr),
                 PTGNN_AMD_EUNSUPPORTED, "edge_linear: dropout needs act none and no target-state half");
+  PTGNN_REQUIRE(feat_dim >= 0 && (feat_dim == 0 || feat_per_type), PTGNN_AMD_EINVAL, "edge_linear: bad feature arguments");
+  PTGNN_REQUIRE(feat_dim == 0 || (feat_dim % 4 == 0 && ld_feat % 4 == 0 && ld_feat >= feat_dim && dropout_mode == 0),
+                PTGNN_AMD_EUNSUPPORTED,
+                "edge_linear: edge features need feat_dim %% 4 == 0, 16-byte aligned rows and no dropout (got %d)", feat_dim);
   if (num_types == 0) return PTGNN_AMD_OK;
   PTGNN_REQUIRE(num_rows > 0, PTGNN_AMD_EINVAL, "edge_linear: num_rows must be positive");
   PTGNN_REQUIRE(x && src_per_type && edges_per_type && w_per_type && msg, PTGNN_AMD_EINVAL,
@@ -272,7 +298,7 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
   const int col_slabs = (msg_dim == 256 && stream_edge_supported(state_dim, 128, use_dst)) ? 2 : 1;
   const int slab_dim = msg_dim / col_slabs;
   bool streaming = (dropout_mode == 0 || mask_bits != nullptr) && stream_edge_supported(state_dim, slab_dim, use_dst) &&
-                   ld_x % 4 == 0 && aligned16(x);
+                   ld_x % 4 == 0 && aligned16(x) && feat_dim == 0;   // (feature rows: the tile kernel's third K phase)
   const int in_dim = use_dst ? 2 * state_dim : state_dim;
   const int mask_words = (dropout_mode == 2 ? msg_dim : state_dim) / 32;   // the mask covers the FORWARD input row
   for (int cs = 0; streaming && cs < col_slabs; ++cs) {
@@ -321,6 +347,8 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
   row_base = 0;
   for (int t0 = 0; t0 < num_types; t0 += kMaxTypes) {
     EdgeTypeTable tab;
+    EdgeFeat ef;
+    ef.ld = ld_feat; ef.F = feat_dim;
     tab.num_types = (num_types - t0 < kMaxTypes) ? (num_types - t0) : kMaxTypes;
     tab.edge_off[0] = 0;
     tab.tile_off[0] = 0;
@@ -332,6 +360,11 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
                     PTGNN_AMD_EINVAL, "edge_linear: null table entry for type %d", t0 + t);
       PTGNN_REQUIRE(n == 0 || aligned16(w_per_type[t0 + t]), PTGNN_AMD_EUNSUPPORTED,
                     "edge_linear: weight of type %d is not 16-byte aligned", t0 + t);
+      if (feat_dim) {
+        PTGNN_REQUIRE(n == 0 || (feat_per_type[t0 + t] && aligned16(feat_per_type[t0 + t])), PTGNN_AMD_EINVAL,
+                      "edge_linear: feature rows of type %d are null or not 16-byte aligned", t0 + t);
+        ef.feat[t] = feat_per_type[t0 + t];
+      }
       tab.src[t] = src_per_type[t0 + t];
       tab.dst[t] = use_dst ? dst_per_type[t0 + t] : nullptr;
       tab.w[t] = w_per_type[t0 + t];
@@ -344,9 +377,22 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
     if (total_tiles > 0) {
       const unsigned grid = (unsigned)xcd_padded_blocks(total_tiles);
 #define PTGNN_EDGE_LAUNCH(ACT, NJ, DROP)                                                            \
-  k_edge_linear<ACT, NJ, DROP><<<grid, 256, 0, st>>>(tab, x, ld_x, num_rows, state_dim, use_dst, msg_dim, msg, \
-                                                     ld_msg, row_base, col_tiles, drop)
-      if (dropout_mode == 1) {
+  k_edge_linear<ACT, NJ, DROP, false><<<grid, 256, 0, st>>>(tab, x, ld_x, num_rows, state_dim, use_dst, msg_dim, msg, \
+                                                            ld_msg, row_base, col_tiles, drop, NoFeat{})
+#define PTGNN_EDGE_LAUNCH_FEAT(ACT, NJ)                                                             \
+  k_edge_linear<ACT, NJ, 0, true><<<grid, 256, 0, st>>>(tab, x, ld_x, num_rows, state_dim, use_dst, msg_dim, msg, \
+                                                        ld_msg, row_base, col_tiles, drop, ef)
+      if (feat_dim) {
+        if (nj == 1) {
+          if (act == PTGNN_AMD_ACT_TANH) PTGNN_EDGE_LAUNCH_FEAT(PTGNN_AMD_ACT_TANH, 1);
+          else if (act == PTGNN_AMD_ACT_RELU) PTGNN_EDGE_LAUNCH_FEAT(PTGNN_AMD_ACT_RELU, 1);
+          else PTGNN_EDGE_LAUNCH_FEAT(PTGNN_AMD_ACT_NONE, 1);
+        } else {
+          if (act == PTGNN_AMD_ACT_TANH) PTGNN_EDGE_LAUNCH_FEAT(PTGNN_AMD_ACT_TANH, 2);
+          else if (act == PTGNN_AMD_ACT_RELU) PTGNN_EDGE_LAUNCH_FEAT(PTGNN_AMD_ACT_RELU, 2);
+          else PTGNN_EDGE_LAUNCH_FEAT(PTGNN_AMD_ACT_NONE, 2);
+        }
+      } else if (dropout_mode == 1) {
         if (nj == 1) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 1, 1); else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 2, 1);
       } else if (dropout_mode == 2) {
         if (nj == 1) PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 1, 2); else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 2, 2);
@@ -360,6 +406,7 @@ static int edge_linear_launch(const float *x, int64_t ld_x, int64_t num_rows, in
         else PTGNN_EDGE_LAUNCH(PTGNN_AMD_ACT_NONE, 2, 0);
       }
 #undef PTGNN_EDGE_LAUNCH
+#undef PTGNN_EDGE_LAUNCH_FEAT
       PTGNN_LAUNCH_CHECK();
       count_launch(PTGNN_AMD_KERNEL_TILE_EDGE);
     }
@@ -377,6 +424,18 @@ extern "C" int ptgnn_amd_edge_linear_f32(const float *x, int64_t ld_x, int64_t n
                                          void *stream_) {
   return edge_linear_launch(x, ld_x, num_rows, state_dim, src_per_type, dst_per_type, edges_per_type, w_per_type,
                             num_types, msg_dim, act, msg, ld_msg, 0, 0.f, 0, stream_);
+}
+
+extern "C" int ptgnn_amd_edge_linear_feat_f32(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,
+                                              const int64_t *const *src_per_type, const int64_t *const *dst_per_type,
+                                              const float *const *feat_per_type, int64_t ld_feat, int32_t feat_dim,
+                                              const int64_t *edges_per_type, const float *const *w_per_type,
+                                              int32_t num_types, int32_t msg_dim, int act, float *msg, int64_t ld_msg,
+                                              void *stream) {
+  PTGNN_REQUIRE(feat_dim > 0, PTGNN_AMD_EINVAL, "edge_linear_feat: feat_dim must be positive (use ptgnn_amd_edge_linear_f32)");
+  return edge_linear_launch(x, ld_x, num_rows, state_dim, src_per_type, dst_per_type, edges_per_type, w_per_type,
+                            num_types, msg_dim, act, msg, ld_msg, 0, 0.f, 0, stream, nullptr, feat_per_type, ld_feat,
+                            feat_dim);
 }
 
 extern "C" int ptgnn_amd_edge_linear_shared_f32(const float *x, int64_t ld_x, int64_t num_rows, int32_t state_dim,

@@ -25,7 +25,9 @@ gradient through the same grouped GEMM + HIP segment-sum) with the GGNN layer's 
 in as a counter-based hash mask; the table form differentiates through `scatter.gather_reduce` (backward
 = the gather-reduce kernel over a backward plan); GRU / Linear blocks are `ptgnn_amd/dense.py` nodes.
 
-Edge features, deeper edge MLPs and custom aggregation modules take the general per-edge path: torch only
+Edge features at inference ride the grouped per-edge GEMM as a third K range of its gathered A rows
+(`ptgnn_amd_edge_linear_feat_f32`; nothing of the reference's [E, H + F] message input exists in memory).
+Edge features in training, deeper edge MLPs and custom aggregation modules take the general per-edge path: torch only
 gathers / concatenates rows, every Linear runs on the HIP GEMM (`ptgnn_amd/dense.py`, any width) and the
 aggregation on the HIP segment-reduce seam with its autograd rule.  fp16 / bf16 node states (AMP) are up-cast
 to fp32 on entry and the result is cast back.  No path runs on the CPU or on a vendor BLAS.
@@ -157,6 +159,19 @@ def _edge_messages(table: torch.Tensor, adjacency_lists, plan, weights):
         if uniq is not None:
             return ops.edge_linear_shared(table, uniq, weights), uniq.slot_row
     return ops.edge_linear(table, adjacency_lists, weights, False), plan.perm
+
+
+def _feat_gemm_ok(node_states, edge_features, state_dim: int, out_dim: int, *params) -> bool:
+    """Inference with per-edge features (graphneuralnetwork.py:162-186 -> gatedmessagepassing.py:57-61 /
+    mlpmessagepassing.py:96-98): the grouped per-edge GEMM reads the feature rows as a third K range of its A operand
+    (ptgnn_amd_edge_linear_feat_f32), so the reference's [E, H (+H) + F] input matrix is never built."""
+    if node_states.dtype != torch.float32 or state_dim % 32 != 0 or out_dim % 4 != 0:
+        return False
+    if any(f is None or f.shape[-1] == 0 or not f.is_cuda for f in edge_features):
+        return False
+    if len({int(f.shape[-1]) for f in edge_features}) != 1:
+        return False
+    return (not torch.is_grad_enabled()) or _no_grad_needed(node_states, *edge_features, *params)
 
 
 def _edge_training_ok(state_dim: int, msg_dim: int) -> bool:
@@ -340,7 +355,16 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
             agg = gather_reduce_autograd(y, None, plan, self._message_dimension, self.__aggregation_fn)
             return dense.gru_cell(gru, agg, node_states)
 
-        # general per-edge path (per-edge dropout / edge features): message order = type-major
+        if (not no_feats and p == 0.0 and self.__aggregation_fn in ops.REDUCE_IDS
+                and _feat_gemm_ok(node_states, edge_features, self.__state_dimension, M, *self.parameters())):
+            # inference with edge features: fused gather of [x[src] | features] inside the grouped GEMM
+            msgs = ops.edge_linear(node_states, adjacency_lists,
+                                   [l.weight for l in self.__edge_message_transformation_layers], False,
+                                   edge_feats=edge_features)
+            agg = ops.gather_reduce(msgs, plan, M, self.__aggregation_fn, type_bits=0, col=plan.perm)
+            return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
+
+        # general per-edge path (per-edge dropout / edge features in training): message order = type-major
         all_messages = []
         for (src, _), feats, lin in zip(adjacency_lists, edge_features,
                                         self.__edge_message_transformation_layers):
@@ -709,6 +733,37 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             ydst = y[:, T * M:] if self.__use_target_state_as_message_input else None
             agg = gather_reduce_autograd(ysrc, ydst, plan, M, self.__aggregation_fn)
             return self._update(agg, False)
+
+        mlps = list(self.__edge_message_transformation_layers)
+        first = [m.linears[0] for m in mlps]
+        if (any(f is not None and f.shape[-1] != 0 for f in edge_features) and all(l.bias is None for l in first)
+                and isinstance(self.__aggregation_fn, str)
+                and _feat_gemm_ok(node_states, edge_features, self.__input_state_dim, first[0].weight.shape[0],
+                                  *self.parameters())
+                and not (self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for e in mlps
+                                               for m in e.modules_in_order))):
+            # inference with edge features: the FIRST Linear of every edge MLP as one grouped GEMM that gathers
+            # [x[src] | x[dst] | features] itself; the rest of the MLP (activation, further Linears) on its [E_t, .] rows
+            plan = ops.plan_for(adjacency_lists, num_nodes)
+            hid = ops.edge_linear(node_states, adjacency_lists, [l.weight for l in first],
+                                  self.__use_target_state_as_message_input, edge_feats=edge_features)
+            if all(m.is_single_linear for m in mlps):
+                messages = hid
+            else:
+                outs, off = [], 0
+                for (src, _), edge_mlp in zip(adjacency_lists, mlps):
+                    n = int(src.shape[0])
+                    mods = edge_mlp.modules_in_order
+                    rest = mods[next(i for i, m in enumerate(mods) if isinstance(m, nn.Linear)) + 1:]
+                    h = hid[off:off + n]
+                    for m in rest:
+                        h = dense.linear(h, m.weight, m.bias) if isinstance(m, nn.Linear) else m(h)
+                    outs.append(h)
+                    off += n
+                messages = torch.cat(outs, dim=0)
+            if self.__aggregation_fn in ops.REDUCE_IDS and messages.shape[1] % 4 == 0:
+                return self._aggregate_and_update(messages, None, plan, col=plan.perm, type_bits=0)
+            return self._update(segment_reduce(messages, plan, self.__aggregation_fn), False)
 
         # general per-edge path
         all_targets, all_messages = [], []

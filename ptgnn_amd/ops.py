@@ -871,12 +871,19 @@ def edge_weight_grad_masked_supported(state_dim: int, msg_dim: int) -> bool:
 
 def edge_linear(x: torch.Tensor, adjacency_lists, weights: Sequence[torch.Tensor], use_dst: bool,
                 act: Optional[str] = None, dropout: Optional[Tuple[int, float, int]] = None,
-                mask_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+                mask_bits: Optional[torch.Tensor] = None,
+                edge_feats: Optional[Sequence[Optional[torch.Tensor]]] = None) -> torch.Tensor:
     """msg[off_t + e] = act([x[src_t[e]] ; x[dst_t[e]] (if use_dst)] W_t^T) for every edge type in one
     launch; rows in type-major message order.  weights[t] is the type's nn.Linear weight.
+    `edge_feats[t]` = [E_t, F] per-edge feature rows appended to the message input (weights [M, H (+H) + F];
+    gatedmessagepassing.py:57-61, mlpmessagepassing.py:96-98) -- see `_edge_linear_feat`.
     dropout = (mode, p, seed): nn.Dropout(p) on the gathered input rows (mode 1) or on the output rows
     (mode 2, the input-gradient form) with the hash mask of ptgnn_amd_edge_linear_dropout_f32; with
     `mask_bits` (`dropout_bitmask` of the same p and seed) the streaming kernel applies the mask from its bits."""
+    if edge_feats is not None and any(f is not None and f.shape[-1] > 0 for f in edge_feats):
+        if dropout is not None and dropout[0] != 0 and dropout[1] > 0.0:
+            raise _lib.PtgnnAmdError("edge_linear: the dropout forms take no edge features")
+        return _edge_linear_feat(x, adjacency_lists, weights, use_dst, act, edge_feats)
     lib = _lib.load()
     _require_cuda_f32("x", x)
     x = _rowmajor(x)
@@ -929,6 +936,55 @@ def edge_linear(x: torch.Tensor, adjacency_lists, weights: Sequence[torch.Tensor
                                            ctypes.cast(wp, ctypes.c_void_p), T, M, ACT_IDS[act],
                                            msg.data_ptr(), M, _stream(msg))
     _lib.check(rc, "ptgnn_amd_edge_linear_f32")
+    return msg[:E] if E > 0 else msg[:0]
+
+
+def _edge_linear_feat(x, adjacency_lists, weights, use_dst: bool, act, edge_feats) -> torch.Tensor:
+    """The grouped per-edge GEMM with feature rows as a third K range of its A operand: nothing of the reference's
+    [E, H (+H) + F] message input is materialised.  Feature widths that are not a multiple of 4 are zero-padded (the
+    [E_t, F] block and the weight's feature columns: exact zeros in the products), so only the small block is copied."""
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    x = _rowmajor(x)
+    T = len(adjacency_lists)
+    H, M = x.shape[1], weights[0].shape[0]
+    Hs = H * (2 if use_dst else 1)
+    counts = [int(a[0].shape[0]) for a in adjacency_lists]
+    E = sum(counts)
+    if len(edge_feats) != T:
+        raise _lib.PtgnnAmdError(f"edge_linear: {len(edge_feats)} feature blocks for {T} edge types")
+    F = max(int(f.shape[-1]) for f in edge_feats if f is not None)
+    F4 = (F + 3) // 4 * 4
+    feats, ws = [], []
+    for t, (f, w, n) in enumerate(zip(edge_feats, weights, counts)):
+        w = w.detach()
+        if tuple(w.shape) != (M, Hs + F) or not w.is_cuda or w.dtype != torch.float32:
+            raise _lib.PtgnnAmdError(f"edge_linear: weight shape {tuple(w.shape)} does not match [{M}, {Hs + F}]")
+        if f is None or tuple(f.shape) != (n, F) or not f.is_cuda:
+            raise _lib.PtgnnAmdError(f"edge_linear: features of type {t} must be a device tensor [{n}, {F}]")
+        f = f.detach().float()
+        if F4 != F:
+            f = torch.nn.functional.pad(f, (0, F4 - F))
+            w = torch.nn.functional.pad(w, (0, F4 - F))
+        feats.append(f.contiguous())
+        ws.append(w.contiguous())
+    msg = torch.empty(max(E, 1), M, dtype=torch.float32, device=x.device)
+    srcs = [a[0].contiguous() for a in adjacency_lists]
+    dsts = [a[1].contiguous() for a in adjacency_lists]
+    PtrArr, CntArr = ctypes.c_void_p * T, ctypes.c_int64 * T
+    sp = PtrArr(*[s.data_ptr() if s.numel() else None for s in srcs])
+    dp = PtrArr(*[d.data_ptr() if d.numel() else None for d in dsts])
+    fp = PtrArr(*[f.data_ptr() if f.numel() else None for f in feats])
+    wp = PtrArr(*[w.data_ptr() for w in ws])
+    cn = CntArr(*counts)
+    K = Hs + F
+    with _timed("edge_linear_feat", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
+        rc = lib.ptgnn_amd_edge_linear_feat_f32(
+            x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),
+            ctypes.cast(dp, ctypes.c_void_p) if use_dst else None, ctypes.cast(fp, ctypes.c_void_p), F4, F4,
+            ctypes.cast(cn, ctypes.c_void_p), ctypes.cast(wp, ctypes.c_void_p), T, M, ACT_IDS[act], msg.data_ptr(), M,
+            _stream(msg))
+    _lib.check(rc, "ptgnn_amd_edge_linear_feat_f32")
     return msg[:E] if E > 0 else msg[:0]
 
 
