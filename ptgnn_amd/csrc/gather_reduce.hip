@@ -71,6 +71,7 @@ struct Args {
   const int32_t *mask_slot;  // MASKED: [E] forward slot of each slot of THIS plan
   int32_t hub_threshold;     // rows with more in-edges are left to the hub kernels (0 = no hub path)
   int32_t long_threshold;    // rows with more in-edges (up to hub_threshold) are left to k_long_rows (0 = none)
+  int32_t hub_blocks;        // leading workgroups of the main launch that walk the hub list (0: a launch of its own does)
   float *hub_part;           // [2 * num_chunks, M] chunk partials
   int32_t *hub_arg;          // [2 * num_chunks, M] (argout only)
   int32_t *hub_tickets;      // [num_chunks * col_blocks] arrival counters, zero between launches
@@ -385,12 +386,121 @@ struct RowOp {
 };
 
 // ------------------------------------------------------------------------------------------------
+// hub kernel: workgroups walk the plan's (chunk, hub row) list
+// ------------------------------------------------------------------------------------------------
+#ifndef PTGNN_HUB_FUSED_BLOCKS
+#define PTGNN_HUB_FUSED_BLOCKS 32      // A/B knob (scripts/build_variant.sh): 0 = the hub launch of its own everywhere
+#endif
+template <int CH, bool HAS_DST, bool HAS_ARG, bool MASKED>
+constexpr bool hub_fuses() { return PTGNN_HUB_FUSED_BLOCKS > 0 && CH == 1 && !HAS_DST && !HAS_ARG && !MASKED; }
+
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED, bool FUSED = false>
+__device__ __forceinline__ void hub_chunks_body(const Args &a, int first, int stride) {
+  using Op = RowOp<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED>;
+  constexpr int G = 256 / LPR;          // lane groups per workgroup
+  constexpr int W = LPR * VEC * CH;     // columns per column block
+  __shared__ float pv[G * W];
+  __shared__ int pa[HAS_ARG ? G * W : 1];
+
+  const int count = *a.hub_count;
+  const int grp = threadIdx.x / LPR, g = threadIdx.x % LPR;
+  const int cbase = blockIdx.y * W;
+  const int64_t num_chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;
+#pragma unroll 1
+  for (int e = first; e < count; e += stride) {
+    const int64_t chunk = a.hub_entries[2 * e];
+    const int64_t row = a.hub_entries[2 * e + 1];
+    const int64_t cbeg = chunk * kHubChunk;
+    const int64_t cend = (cbeg + kHubChunk < a.num_edges) ? cbeg + kHubChunk : a.num_edges;
+    const int rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
+    const int sbeg = (int)(rbeg > cbeg ? rbeg : cbeg), send = (int)(rend < cend ? rend : cend);
+    // partial slot of this (chunk, row): 0 if the hub owns the chunk's first slot, else 1
+    const int which = rbeg <= cbeg ? 0 : 1;
+    Op op(a, g, cbase);
+    // the chunk's slots are interleaved over the lane groups (stride G); same prefetched groups of 8 as the main kernel
+    constexpr int UP = (VEC == 4 && !MASKED && !HAS_DST && CH == 1) ? (FUSED ? 4 : 8) : 0;
+    if constexpr (UP == 0) op.reduce(row, sbeg + grp, send, G);
+    else op.template reduce_pf<UP>(row, sbeg + grp, send, G);
+    __syncthreads();  // the previous entry's readers are done with the staging arrays
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        pv[grp * W + (g + c * LPR) * VEC + v] = op.acc[c][v];
+        if (HAS_ARG) pa[grp * W + (g + c * LPR) * VEC + v] = op.arg[c][v];
+      }
+    __syncthreads();
+    if (grp != 0) continue;           // group 0 (part of wave 0) finishes the entry
+    for (int q = 1; q < G; ++q) {     // fixed combine order => deterministic
+      float m[CH][VEC];
+      int ma[CH][VEC];
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          m[c][v] = pv[q * W + (g + c * LPR) * VEC + v];
+          ma[c][v] = HAS_ARG ? pa[q * W + (g + c * LPR) * VEC + v] : -1;
+        }
+      op.fold_partial(m, ma);
+    }
+    const int64_t c_first = rbeg / kHubChunk, c_last = (rend - 1) / kHubChunk;
+    op.store(a.hub_part + (2 * chunk + which) * (int64_t)a.msg_dim,
+             HAS_ARG ? a.hub_arg + (2 * chunk + which) * (int64_t)a.msg_dim : nullptr);
+    // publish: every storing lane releases at agent scope, then ONE lane takes a ticket
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int32_t *ticket = a.hub_tickets + (int64_t)blockIdx.y * num_chunks + c_first;
+    int arrived = 0;
+    if (g == 0) arrived = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrived = __shfl(arrived, 0, LPR);
+    if (arrived != (int)(c_last - c_first)) continue;   // not the last chunk of this hub
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1 lines before reading partials
+    if (g == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-clean
+    Op fin(a, g, cbase);
+    // chunk partials fold in chunk order, fetched FB at a time (a 150 k-edge hub has ~150 of them: loaded one by
+    // one, this fold was most of the hub launch on the cfg5 shard)
+    // (FUSED: inside the main kernel the body must fit ITS register budget -- minibatch-sized plans, short hub lists)
+    constexpr int FB = FUSED ? 2 : ((HAS_ARG || CH > 1) ? 4 : 8);
+    for (int64_t c0 = c_first; c0 <= c_last; c0 += FB) {
+      float m[FB][CH][VEC];
+      int ma[FB][CH][VEC];
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int64_t c = c0 + u <= c_last ? c0 + u : c_last;
+        const int w2 = (c > c_first || rbeg == (int)(c_first * kHubChunk)) ? 0 : 1;
+        fin.load_partial(a.hub_part + (2 * c + w2) * (int64_t)a.msg_dim,
+                         HAS_ARG ? a.hub_arg + (2 * c + w2) * (int64_t)a.msg_dim : nullptr, m[u], ma[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < FB; ++u)
+        if (c0 + u <= c_last) fin.fold_partial(m[u], ma[u]);
+    }
+    fin.finish_and_store(row, rend - rbeg);
+  }
+}
+
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED>
+__global__ __launch_bounds__(256) void k_hub_chunks(Args a) {
+  hub_chunks_body<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------
 // main kernel: one row per lane group
 // ------------------------------------------------------------------------------------------------
 template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED, bool DST1 = false>
 __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
   constexpr int ROWS_PER_BLOCK = 256 / LPR;
-  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  // the first `hub_blocks` workgroups (a multiple of 8: the XCD mapping of the row tiles is unchanged) walk the plan's
+  // hub list instead of row tiles -- on a minibatch-sized plan the list is almost always empty and they leave at once,
+  // where a hub launch of its own behind this one cost ~4.6 us of dependent launch latency per aggregation
+  // (only the variants whose register budget -- 8 / 7 waves per SIMD -- the hub body fits: plain rows, one column chunk)
+  if constexpr (hub_fuses<CH, HAS_DST, HAS_ARG, MASKED>()) {
+    if ((int)blockIdx.x < a.hub_blocks) {
+      hub_chunks_body<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED, true>(a, (int)blockIdx.x, a.hub_blocks);
+      return;
+    }
+  }
+  const int64_t tile = xcd_swizzle(blockIdx.x - a.hub_blocks, gridDim.x - a.hub_blocks);
   if (tile >= a.num_tiles) return;
   const int64_t row = tile * ROWS_PER_BLOCK + threadIdx.x / LPR;
   if (row >= a.num_nodes) return;  // whole lane-group exits together (no cross-group shuffles)
@@ -441,93 +551,6 @@ __global__ __launch_bounds__(256) void k_long_rows(Args a) {
         op.finish_and_store(base + b, rdeg);
       }
     }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// hub kernel: workgroups walk the plan's (chunk, hub row) list
-// ------------------------------------------------------------------------------------------------
-template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED>
-__global__ __launch_bounds__(256) void k_hub_chunks(Args a) {
-  using Op = RowOp<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED>;
-  constexpr int G = 256 / LPR;          // lane groups per workgroup
-  constexpr int W = LPR * VEC * CH;     // columns per column block
-  __shared__ float pv[G * W];
-  __shared__ int pa[HAS_ARG ? G * W : 1];
-
-  const int count = *a.hub_count;
-  const int grp = threadIdx.x / LPR, g = threadIdx.x % LPR;
-  const int cbase = blockIdx.y * W;
-  const int64_t num_chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;
-#pragma unroll 1
-  for (int e = blockIdx.x; e < count; e += gridDim.x) {
-    const int64_t chunk = a.hub_entries[2 * e];
-    const int64_t row = a.hub_entries[2 * e + 1];
-    const int64_t cbeg = chunk * kHubChunk;
-    const int64_t cend = (cbeg + kHubChunk < a.num_edges) ? cbeg + kHubChunk : a.num_edges;
-    const int rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
-    const int sbeg = (int)(rbeg > cbeg ? rbeg : cbeg), send = (int)(rend < cend ? rend : cend);
-    // partial slot of this (chunk, row): 0 if the hub owns the chunk's first slot, else 1
-    const int which = rbeg <= cbeg ? 0 : 1;
-    Op op(a, g, cbase);
-    // the chunk's slots are interleaved over the lane groups (stride G); same prefetched groups of 8 as the main kernel
-    constexpr int UP = (VEC == 4 && !MASKED && !HAS_DST && CH == 1) ? 8 : 0;
-    if constexpr (UP == 0) op.reduce(row, sbeg + grp, send, G);
-    else op.template reduce_pf<UP>(row, sbeg + grp, send, G);
-    __syncthreads();  // the previous entry's readers are done with the staging arrays
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        pv[grp * W + (g + c * LPR) * VEC + v] = op.acc[c][v];
-        if (HAS_ARG) pa[grp * W + (g + c * LPR) * VEC + v] = op.arg[c][v];
-      }
-    __syncthreads();
-    if (grp != 0) continue;           // group 0 (part of wave 0) finishes the entry
-    for (int q = 1; q < G; ++q) {     // fixed combine order => deterministic
-      float m[CH][VEC];
-      int ma[CH][VEC];
-#pragma unroll
-      for (int c = 0; c < CH; ++c)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          m[c][v] = pv[q * W + (g + c * LPR) * VEC + v];
-          ma[c][v] = HAS_ARG ? pa[q * W + (g + c * LPR) * VEC + v] : -1;
-        }
-      op.fold_partial(m, ma);
-    }
-    const int64_t c_first = rbeg / kHubChunk, c_last = (rend - 1) / kHubChunk;
-    op.store(a.hub_part + (2 * chunk + which) * (int64_t)a.msg_dim,
-             HAS_ARG ? a.hub_arg + (2 * chunk + which) * (int64_t)a.msg_dim : nullptr);
-    // publish: every storing lane releases at agent scope, then ONE lane takes a ticket
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int32_t *ticket = a.hub_tickets + (int64_t)blockIdx.y * num_chunks + c_first;
-    int arrived = 0;
-    if (g == 0) arrived = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    arrived = __shfl(arrived, 0, LPR);
-    if (arrived != (int)(c_last - c_first)) continue;   // not the last chunk of this hub
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1 lines before reading partials
-    if (g == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-clean
-    Op fin(a, g, cbase);
-    // chunk partials fold in chunk order, fetched FB at a time (a 150 k-edge hub has ~150 of them: loaded one by
-    // one, this fold was most of the hub launch on the cfg5 shard)
-    constexpr int FB = (HAS_ARG || CH > 1) ? 4 : 8;
-    for (int64_t c0 = c_first; c0 <= c_last; c0 += FB) {
-      float m[FB][CH][VEC];
-      int ma[FB][CH][VEC];
-#pragma unroll
-      for (int u = 0; u < FB; ++u) {
-        const int64_t c = c0 + u <= c_last ? c0 + u : c_last;
-        const int w2 = (c > c_first || rbeg == (int)(c_first * kHubChunk)) ? 0 : 1;
-        fin.load_partial(a.hub_part + (2 * c + w2) * (int64_t)a.msg_dim,
-                         HAS_ARG ? a.hub_arg + (2 * c + w2) * (int64_t)a.msg_dim : nullptr, m[u], ma[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < FB; ++u)
-        if (c0 + u <= c_last) fin.fold_partial(m[u], ma[u]);
-    }
-    fin.finish_and_store(row, rend - rbeg);
   }
 }
 
@@ -596,7 +619,7 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
   constexpr int ROWS_PER_BLOCK = 256 / LPR;
   Args a = a0;
   a.num_tiles = (a.num_nodes + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  dim3 grid((unsigned)xcd_padded_blocks(a.num_tiles), (unsigned)col_blocks);
+  a.hub_blocks = 0;
   SideStream *side = nullptr;
   // large plans only: on a minibatch-sized graph the launches are ~0.1 ms, have no tail worth hiding, and the
   // fork / join events cost more than they save (measured on cfg3: +20 us per aggregation)
@@ -635,6 +658,12 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
       }
     }
   }
+  constexpr bool kFuseHub = hub_fuses<CH, HAS_DST, HAS_ARG, MASKED>();
+  if (kFuseHub && !side && a.hub_threshold > 0) {   // no side stream: the first workgroups of the main launch walk the hub list
+    const int64_t chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;
+    a.hub_blocks = (int)(((chunks < PTGNN_HUB_FUSED_BLOCKS ? chunks : PTGNN_HUB_FUSED_BLOCKS) + 7) / 8 * 8);
+  }
+  dim3 grid((unsigned)(xcd_padded_blocks(a.num_tiles) + a.hub_blocks), (unsigned)col_blocks);
   // one edge type (type_bits == 0): the destination term of a row is one row -> the DST1 variant loads it once
   constexpr bool kDst1Variant = VEC == 4 && HAS_DST && !MASKED;
   if (kDst1Variant && a.type_bits == 0)
@@ -647,7 +676,7 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
     if (long_launch) PTGNN_HIP(hipStreamWaitEvent(stream, side->join2, 0));
     return PTGNN_AMD_OK;
   }
-  if (a.hub_threshold > 0) {
+  if (!kFuseHub && a.hub_threshold > 0) {
     // the list length lives on the device: a fixed grid strides over it (zero entries => instant exit)
     int64_t chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;
     dim3 hgrid((unsigned)(chunks < 1024 ? chunks : 1024), (unsigned)col_blocks);
