@@ -671,7 +671,11 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
         if self._dense is not None:
             if _no_grad_needed(x, *self._dense.parameters()):
                 tanh = isinstance(self._dense_act, nn.Tanh)
-                x = ops.linear(x, self._dense.weight, self._dense.bias, act="tanh" if tanh else None)
+                hint = None
+                if (tanh or self._dense_act is None) and not (self.training and getattr(self._dropout, "p", 0.0) > 0):
+                    # nothing follows the GEMM: it may write straight into the right half of a concat residual's result
+                    hint = _take_output_hint(x.shape[0], self._dense.out_features, x)
+                x = ops.linear(x, self._dense.weight, self._dense.bias, act="tanh" if tanh else None, out=hint)
                 if self._dense_act is not None and not tanh:
                     x = self._dense_act(x)
             else:

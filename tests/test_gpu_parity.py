@@ -717,6 +717,35 @@ def test_config4_varmisuse_mlp_stack_vs_oracle():
     assert err <= 8 * TOL, f"max |delta| after 8 MLP-MP layers = {err:.3e} (ours vs fp64 {err_ours:.3e}, " \
                            f"oracle vs fp64 {err_ref:.3e})"
     print(f"cfg4: ours-vs-oracle {err:.2e}, ours-vs-fp64 {err_ours:.2e}, oracle-vs-fp64 {err_ref:.2e}")
+    # the container hands the layer in front of a concat residual the right half of the residual's result to write
+    # into (GRU of a GGNN layer, the dense update of an MLP-MP layer): same bits as the module-by-module loop, whose
+    # residuals torch.cat -- and no torch.cat inside the container's loop
+    from ptgnn_amd import ops
+    cadj = to_cuda_adj(mb["adjacency_lists"])
+    cadj = cadj + [(d, s_) for s_, d in cadj]
+    ar = torch.arange(N, device="cuda")
+    cadj.append((ar, ar))
+    feats = [None] * len(cadj)
+    n2g = mb["node_to_graph_idx"].cuda()
+    with torch.no_grad(), L.forward_scope():
+        h = x.cuda()
+        for m in net.message_passing_layers:
+            h = m(h, cadj, n2g, {}, {}, feats)
+    cats = []
+    real_cat = torch.cat
+    try:
+        def counting_cat(tensors, *a, **k):     # (weight stacks may be cat-ed; node-state matrices may not)
+            if len(tensors) and tensors[0].dim() == 2 and tensors[0].shape[0] == N:
+                cats.append(1)
+            return real_cat(tensors, *a, **k)
+        torch.cat = counting_cat
+        ops.clear_plan_cache()
+        with torch.no_grad():
+            via_container = net.gnn(x.cuda(), cadj, feats, n2g, {}, {})
+    finally:
+        torch.cat = real_cat
+    assert torch.equal(via_container, h) and torch.equal(via_container.cpu(), got)
+    assert not cats, "a concat residual fell back to torch.cat inside the container"
 
 
 @pytest.mark.parametrize("kind", ["ggnn", "mlp"])
