@@ -333,10 +333,14 @@ __device__ __forceinline__ void uniq_counts_wave(const uint32_t *__restrict__ bi
     table->unit_off[lane] = unit_incl - units;
     table->wg_off[lane] = wg_incl - w;
   }
+  if (lane >= num_types) {   // every prefix entry past the last type holds the totals: the GEMM kernel fetches the arrays one
+    table->unit_off[lane] = total_units;   // entry per lane and searches them with a ballot, without knowing num_types
+    table->wg_off[lane] = sum;
+  }
   if (lane == 0) {
     table->edge_off[num_types] = total;
-    table->unit_off[num_types] = total_units;
-    table->wg_off[num_types] = sum;
+    table->unit_off[kStreamMaxTypes] = total_units;
+    table->wg_off[kStreamMaxTypes] = sum;
     table->num_types = num_types;
   }
 }

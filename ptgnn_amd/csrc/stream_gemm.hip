@@ -209,6 +209,36 @@ struct Slab {
   }
 };
 
+// Slab fill: `src(r, q)` = global address of the float4 `q` of slab row `r` (always loadable), `live(r)` = whether the
+// row is real (else zeros).  The loads of a batch of 8 are ALL issued before the first LDS store: written as one load ->
+// store per iteration the compiler waits for every float4 at once, and the fill is 8-18 dependent L2 round trips --
+// 4-9 us of every launch, most of the kernels' size-independent cost (profiles/r04_notes.md 9).
+template <bool SPLIT, int NT, typename SrcFn, typename LiveFn>
+__device__ __forceinline__ void fill_slab(float *smem, const Slab<SPLIT> &sl, int rows, int kq, SrcFn src, LiveFn live) {
+  constexpr int UB = 8;
+  const int total = rows * kq;
+  for (int i0 = threadIdx.x; i0 < total; i0 += NT * UB) {
+    float4 v[UB];
+    int rr[UB], qq[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int i = i0 + u * NT;
+      const int ic = i < total ? i : total - 1;
+      rr[u] = ic / kq;
+      qq[u] = ic - rr[u] * kq;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      v[u] = *reinterpret_cast<const float4 *>(src(rr[u], qq[u]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (i0 + u * NT < total) sl.put4(smem, rr[u], qq[u] * 4, live(rr[u]) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  }
+}
+
 // K loop of one unit: chunks [0, ch0) are phase 0, [ch0, nch) phase 1; a0/a1 hold chunks 0/1 on entry
 // and the next unit's chunks 0/1 on exit.  ch0 and nch are even.
 template <int NBLK, int NACC, bool GRU, bool SPLIT>
@@ -441,15 +471,12 @@ __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
   float *const tq = smem + p.lds_floats + 4 + (threadIdx.x >> 6) * kTqFloats;   // this wave's transposing slab
   if (threadIdx.x == 0) *counter = 0;
   const int col_base = slab * BN;
-  {
-    const int kq = p.K >> 2;
-    for (int i = threadIdx.x; i < BN * kq; i += NT) {
-      const int r = i / kq, k = (i - r * kq) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (col_base + r < p.n_out) v = *reinterpret_cast<const float4 *>(p.w + (int64_t)(col_base + r) * p.K + k);
-      sl.put4(smem, r, k, v);
-    }
-  }
+  fill_slab<SPLIT, NT>(smem, sl, BN, p.K >> 2,
+                       [&](int r, int q) {
+                         const int wr = col_base + r < p.n_out ? col_base + r : p.n_out - 1;
+                         return p.w + (int64_t)wr * p.K + q * 4;
+                       },
+                       [&](int r) { return col_base + r < p.n_out; });
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -596,14 +623,14 @@ __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
   if (threadIdx.x == 0) *counter = 0;
   const int j0 = slab * 32;
   {
-    const int kq = K >> 2, mq = p.M >> 2;
-    for (int i = threadIdx.x; i < 96 * kq; i += NT) {
-      const int r = i / kq, q = i - r * kq;
-      const int gate = r >> 5, jj = j0 + (r & 31);   // H % 32 == 0: always a valid feature
-      const float *src = q < mq ? p.w_ih + ((int64_t)gate * p.H + jj) * p.M + q * 4
-                                : p.w_hh + ((int64_t)gate * p.H + jj) * p.H + (q - mq) * 4;
-      sl.put4(smem, r, q * 4, *reinterpret_cast<const float4 *>(src));
-    }
+    const int mq = p.M >> 2;
+    fill_slab<SPLIT, NT>(smem, sl, 96, K >> 2,
+                         [&](int r, int q) {
+                           const int gate = r >> 5, jj = j0 + (r & 31);   // H % 32 == 0: always a valid feature
+                           return q < mq ? p.w_ih + ((int64_t)gate * p.H + jj) * p.M + q * 4
+                                         : p.w_hh + ((int64_t)gate * p.H + jj) * p.H + (q - mq) * 4;
+                         },
+                         [](int) { return true; });
   }
   __syncthreads();
 
@@ -908,14 +935,33 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
   const StreamEdgeTable *tabp;
   if constexpr (INDIRECT) tabp = p.tab_dev; else tabp = &p.tab;
   const StreamEdgeTable &tab = *tabp;
+  // INDIRECT: the two prefix arrays of the device-resident table are fetched ONCE, one entry per lane (the writer fills all
+  // 65 entries, those past num_types with the totals), and searched with a ballot: a binary search over device memory
+  // is five dependent L2 round trips, twice, in front of every launch's first MFMA (profiles/r04_notes.md 9)
+  [[maybe_unused]] int v_wg = 0, v_unit = 0, wg_total = 0, unit_total = 0;
   if constexpr (INDIRECT) {
-    if ((int)blockIdx.x >= tab.wg_off[tab.num_types]) return;   // the launch is sized for the largest apportioning
+    const int l = threadIdx.x & 63;
+    v_wg = tab.wg_off[l];
+    v_unit = tab.unit_off[l];
+    wg_total = tab.wg_off[kStreamMaxTypes];
+    unit_total = tab.unit_off[kStreamMaxTypes];
+    if ((int)blockIdx.x >= wg_total) return;   // the launch is sized for the largest apportioning
   }
+  auto entry = [&](int v, int total, int i) {   // prefix entry i (uniform) out of the per-lane copy
+    return i >= kStreamMaxTypes ? total : __builtin_amdgcn_readlane(v, i);
+  };
   // Workgroups are apportioned to edge types in proportion to their units, and a type's units are split evenly
   // over its workgroups: no run crosses a type boundary (a mid-run slab reload + barrier made the ~T affected
   // workgroups the stragglers that set the kernel time).
   int u, u_end;
-  {
+  if constexpr (INDIRECT) {
+    const int lo = __popcll(__ballot(v_wg <= (int)blockIdx.x)) - 1;     // last type whose first workgroup is <= this one
+    const int wg0 = entry(v_wg, wg_total, lo), u0 = entry(v_unit, unit_total, lo);
+    const int64_t w = entry(v_wg, wg_total, lo + 1) - wg0, part = (int)blockIdx.x - wg0;
+    const int64_t units = entry(v_unit, unit_total, lo + 1) - u0;
+    u = u0 + (int)(part * units / w);
+    u_end = u0 + (int)((part + 1) * units / w);
+  } else {
     int lo = 0, hi_t = tab.num_types;
     while (hi_t - lo > 1) {
       const int mid = (lo + hi_t) >> 1;
@@ -937,14 +983,23 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
   const int lofs = lane_piece_offset<SPLIT>(hi);
 
   while (u < u_end) {
-    int lo = 0, hi_t = tab.num_types;   // edge type of unit u (table lives in SGPRs)
-    while (hi_t - lo > 1) {
-      const int mid = (lo + hi_t) >> 1;
-      if (tab.unit_off[mid] <= u) lo = mid; else hi_t = mid;
+    int t, t_u0, t_u1;                  // edge type of unit u and the type's unit range
+    if constexpr (INDIRECT) {
+      t = __popcll(__ballot(v_unit <= u)) - 1;
+      t_u0 = entry(v_unit, unit_total, t);
+      t_u1 = entry(v_unit, unit_total, t + 1);
+    } else {
+      int lo = 0, hi_t = tab.num_types;   // (table lives in SGPRs)
+      while (hi_t - lo > 1) {
+        const int mid = (lo + hi_t) >> 1;
+        if (tab.unit_off[mid] <= u) lo = mid; else hi_t = mid;
+      }
+      t = lo;
+      t_u0 = tab.unit_off[t];
+      t_u1 = tab.unit_off[t + 1];
     }
-    const int t = lo;
-    const int seg_end = tab.unit_off[t + 1] < u_end ? tab.unit_off[t + 1] : u_end;
-    const int ub = u - tab.unit_off[t];             // first unit of the segment inside the type
+    const int seg_end = t_u1 < u_end ? t_u1 : u_end;
+    const int ub = u - t_u0;                        // first unit of the segment inside the type
     const int count = seg_end - u;
     // every table field the unit loop needs is read HERE: with the table in device memory (INDIRECT) a read inside the
     // loop -- after the kernel's own stores -- cannot be proven unclobbered, becomes a vector load whose result is needed
@@ -965,13 +1020,9 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
     if (threadIdx.x == 0) *counter = 0;
     {
       const float *w = p.tab.w[t];
-      const int kq = K >> 2;
-      for (int i = threadIdx.x; i < BN * kq; i += NT) {
-        const int r = i / kq, k = (i - r * kq) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < p.M) v = *reinterpret_cast<const float4 *>(w + (int64_t)r * K + k);
-        sl.put4(smem, r, k, v);
-      }
+      fill_slab<SPLIT, NT>(smem, sl, BN, K >> 2,
+                           [&](int r, int q) { return w + (int64_t)(r < p.M ? r : p.M - 1) * K + q * 4; },
+                           [&](int r) { return r < p.M; });
     }
     __syncthreads();
 
@@ -1166,11 +1217,8 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
     if (threadIdx.x == 0) *counter = 0;
     {
       const float *w = p.tab.w[t];
-      constexpr int kq = K >> 2;
-      for (int i = threadIdx.x; i < BN * kq; i += NT) {
-        const int r = i / kq, k = (i - r * kq) * 4;
-        sl.put4(smem, r, k, *reinterpret_cast<const float4 *>(w + (int64_t)r * K + k));
-      }
+      fill_slab<false, NT>(smem, sl, BN, K >> 2, [&](int r, int q) { return w + (int64_t)r * K + q * 4; },
+                           [](int) { return true; });
     }
     __syncthreads();
 
