@@ -908,6 +908,36 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void k_stream_linear_ring(Linea
 // grouped per-edge GEMM: unit = 32 edges of one type; flat balanced runs over the type-major unit order;
 // a run reloads the slab (W_t) when it crosses into the next edge type.
 // ---------------------------------------------------------------------------------------------------
+// The two prefix arrays of an edge table (65 entries each, those past num_types hold the totals), one entry per lane,
+// searched with a ballot; single entries come back through v_readlane.
+struct TablePrefixes {
+  int v_wg, v_unit, wg_total, unit_total;
+  __device__ __forceinline__ explicit TablePrefixes(const StreamEdgeTable &tab) {
+    const int l = threadIdx.x & 63;
+    v_wg = tab.wg_off[l];
+    v_unit = tab.unit_off[l];
+    wg_total = tab.wg_off[kStreamMaxTypes];
+    unit_total = tab.unit_off[kStreamMaxTypes];
+  }
+  __device__ __forceinline__ static int entry(int v, int total, int i) {   // prefix entry i (wave-uniform)
+    return i >= kStreamMaxTypes ? total : __builtin_amdgcn_readlane(v, i);
+  }
+  // units [u, u_end) of workgroup `wg`: its share of the units of the type that owns it
+  __device__ __forceinline__ void run_of_workgroup(int wg, int &u, int &u_end) const {
+    const int lo = __popcll(__ballot(v_wg <= wg)) - 1;     // last type whose first workgroup is <= this one
+    const int wg0 = entry(v_wg, wg_total, lo), u0 = entry(v_unit, unit_total, lo);
+    const int64_t w = entry(v_wg, wg_total, lo + 1) - wg0, part = wg - wg0;
+    const int64_t units = entry(v_unit, unit_total, lo + 1) - u0;
+    u = u0 + (int)(part * units / w);
+    u_end = u0 + (int)((part + 1) * units / w);
+  }
+  __device__ __forceinline__ void type_of_unit(int u, int &t, int &u0, int &u1) const {
+    t = __popcll(__ballot(v_unit <= u)) - 1;
+    u0 = entry(v_unit, unit_total, t);
+    u1 = entry(v_unit, unit_total, t + 1);
+  }
+};
+
 struct EdgeArgs {
   StreamEdgeTable tab;
   const StreamEdgeTable *tab_dev;   // INDIRECT kernels: the table in device memory (tab then only carries w / num_types)
@@ -938,40 +968,17 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
   // INDIRECT: the two prefix arrays of the device-resident table are fetched ONCE, one entry per lane (the writer fills all
   // 65 entries, those past num_types with the totals), and searched with a ballot: a binary search over device memory
   // is five dependent L2 round trips, twice, in front of every launch's first MFMA (profiles/r04_notes.md 9)
-  [[maybe_unused]] int v_wg = 0, v_unit = 0, wg_total = 0, unit_total = 0;
+  // (the by-value table of the kernel arguments is searched the same way: its binary searches were ten dependent scalar
+  //  loads; stream_edge() fills the entries past num_types like the device-side writer)
+  const TablePrefixes tp(tab);
   if constexpr (INDIRECT) {
-    const int l = threadIdx.x & 63;
-    v_wg = tab.wg_off[l];
-    v_unit = tab.unit_off[l];
-    wg_total = tab.wg_off[kStreamMaxTypes];
-    unit_total = tab.unit_off[kStreamMaxTypes];
-    if ((int)blockIdx.x >= wg_total) return;   // the launch is sized for the largest apportioning
+    if ((int)blockIdx.x >= tp.wg_total) return;   // the launch is sized for the largest apportioning
   }
-  auto entry = [&](int v, int total, int i) {   // prefix entry i (uniform) out of the per-lane copy
-    return i >= kStreamMaxTypes ? total : __builtin_amdgcn_readlane(v, i);
-  };
   // Workgroups are apportioned to edge types in proportion to their units, and a type's units are split evenly
   // over its workgroups: no run crosses a type boundary (a mid-run slab reload + barrier made the ~T affected
   // workgroups the stragglers that set the kernel time).
   int u, u_end;
-  if constexpr (INDIRECT) {
-    const int lo = __popcll(__ballot(v_wg <= (int)blockIdx.x)) - 1;     // last type whose first workgroup is <= this one
-    const int wg0 = entry(v_wg, wg_total, lo), u0 = entry(v_unit, unit_total, lo);
-    const int64_t w = entry(v_wg, wg_total, lo + 1) - wg0, part = (int)blockIdx.x - wg0;
-    const int64_t units = entry(v_unit, unit_total, lo + 1) - u0;
-    u = u0 + (int)(part * units / w);
-    u_end = u0 + (int)((part + 1) * units / w);
-  } else {
-    int lo = 0, hi_t = tab.num_types;
-    while (hi_t - lo > 1) {
-      const int mid = (lo + hi_t) >> 1;
-      if (tab.wg_off[mid] <= (int)blockIdx.x) lo = mid; else hi_t = mid;
-    }
-    const int64_t w = tab.wg_off[lo + 1] - tab.wg_off[lo], part = (int)blockIdx.x - tab.wg_off[lo];
-    const int64_t units = tab.unit_off[lo + 1] - tab.unit_off[lo];
-    u = tab.unit_off[lo] + (int)(part * units / w);
-    u_end = tab.unit_off[lo] + (int)((part + 1) * units / w);
-  }
+  tp.run_of_workgroup((int)blockIdx.x, u, u_end);
   if (u >= u_end) return;
   const int K = p.use_dst ? 2 * p.H : p.H;
   const Slab<SPLIT> sl(K, BN);
@@ -984,20 +991,7 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
 
   while (u < u_end) {
     int t, t_u0, t_u1;                  // edge type of unit u and the type's unit range
-    if constexpr (INDIRECT) {
-      t = __popcll(__ballot(v_unit <= u)) - 1;
-      t_u0 = entry(v_unit, unit_total, t);
-      t_u1 = entry(v_unit, unit_total, t + 1);
-    } else {
-      int lo = 0, hi_t = tab.num_types;   // (table lives in SGPRs)
-      while (hi_t - lo > 1) {
-        const int mid = (lo + hi_t) >> 1;
-        if (tab.unit_off[mid] <= u) lo = mid; else hi_t = mid;
-      }
-      t = lo;
-      t_u0 = tab.unit_off[t];
-      t_u1 = tab.unit_off[t + 1];
-    }
+    tp.type_of_unit(u, t, t_u0, t_u1);
     const int seg_end = t_u1 < u_end ? t_u1 : u_end;
     const int ub = u - t_u0;                        // first unit of the segment inside the type
     const int count = seg_end - u;
@@ -1171,21 +1165,12 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
   const StreamEdgeTable *tabp;
   if constexpr (INDIRECT) tabp = p.tab_dev; else tabp = &p.tab;
   const StreamEdgeTable &tab = *tabp;
+  const TablePrefixes tp(tab);
   if constexpr (INDIRECT) {
-    if ((int)blockIdx.x >= tab.wg_off[tab.num_types]) return;
+    if ((int)blockIdx.x >= tp.wg_total) return;
   }
   int u, u_end;
-  {
-    int lo = 0, hi_t = tab.num_types;
-    while (hi_t - lo > 1) {
-      const int mid = (lo + hi_t) >> 1;
-      if (tab.wg_off[mid] <= (int)blockIdx.x) lo = mid; else hi_t = mid;
-    }
-    const int64_t w = tab.wg_off[lo + 1] - tab.wg_off[lo], part = (int)blockIdx.x - tab.wg_off[lo];
-    const int64_t units = tab.unit_off[lo + 1] - tab.unit_off[lo];
-    u = tab.unit_off[lo] + (int)(part * units / w);
-    u_end = tab.unit_off[lo] + (int)((part + 1) * units / w);
-  }
+  tp.run_of_workgroup((int)blockIdx.x, u, u_end);
   if (u >= u_end) return;
   const Slab<false> sl(K, BN);
   int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
@@ -1199,14 +1184,10 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
   const int cbs = 32 * sl.ld;
 
   while (u < u_end) {
-    int lo = 0, hi_t = tab.num_types;
-    while (hi_t - lo > 1) {
-      const int mid = (lo + hi_t) >> 1;
-      if (tab.unit_off[mid] <= u) lo = mid; else hi_t = mid;
-    }
-    const int t = lo;
-    const int seg_end = tab.unit_off[t + 1] < u_end ? tab.unit_off[t + 1] : u_end;
-    const int ub = u - tab.unit_off[t];
+    int t, t_u0, t_u1;
+    tp.type_of_unit(u, t, t_u0, t_u1);
+    const int seg_end = t_u1 < u_end ? t_u1 : u_end;
+    const int ub = u - t_u0;
     const int count = seg_end - u;
     const int64_t type_row0 = tab.edge_off[t];
     const int64_t n_edges = tab.edge_off[t + 1] - type_row0;
@@ -1646,6 +1627,10 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   }
   p.tab.wg_off[0] = 0;
   for (int t = 0; t < tab.num_types; ++t) p.tab.wg_off[t + 1] = p.tab.wg_off[t] + w[t];
+  for (int t = tab.num_types + 1; t <= kStreamMaxTypes; ++t) {   // the kernels search the prefixes with a ballot over all
+    p.tab.wg_off[t] = p.tab.wg_off[tab.num_types];               // 65 entries: those past the last type hold the totals
+    p.tab.unit_off[t] = p.tab.unit_off[tab.num_types];
+  }
   p.run_len = 0;
   p.lds_floats = (int)(slab / 4);
   const unsigned grid = (unsigned)p.tab.wg_off[tab.num_types];
