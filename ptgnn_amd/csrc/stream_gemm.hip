@@ -371,15 +371,17 @@ __device__ __forceinline__ void store_row4(__amdgpu_buffer_rsrc_t rsrc, int lane
 }
 
 // one 32 x 32 C block -> y (bias + activation on the way), 4 dwordx4 stores per lane
-template <int ACT>
+// BIAS = false: no bias add at all (the edge GEMMs: `c + 0.f` is not foldable under IEEE rules -- it turns -0 into +0 --
+// so the literal zero they passed cost 64 v_add_f32 per unit, 1.5 % of the unit's MFMA time)
+template <int ACT, bool BIAS = true>
 __device__ __forceinline__ void store_block_tq(const f32x16 &c, float *tq, float *yblk /* row0, col0 of the block */,
                                                int64_t ld_y, float bv, int64_t rows_left, int lane, int li, int hi) {
+  auto val = [&](int r) { return BIAS ? act_apply<ACT>(c[r] + bv) : act_apply<ACT>(c[r]); };
 #ifdef PTGNN_GLOBAL_STORES   // A/B (scripts/build_variant.sh): the round-1..3 form, global_store_dwordx4 per lane
   float *yp = yblk + (int64_t)(lane >> 3) * ld_y + (lane & 7) * 4;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float4 o = tq_transpose(tq, lane, li, hi, act_apply<ACT>(c[4 * q] + bv), act_apply<ACT>(c[4 * q + 1] + bv),
-                                  act_apply<ACT>(c[4 * q + 2] + bv), act_apply<ACT>(c[4 * q + 3] + bv));
+    const float4 o = tq_transpose(tq, lane, li, hi, val(4 * q), val(4 * q + 1), val(4 * q + 2), val(4 * q + 3));
     if (8 * q + (lane >> 3) < rows_left) *reinterpret_cast<float4 *>(yp + (int64_t)(8 * q) * ld_y) = o;
   }
 #else
@@ -388,8 +390,7 @@ __device__ __forceinline__ void store_block_tq(const f32x16 &c, float *tq, float
   const int lane_bytes = (lane >> 3) * ldb + (lane & 7) * 16;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float4 o = tq_transpose(tq, lane, li, hi, act_apply<ACT>(c[4 * q] + bv), act_apply<ACT>(c[4 * q + 1] + bv),
-                                  act_apply<ACT>(c[4 * q + 2] + bv), act_apply<ACT>(c[4 * q + 3] + bv));
+    const float4 o = tq_transpose(tq, lane, li, hi, val(4 * q), val(4 * q + 1), val(4 * q + 2), val(4 * q + 3));
     store_row4(rsrc, lane_bytes, 8 * q * ldb, o);
   }
 #endif
@@ -533,6 +534,17 @@ __device__ __forceinline__ float fast_sigmoid(float v) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 
+// The same gate math on PAIRS of elements: gfx950's packed fp32 ops (v_pk_add_f32 / v_pk_mul_f32) process two floats per
+// lane per instruction with the results of the scalar ops (IEEE round-to-nearest per element), and VALU work is not
+// hidden under fp32 MFMAs -- the ~300 adds / muls of a unit's gate math were 5 % of its MFMA time.  The transcendentals stay
+// scalar.  Every expression below is the scalar one above, element for element: identical bits.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 rcp_1_plus_exp2(f32x2 t) {     // 1 / (1 + 2^t) per element
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + splat2(1.0f);
+  return f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+
 // Epilogue of one GRU unit (32 rows x 32 features), per row group of 8 rows: previous state in as one dwordx4 per
 // lane (8 rows x 128 B of the h tile), un-transposed through the wave's slab into the C layout; gate math per lane;
 // h' (and, in training, the gates) back through the slab as dwordx4 stores.  No mul+add contraction in the gate
@@ -558,13 +570,19 @@ __device__ __forceinline__ void gru_epilogue(const GruArgs &p, const f32x16 (&ac
     {
 #pragma clang fp contract(off)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; i += 2) {
         const int r = 4 * q + i;
-        rg[i] = fast_sigmoid((acc[0][r] + bir) + bhr);
-        zg[i] = fast_sigmoid((acc[1][r] + biz) + bhz);
-        hn[i] = acc[3][r] + bhn;
-        ng[i] = fast_tanh((acc[2][r] + bin) + rg[i] * hn[i]);
-        res[i] = (1.0f - zg[i]) * ng[i] + zg[i] * hp[i];
+        const f32x2 ar = {acc[0][r], acc[0][r + 1]}, az = {acc[1][r], acc[1][r + 1]};
+        const f32x2 an = {acc[2][r], acc[2][r + 1]}, ah = {acc[3][r], acc[3][r + 1]};
+        const f32x2 hp2 = {hp[i], hp[i + 1]};
+        const f32x2 r2 = rcp_1_plus_exp2(((ar + splat2(bir)) + splat2(bhr)) * splat2(-1.4426950408889634f));   // fast_sigmoid
+        const f32x2 z2 = rcp_1_plus_exp2(((az + splat2(biz)) + splat2(bhz)) * splat2(-1.4426950408889634f));
+        const f32x2 h2 = ah + splat2(bhn);
+        const f32x2 pre = (an + splat2(bin)) + r2 * h2;
+        const f32x2 n2 = splat2(2.0f) * rcp_1_plus_exp2(pre * splat2(-2.8853900817779268f)) - splat2(1.0f);     // fast_tanh
+        const f32x2 o2 = (splat2(1.0f) - z2) * n2 + z2 * hp2;
+        rg[i] = r2.x; rg[i + 1] = r2.y; zg[i] = z2.x; zg[i + 1] = z2.y; hn[i] = h2.x; hn[i + 1] = h2.y;
+        ng[i] = n2.x; ng[i + 1] = n2.y; res[i] = o2.x; res[i + 1] = o2.y;
       }
     }
     const float4 o = tq_transpose(tq, lane, li, hi, res[0], res[1], res[2], res[3]);
@@ -1056,9 +1074,9 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
           if (n * 32 < p.M) {   // host guarantees 16-byte aligned message rows
             float *yb = p.msg + out_row0 * p.ld_msg + n * 32;
             const int64_t left = n_edges - e_row0;
-            if (p.act == PTGNN_AMD_ACT_TANH) store_block_tq<PTGNN_AMD_ACT_TANH>(acc[n], tq, yb, p.ld_msg, 0.f, left, lane, li, hi);
-            else if (p.act == PTGNN_AMD_ACT_RELU) store_block_tq<PTGNN_AMD_ACT_RELU>(acc[n], tq, yb, p.ld_msg, 0.f, left, lane, li, hi);
-            else store_block_tq<PTGNN_AMD_ACT_NONE>(acc[n], tq, yb, p.ld_msg, 0.f, left, lane, li, hi);
+            if (p.act == PTGNN_AMD_ACT_TANH) store_block_tq<PTGNN_AMD_ACT_TANH, false>(acc[n], tq, yb, p.ld_msg, 0.f, left, lane, li, hi);
+            else if (p.act == PTGNN_AMD_ACT_RELU) store_block_tq<PTGNN_AMD_ACT_RELU, false>(acc[n], tq, yb, p.ld_msg, 0.f, left, lane, li, hi);
+            else store_block_tq<PTGNN_AMD_ACT_NONE, false>(acc[n], tq, yb, p.ld_msg, 0.f, left, lane, li, hi);
           }
           acc[n] = zero16();
         }
