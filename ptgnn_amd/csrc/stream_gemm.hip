@@ -434,9 +434,15 @@ __device__ __forceinline__ void linear_epilogue(const LinearArgs &p, f32x16 (&ac
       if (p.vec_store) {
         float *yb = p.y + row0 * p.ld_y + col_base + n * 32;
         const int64_t left = p.rows - row0;
-        if (p.act == PTGNN_AMD_ACT_TANH) store_block_tq<PTGNN_AMD_ACT_TANH>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
-        else if (p.act == PTGNN_AMD_ACT_RELU) store_block_tq<PTGNN_AMD_ACT_RELU>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
-        else store_block_tq<PTGNN_AMD_ACT_NONE>(acc[n], tq, yb, p.ld_y, bv, left, lane, li, hi);
+        // the bias goes into the accumulators under a uniform branch, the store adds nothing: a bias-free Linear (the
+        // stacked edge pre-transform, the GRU's gradient GEMMs) must not pay 16 `c + 0.f` per block (not foldable: -0 + 0)
+        if (p.bias) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[n][r] += bv;
+        }
+        if (p.act == PTGNN_AMD_ACT_TANH) store_block_tq<PTGNN_AMD_ACT_TANH, false>(acc[n], tq, yb, p.ld_y, 0.f, left, lane, li, hi);
+        else if (p.act == PTGNN_AMD_ACT_RELU) store_block_tq<PTGNN_AMD_ACT_RELU, false>(acc[n], tq, yb, p.ld_y, 0.f, left, lane, li, hi);
+        else store_block_tq<PTGNN_AMD_ACT_NONE, false>(acc[n], tq, yb, p.ld_y, 0.f, left, lane, li, hi);
       } else {
         float *yp = p.y + (row0 + 4 * hi) * p.ld_y + col;
         if (p.act == PTGNN_AMD_ACT_TANH) store_block<PTGNN_AMD_ACT_TANH>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
