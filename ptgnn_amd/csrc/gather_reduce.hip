@@ -659,7 +659,9 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
     }
   }
   constexpr bool kFuseHub = hub_fuses<CH, HAS_DST, HAS_ARG, MASKED>();
-  if (kFuseHub && !side && a.hub_threshold > 0) {   // no side stream: the first workgroups of the main launch walk the hub list
+  // minibatch-sized plans only (below the side streams' threshold): there the list is almost always empty.  A large plan that
+  // stays on one stream (side streams switched off or exhausted) keeps the dedicated hub launch with its full grid.
+  if (kFuseHub && !side && a.hub_threshold > 0 && a.num_edges < side_min_edges) {
     const int64_t chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;
     a.hub_blocks = (int)(((chunks < PTGNN_HUB_FUSED_BLOCKS ? chunks : PTGNN_HUB_FUSED_BLOCKS) + 7) / 8 * 8);
   }
@@ -676,7 +678,7 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
     if (long_launch) PTGNN_HIP(hipStreamWaitEvent(stream, side->join2, 0));
     return PTGNN_AMD_OK;
   }
-  if (!kFuseHub && a.hub_threshold > 0) {
+  if (a.hub_blocks == 0 && a.hub_threshold > 0) {
     // the list length lives on the device: a fixed grid strides over it (zero entries => instant exit)
     int64_t chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;
     dim3 hgrid((unsigned)(chunks < 1024 ? chunks : 1024), (unsigned)col_blocks);
