@@ -45,7 +45,14 @@
 extern "C" {
 #endif
 
-#define PTGNN_AMD_VERSION 100 /* 0.1.0 */
+/* The library is built with -fvisibility=hidden; the declarations of this header are its ONLY exported
+ * symbols (`nm -D --defined-only libptgnn_amd.so` lists ptgnn_amd_* and nothing else). */
+#pragma GCC visibility push(default)
+
+/* 101: ptgnn_amd_shard_index gained `bad_index_count` (round 4, mid-signature), ptgnn_amd_gru_cell_csr_f32 and the
+ * fused node-update entry points were added (round 5).  Callers check ptgnn_amd_version() >= the version their
+ * header was compiled against (the Python host does, ptgnn_amd/_lib.py). */
+#define PTGNN_AMD_VERSION 101 /* 0.1.1 */
 
 enum {
   PTGNN_AMD_OK = 0,
@@ -537,6 +544,8 @@ int ptgnn_amd_gru_cell_f32(const float *a, int64_t ld_a, const float *h, int64_t
  * mlp_hidden_layers > 0) and for task heads (output_node_representations[node_idx_references]). */
 int ptgnn_amd_gather_rows_f32(const float *x, int64_t ld_x, const int64_t *idx, int64_t n_idx,
                               int32_t dim, float *out, int64_t ld_out, void *stream);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

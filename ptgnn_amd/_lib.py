@@ -85,6 +85,10 @@ SIGNATURES = {
     "ptgnn_amd_gather_rows_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
 }
 
+# The header version this host was written against (include/ptgnn_amd.h: PTGNN_AMD_VERSION).  A stale .so with an
+# older ABI (e.g. ptgnn_amd_shard_index before `bad_index_count` joined its signature) is refused at load time.
+MIN_VERSION = 101
+
 _lock = threading.Lock()
 _lib = None
 
@@ -108,6 +112,10 @@ def load():
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)  # AttributeError if the .so is stale
                 fn.restype, fn.argtypes = res, args
+            have = lib.ptgnn_amd_version()
+            if have < MIN_VERSION:
+                raise PtgnnAmdError(f"{LIB_PATH} reports ABI version {have}, this host needs >= {MIN_VERSION}: "
+                                    "rebuild it with `python -m ptgnn_amd.build --force`")
             _lib = lib
     return _lib
 

@@ -17,8 +17,9 @@ LIB = os.path.join(CSRC, "libptgnn_amd.so")
 SOURCES = ["errors.cpp", "csr_build.hip", "gather_reduce.hip", "dense_f32.hip", "stream_gemm.hip", "edge_gemm.hip", "edge_wgrad.hip", "wgrad_stream.hip", "batching.hip", "row_epilogue.hip", "shard_index.hip", "segment_mul.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "dense_common.h"), os.path.join(CSRC, "stream_gemm.h"), os.path.join(CSRC, "wgrad_stream.h"),
            os.path.join(INCLUDE, "ptgnn_amd.h")]
+EXPORTS = os.path.join(CSRC, "exports.map")   # only ptgnn_amd_* leaves the library
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-deprecated-declarations"]
 
 
@@ -48,9 +49,9 @@ def _compile(src: str, force: bool) -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
-    if force or _stale(LIB, objs):
+    if force or _stale(LIB, objs + [EXPORTS]):
         # NEEDED libamdhip64.so.7 resolves to the copy torch already loaded in-process (same SONAME)
-        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", f"-Wl,--version-script={EXPORTS}", "-o", LIB] + objs
         subprocess.run(cmd, check=True)
         if verbose:
             print("built", LIB)

@@ -38,7 +38,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_version_and_pure_host_entry_points(lib):
-    assert lib.ptgnn_amd_version() == 100
+    assert lib.ptgnn_amd_version() == 101 >= __import__('ptgnn_amd')._lib.MIN_VERSION
     assert [lib.ptgnn_amd_type_bits(t) for t in (1, 2, 3, 4, 5, 17, 32, 33)] == [0, 1, 2, 2, 3, 5, 5, 6]
     assert lib.ptgnn_amd_last_error() is not None
 
@@ -294,6 +294,16 @@ def test_committed_bench_line_keeps_the_driver_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["parity"]["max_abs"] <= d["parity"]["tol"] == 1e-5
+
+
+def test_only_the_c_abi_is_exported(lib):
+    """-fvisibility=hidden + csrc/exports.map: the dynamic symbol table holds the header's ptgnn_amd_* functions and
+    nothing else (no mangled ptgnn_amd::stream_*, set_error, libstdc++ instantiations, __hip_cuid_*)."""
+    import subprocess
+    from ptgnn_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert names == declared_symbols(), sorted(set(names) ^ set(declared_symbols()))
 
 
 def test_library_carries_no_vendor_sort_or_scan(lib):
