@@ -93,6 +93,9 @@ _lock = threading.Lock()
 _lib = None
 
 
+EUNSUPPORTED = -2    # PTGNN_AMD_EUNSUPPORTED of include/ptgnn_amd.h
+
+
 class PtgnnAmdError(RuntimeError):
     pass
 

@@ -30,7 +30,11 @@ Edge features at inference ride the grouped per-edge GEMM as a third K range of 
 Edge features in training, deeper edge MLPs and custom aggregation modules take the general per-edge path: torch only
 gathers / concatenates rows, every Linear runs on the HIP GEMM (`ptgnn_amd/dense.py`, any width) and the
 aggregation on the HIP segment-reduce seam with its autograd rule.  fp16 / bf16 node states (AMP) are up-cast
-to fp32 on entry and the result is cast back.  No path runs on the CPU or on a vendor BLAS.
+to fp32 on entry and the result is cast back.  No GPU path runs on a vendor BLAS or falls back to torch.
+
+Device dispatch (round 5): tensors on the CPU take `ptgnn_amd/torch_route.py` (plain torch operators, so that the
+reference's `predict.py` -- which restores and runs on "cpu" -- and a CPU `ModelTrainer` work with these layers);
+tensors on the GPU always take the HIP library and raise when it is missing.
 """
 import contextlib
 import os
@@ -40,7 +44,7 @@ from typing import Dict, List, Optional, Tuple, Union
 import torch
 from torch import nn
 
-from ptgnn_amd import _lib, dense, ops
+from ptgnn_amd import _lib, dense, ops, torch_route
 from ptgnn_amd.scatter import (edge_linear as edge_linear_autograd, gather_reduce as gather_reduce_autograd,
                                segment_reduce)
 
@@ -167,8 +171,9 @@ def _feat_gemm_ok(node_states, edge_features, state_dim: int, out_dim: int, *par
     (ptgnn_amd_edge_linear_feat_f32), so the reference's [E, H (+H) + F] input matrix is never built."""
     if node_states.dtype != torch.float32 or state_dim % 32 != 0 or out_dim % 4 != 0:
         return False
-    if any(f is None or f.shape[-1] == 0 or not f.is_cuda for f in edge_features):
-        return False
+    if any(f is None or f.shape[-1] == 0 or f.device != node_states.device or f.dtype != torch.float32
+           for f in edge_features):
+        return False   # float64 / integer / other-device features: the general path (torch.cat promotes like the reference)
     if len({int(f.shape[-1]) for f in edge_features}) != 1:
         return False
     return (not torch.is_grad_enabled()) or _no_grad_needed(node_states, *edge_features, *params)
@@ -202,10 +207,19 @@ def _run_mlp(mlp: "MLP", x: torch.Tensor) -> torch.Tensor:
 
 
 def _check_device(node_states: torch.Tensor):
+    """The sharded forms (RCCL halo exchange) exist on the GPU only."""
     if not node_states.is_cuda:
         raise _lib.PtgnnAmdError(
-            "ptgnn_amd layers run on the MI355X only; node_states is on "
-            f"{node_states.device}. (Use the reference layers for a CPU run.)")
+            "forward_sharded runs on the MI355X only; node_states is on "
+            f"{node_states.device}. (The unsharded `forward` takes CPU tensors through ptgnn_amd.torch_route.)")
+
+
+def _on_host(node_states: torch.Tensor) -> bool:
+    """Device dispatch of the unsharded layers, like a torch operator's: CPU tensors take the plain-torch route
+    (ptgnn_amd/torch_route.py: the reference's own `predict.py` restores and runs a model on "cpu",
+    typilus/predict.py:25-27; trainer.py:392-395 trains there without a GPU); GPU tensors ALWAYS take
+    libptgnn_amd.so and raise when it is missing or fails -- there is no way from a GPU tensor into the torch route."""
+    return not node_states.is_cuda
 
 
 # ------------------------------------------------------------------------------------------------
@@ -305,7 +319,10 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                 reference_node_graph_idx: Dict[str, torch.Tensor],
                 edge_features: List[torch.Tensor]) -> torch.Tensor:
         assert len(adjacency_lists) == len(self.__edge_message_transformation_layers)
-        _check_device(node_states)
+        if _on_host(node_states):
+            return torch_route.ggnn_layer(node_states, adjacency_lists, edge_features,
+                                          list(self.__edge_message_transformation_layers), self.__dropout,
+                                          self.__state_update, self.__aggregation_fn)
         if node_states.dtype in _AMP_DTYPES:
             # AMP (trainer.py:205,221): the reference computes messages in the autocast dtype and up-casts them
             # to fp32 at the aggregation (abstractmessagepassing.py:43-50).  Here the whole layer runs in fp32 on
@@ -390,6 +407,9 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
         if self._edge_feature_dimension != 0 or node_states.dtype != torch.float32:
             raise _lib.PtgnnAmdError("forward_sharded: edge features / non-fp32 states are not supported on a "
                                      "sharded graph")
+        if self.__aggregation_fn not in ops.REDUCE_IDS:
+            raise _lib.PtgnnAmdError(f"forward_sharded: aggregation {self.__aggregation_fn!r} is not supported on a "
+                                     "sharded graph (sum / mean / max / min are)")
         M, H = self._message_dimension, self.__state_dimension
         gru = self.__state_update
         p = self.__dropout.p if self.training else 0.0
@@ -698,7 +718,11 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
                 edge_features: List[torch.Tensor]) -> torch.Tensor:
         assert len(adjacency_lists) == len(self.__edge_message_transformation_layers), \
             "The number of adjacency lists must be equal to the number of edge types."
-        _check_device(node_states)
+        if _on_host(node_states):
+            return torch_route.mlp_layer(node_states, adjacency_lists, edge_features,
+                                         list(self.__edge_message_transformation_layers),
+                                         self.__use_target_state_as_message_input, self.__aggregation_fn,
+                                         self.__message_activation, self.__state_update)
         if node_states.dtype in _AMP_DTYPES:   # see GatedMessagePassingLayer.forward
             feats = [f.float() if f is not None and f.dtype in _AMP_DTYPES else f for f in edge_features]
             return self.forward(node_states.float(), adjacency_lists, node_to_graph_idx, reference_node_ids,
@@ -896,6 +920,8 @@ class LinearResidualLayer(_ResidualBase):
                 reference_node_graph_idx, edge_features):
         x = torch.cat((self._pop(), node_states), dim=-1)
         lin = self.__linear_combination
+        if _on_host(x):
+            return self.__dropout(lin(x))
         if x.dtype in _AMP_DTYPES:
             return self.__dropout(dense.linear(x.float(), lin.weight).to(x.dtype))
         if _no_grad_needed(x, lin.weight):

@@ -919,8 +919,12 @@ def edge_linear(x: torch.Tensor, adjacency_lists, weights: Sequence[torch.Tensor
                     x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),
                     ctypes.cast(cn, ctypes.c_void_p), ctypes.cast(wp, ctypes.c_void_p), T, M, msg.data_ptr(), M,
                     int(dropout[0]), float(dropout[1]), mask_bits.data_ptr(), _stream(msg))
-            _lib.check(rc, "ptgnn_amd_edge_linear_masked_f32")
-            return msg[:E]
+            if rc != _lib.EUNSUPPORTED:
+                _lib.check(rc, "ptgnn_amd_edge_linear_masked_f32")
+                return msg[:E]
+            # the streaming kernel declined at run time (first use inside a graph capture, an operand that is not
+            # 16-byte aligned, PTGNN_AMD_* developer switches): the seed form below evaluates the SAME hash inside the
+            # tile kernels -- bit-identical mask -- and rewrites every output row
         with _timed("edge_linear", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
             rc = lib.ptgnn_amd_edge_linear_dropout_f32(
                 x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),
@@ -1023,8 +1027,10 @@ def edge_weight_grad(x: torch.Tensor, adjacency_lists, grad_msg: torch.Tensor, u
                 x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),
                 ctypes.cast(cn, ctypes.c_void_p), gm_ptr, _ld(grad_msg), T, M, float(dropout_p),
                 mask_bits.data_ptr(), grad_w.data_ptr(), ws.data_ptr(), ws_bytes, _stream(grad_w))
-        _lib.check(rc, "ptgnn_amd_edge_weight_grad_masked_f32")
-        return grad_w
+        if rc != _lib.EUNSUPPORTED:
+            _lib.check(rc, "ptgnn_amd_edge_weight_grad_masked_f32")
+            return grad_w
+        # declined at run time (see edge_linear): the seed form computes the same mask from its hash
     with _timed("edge_weight_grad", flops=2.0 * E * K * M, bytes=4.0 * (E * K + E * M + T * M * K) + 8.0 * E):
         rc = lib.ptgnn_amd_edge_weight_grad_f32(
             x.data_ptr(), _ld(x), x.shape[0], H, ctypes.cast(sp, ctypes.c_void_p),

@@ -13,7 +13,7 @@ from typing import NamedTuple, Union
 import torch
 from torch import nn
 
-from ptgnn_amd import _lib, dense, ops
+from ptgnn_amd import _lib, dense, ops, torch_route
 from ptgnn_amd.layers import AbstractMessagePassingLayer, _check_device, _no_grad_needed
 from ptgnn_amd.scatter import gather_rows as gather_rows_autograd, segment_reduce
 
@@ -55,8 +55,8 @@ def _index_plan(index: torch.Tensor, num_samples: int) -> "ops.GraphPlan":
 
 
 def _pool(values: torch.Tensor, index: torch.Tensor, num_samples, reduce: str) -> torch.Tensor:
-    if not values.is_cuda:
-        raise _lib.PtgnnAmdError("ptgnn_amd reduce ops run on the MI355X only")
+    if not values.is_cuda:    # device dispatch: CPU tensors take the plain-torch route (ptgnn_amd/torch_route.py)
+        return torch_route.aggregate(values, index, int(num_samples), reduce)
     plan = _index_plan(index, int(num_samples))
     dt = values.dtype
     return segment_reduce(values.to(torch.float32).contiguous(), plan, reduce).to(dt)
@@ -102,7 +102,11 @@ class AbstractGlobalGraphExchange(AbstractMessagePassingLayer):
 
     def forward(self, node_states, adjacency_lists, node_to_graph_idx, reference_node_ids,
                 reference_node_graph_idx, edge_features) -> torch.Tensor:
-        _check_device(node_states)
+        if not node_states.is_cuda:   # globalgraphexchange.py:37-45 on host tensors
+            num_graphs = _num_samples(node_to_graph_idx)
+            e = ElementsToSummaryRepresentationInput(node_states, node_to_graph_idx, num_graphs)
+            graph_reps = self.__dropout(self.__global_graph_representation_module(e))
+            return self._update_node_states(node_states, graph_reps[node_to_graph_idx])
         if node_states.dtype in (torch.float16, torch.bfloat16):   # AMP: fp32 inside, caller's dtype outside
             return self.forward(node_states.float(), adjacency_lists, node_to_graph_idx, reference_node_ids,
                                 reference_node_graph_idx, edge_features).to(node_states.dtype)
@@ -167,6 +171,8 @@ class GruGlobalStateUpdate(AbstractGlobalGraphExchange):
 
     def _update_node_states(self, node_states, global_info_per_node):
         gru = self.__gru_cell
+        if not node_states.is_cuda:
+            return gru(global_info_per_node, node_states)
         if (node_states.dtype == torch.float32
                 and _no_grad_needed(node_states, global_info_per_node, *gru.parameters())):
             return ops.gru_cell(global_info_per_node, node_states, gru.weight_ih, gru.weight_hh,

@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-from ptgnn_amd import _lib, ops
+from ptgnn_amd import _lib, ops, torch_route
 
 
 class _SegmentReduce(torch.autograd.Function):
@@ -110,6 +110,8 @@ def scatter(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional
             dim_size: Optional[int] = None, reduce: str = "sum") -> torch.Tensor:
     """torch_scatter.scatter for the layout the ptgnn hot path uses (abstractmessagepassing.py:44-50,
     pna_aggregation.py:28-45, varsizedsummary.py:35)."""
+    if not src.is_cuda:   # device dispatch: host tensors take plain torch operators (ptgnn_amd/torch_route.py)
+        return torch_route.scatter(src, index, dim, out, dim_size, reduce)
     src2, squeeze, plan = _prepare(src, index, dim, out, dim_size)
     res = segment_reduce(src2.to(torch.float32), plan, reduce).to(src.dtype)
     return res.squeeze(1) if squeeze else res
@@ -134,6 +136,8 @@ def scatter_mean(src, index, dim: int = -1, out=None, dim_size: Optional[int] = 
 
 
 def _scatter_minmax(src, index, dim, out, dim_size, reduce):
+    if not src.is_cuda:
+        return torch_route.scatter(src, index, dim, out, dim_size, reduce, return_arg=True)
     src2, squeeze, plan = _prepare(src, index, dim, out, dim_size)
     x = src2.to(torch.float32)
     res = segment_reduce(x, plan, reduce).to(src.dtype)
@@ -183,6 +187,8 @@ def scatter_log_softmax(src, index, dim: int = -1, eps: float = 1e-12,
                         dim_size: Optional[int] = None) -> torch.Tensor:
     """torch_scatter.composite.scatter_log_softmax (varsizedsummary.py:57,106,158; varmisuse.py:79;
     grucopydecoder.py:100):  src - max_seg - log(sum_seg exp(src - max_seg) + eps)."""
+    if not src.is_cuda:
+        return torch_route.scatter_log_softmax(src, index, dim, eps, dim_size)
     src2, squeeze, plan = _prepare(src, index, dim, None, dim_size)
     x = src2.to(torch.float32)
     if x.shape[0] == 0:
@@ -198,6 +204,8 @@ def scatter_log_softmax(src, index, dim: int = -1, eps: float = 1e-12,
 def scatter_softmax(src, index, dim: int = -1, eps: float = 1e-12,
                     dim_size: Optional[int] = None) -> torch.Tensor:
     """torch_scatter.composite.scatter_softmax:  exp(src - max_seg) / (sum_seg exp(src - max_seg) + eps)."""
+    if not src.is_cuda:
+        return torch_route.scatter_softmax(src, index, dim, eps, dim_size)
     src2, squeeze, plan = _prepare(src, index, dim, None, dim_size)
     x = src2.to(torch.float32)
     if x.shape[0] == 0:
@@ -208,6 +216,94 @@ def scatter_softmax(src, index, dim: int = -1, eps: float = 1e-12,
     total = segment_reduce(e, plan, "sum")
     res = (e / (_GatherRows.apply(total, index, plan) + eps)).to(src.dtype)
     return res.squeeze(1) if squeeze else res
+
+
+def scatter_logsumexp(src, index, dim: int = -1, out=None, dim_size: Optional[int] = None,
+                      eps: float = 1e-12) -> torch.Tensor:
+    """torch_scatter.composite.scatter_logsumexp (grucopydecoder.py:122,190): log(sum_seg exp(src - max_seg) + eps)
+    + max_seg, the maximum taken over a -inf initialised buffer (a segment without elements answers -inf)."""
+    if not src.is_cuda:
+        return torch_route.scatter_logsumexp(src, index, dim, out, dim_size, eps)
+    src2, squeeze, plan = _prepare(src, index, dim, out, dim_size)
+    x = src2.to(torch.float32)
+    n, D = plan.num_nodes, x.shape[1]
+    if x.shape[0] == 0:
+        res = torch.full((n, D), float("-inf"), dtype=src.dtype, device=src.device)
+        return res.squeeze(1) if squeeze else res
+    with torch.no_grad():
+        vals, slot = ops.gather_reduce(x.detach(), plan, D, "max", return_arg=True, type_bits=0, col=plan.perm)
+        top = torch.where(slot >= 0, vals, torch.full_like(vals, float("-inf")))
+        shift = ops.gather_rows(top, index)
+    rec = x - shift
+    rec = rec.masked_fill(rec.isnan(), float("-inf"))
+    total = segment_reduce(rec.exp(), plan, "sum")
+    res = ((total + eps).log() + top).to(src.dtype)
+    return res.squeeze(1) if squeeze else res
+
+
+def scatter_std(src, index, dim: int = -1, out=None, dim_size: Optional[int] = None,
+                unbiased: bool = True) -> torch.Tensor:
+    """torch_scatter.scatter_std: sqrt(sum_seg (x - mean_seg)^2 / (max(count - 1, 1) + 1e-6)) (count, not count - 1,
+    with unbiased=False)."""
+    if not src.is_cuda:
+        return torch_route.scatter_std(src, index, dim, out, dim_size, unbiased)
+    src2, squeeze, plan = _prepare(src, index, dim, out, dim_size)
+    x = src2.to(torch.float32)
+    n, D = plan.num_nodes, x.shape[1]
+    if x.shape[0] == 0:
+        res = torch.zeros(n, D, dtype=src.dtype, device=src.device)
+        return res.squeeze(1) if squeeze else res
+    plan.wait()
+    count = (plan.rowptr[1:] - plan.rowptr[:-1]).clamp(min=1).to(torch.float32).unsqueeze(1)
+    mean = segment_reduce(x, plan, "sum") / count
+    dev = x - _GatherRows.apply(mean.contiguous(), index, plan)
+    ssq = segment_reduce(dev * dev, plan, "sum")
+    if unbiased:
+        count = (count - 1).clamp(min=1)
+    res = (ssq / (count + 1e-6)).sqrt().to(src.dtype)
+    return res.squeeze(1) if squeeze else res
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# `import torch_scatter` for the untouched reference modules
+# ------------------------------------------------------------------------------------------------------------------
+FACADE_VERSION = "2.0.6+ptgnn_amd"
+
+
+def install(force: bool = False):
+    """Register this facade as the modules `torch_scatter` and `torch_scatter.composite` in `sys.modules`, so that the
+    reference's untouched sources -- `from torch_scatter import scatter` (abstractmessagepassing.py:4),
+    `scatter_log_softmax, scatter_max` (varmisuse.py:8), `scatter, scatter_log_softmax, scatter_sum`
+    (varsizedsummary.py:7), `scatter_add` + `from torch_scatter.composite import scatter_log_softmax,
+    scatter_logsumexp` (grucopydecoder.py:9-10), `scatter_mean` (graphnorm.py:3) -- import the HIP-backed functions
+    (GPU tensors) / the plain-torch route (CPU tensors) with NO edit of reference code:
+
+        import ptgnn_amd.scatter; ptgnn_amd.scatter.install()     # before the first `import ptgnn`
+
+    A real `torch_scatter` wheel, when one is importable, is left alone unless `force=True`.  Returns the module."""
+    import importlib.util
+    import sys
+    import types
+    have = sys.modules.get("torch_scatter")
+    if have is not None and getattr(have, "__version__", "") == FACADE_VERSION:
+        return have
+    if not force and (have is not None or importlib.util.find_spec("torch_scatter") is not None):
+        return sys.modules.get("torch_scatter") or importlib.import_module("torch_scatter")
+    top = types.ModuleType("torch_scatter")
+    top.__doc__ = "ptgnn_amd.scatter registered as torch_scatter (HIP segment reduce on MI355X; torch on CPU tensors)"
+    comp = types.ModuleType("torch_scatter.composite")
+    for f in (scatter, scatter_sum, scatter_mul, scatter_mean, scatter_max, scatter_min, scatter_softmax,
+              scatter_log_softmax, scatter_logsumexp, scatter_std):
+        setattr(top, f.__name__, f)
+    top.scatter_add = scatter_add
+    for f in (scatter_softmax, scatter_log_softmax, scatter_logsumexp, scatter_std):
+        setattr(comp, f.__name__, f)
+    top.composite = comp
+    top.__version__ = FACADE_VERSION
+    top.__path__ = []            # a package: `import torch_scatter.composite` resolves through sys.modules
+    sys.modules["torch_scatter"] = top
+    sys.modules["torch_scatter.composite"] = comp
+    return top
 
 
 class _EdgeLinear(torch.autograd.Function):
@@ -280,6 +376,11 @@ def edge_linear(x: torch.Tensor, plan: "ops.GraphPlan", weights, use_dst: bool, 
     if plan._adj is None:
         raise _lib.PtgnnAmdError("edge_linear: the plan must keep its adjacency lists")
     w_stack = weights if isinstance(weights, torch.Tensor) else torch.stack(list(weights))
+    if int(float(dropout_p) * 65536.0 + 0.5) == 0:
+        # the hash mask keeps an element when 16 hash bits >= round(p * 65536): below p ~ 7.6e-6 that threshold is 0,
+        # every element is kept, and "dropout off" (no mask, no 1 / (1 - p) scale) is the one consistent reading for the
+        # forward, the input gradient and the weight gradient alike
+        dropout_p = 0.0
     return _EdgeLinear.apply(x, plan, bool(use_dst), float(dropout_p), int(dropout_seed), w_stack)
 
 

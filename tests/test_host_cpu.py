@@ -57,7 +57,7 @@ def test_argument_validation_without_a_gpu(lib):
     assert rc == -1
 
 
-def test_layers_mirror_reference_interface_and_refuse_cpu():
+def test_layers_mirror_reference_interface_and_dispatch_on_the_device():
     from ptgnn_amd import PtgnnAmdError, layers as L
     g = L.GatedMessagePassingLayer(state_dimension=8, message_dimension=12, num_edge_types=3,
                                    message_aggregation_function="max", dropout_rate=0.1,
@@ -82,8 +82,18 @@ def test_layers_mirror_reference_interface_and_refuse_cpu():
     assert tuple(m.state_dict()["_MlpMessagePassingLayer__edge_message_transformation_layers.0."
                                 "_MLP__mlp_modules.1.weight"].shape) == (10, 16)
     adj = [(torch.tensor([0]), torch.tensor([1]))] * 3
+    # CPU tensors: device dispatch to the plain-torch route (ptgnn_amd/torch_route.py; predict.py runs on "cpu") ...
+    y = g.eval()(torch.randn(4, 8), adj, None, {}, {}, [torch.empty(1, 0)] * 3)
+    assert tuple(y.shape) == (4, 8) and not y.is_cuda
+    # ... while every C-ABI wrapper keeps refusing them (the HIP path has no eager substitute) and the sharded
+    # forms exist on the GPU only
+    from ptgnn_amd import ops
     with pytest.raises(PtgnnAmdError):
-        g(torch.randn(4, 8), adj, None, {}, {}, [torch.empty(1, 0)] * 3)
+        ops.linear(torch.randn(4, 8), torch.randn(3, 8))
+    with pytest.raises(PtgnnAmdError):
+        ops.build_plan(adj, 4)
+    with pytest.raises(PtgnnAmdError):
+        g.forward_sharded(torch.randn(4, 8), None)
     with pytest.raises(AssertionError):          # wrong number of edge types: the reference's assert
         g(torch.randn(4, 8), adj[:2], None, {}, {}, [torch.empty(1, 0)] * 2)
     r = L.ConcatResidualLayer(8)
@@ -120,8 +130,10 @@ def test_golden_fixture_weights_load_into_layers():
 def test_scatter_facade_rejects_unsupported_layouts():
     from ptgnn_amd import PtgnnAmdError
     from ptgnn_amd.scatter import scatter
-    with pytest.raises(PtgnnAmdError):
-        scatter(torch.randn(4, 3, 2), torch.tensor([0, 1, 0, 1]), dim=0)
+    from ptgnn_amd.scatter import _prepare
+    with pytest.raises(PtgnnAmdError, match="supports src"):     # the HIP side's layout rule (argument check only)
+        _prepare(torch.randn(4, 3, 2), torch.tensor([0, 1, 0, 1]), 0, None, None)
+    assert tuple(scatter(torch.randn(4, 3, 2), torch.tensor([0, 1, 0, 1]), dim=0).shape) == (2, 3, 2)   # host route
     with pytest.raises(PtgnnAmdError):
         scatter(torch.randn(4, 3), torch.tensor([0, 1, 0, 1]), dim=0, out=torch.zeros(2, 3))
     with pytest.raises(ValueError):
