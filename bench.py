@@ -556,53 +556,12 @@ def sustained_stats(dev, seconds=10.0, batches=4, block=40):
             "edges_per_sec_per_layer_median": round(edges / (med / 1e3 / 8), 1)}
 
 
-def sampled_layer_parity(kind, spec, adj_cpu, x_cpu, got_gpu, deg, n_rows=4096, n_hubs=8, seed=3):
-    """Oracle parity of ONE layer on a graph too large for a full CPU evaluation (cfg5 shard: the per-edge restatement
-    would gather a 12.8 GB [E, 256] matrix): the oracle runs on the in-neighbourhood closure of a ROW SAMPLE of the
-    same graph -- `n_rows` random destination rows plus the `n_hubs` rows of largest in-degree, all their in-edges
-    (in the original order, so every sampled row folds exactly as in the full graph) and the source rows those
-    edges read -- in fp32 (the reference's arithmetic) and in float64 (for attribution).
-    Bars: rows with < 32 in-edges (where fp32 itself supports it) within 1e-5 of the fp32 oracle; every sampled row
-    no further from float64 than 2 x the reference's own fp32 arithmetic is (GGNN + sum feeds an un-normalised sum
-    of up to 1.6e5 messages into the GRU: the oracle itself is ~2e-4 from float64 on hub rows)."""
-    from oracle import mp_oracle as O
-    src, dst = adj_cpu[0]
-    n = x_cpu.shape[0]
-    g = torch.Generator().manual_seed(seed)
-    rows = torch.unique(torch.cat([torch.randperm(n, generator=g)[:n_rows], torch.topk(deg, n_hubs).indices]))
-    pick = torch.zeros(n, dtype=torch.bool)
-    pick[rows] = True
-    m = pick[dst]
-    s_sub, d_sub = src[m], dst[m]
-    nodes = torch.unique(torch.cat([rows, s_sub]))
-    sub_adj = [(torch.searchsorted(nodes, s_sub), torch.searchsorted(nodes, d_sub))]
-    at = torch.searchsorted(nodes, rows)
-    x_sub = x_cpu[nodes]
-    feats = [torch.empty(int(s_sub.shape[0]), 0)]
-    fn = O.ggnn_layer if kind == "ggnn" else O.mlp_mp_layer
-    with torch.no_grad():
-        w32 = fn(x_sub, sub_adj, feats, spec)[at]
-        w64 = fn(x_sub.double(), sub_adj, [f.double() for f in feats], O.cast_spec(spec, torch.float64))[at]
-    got = got_gpu[rows.to(got_gpu.device)].cpu()
-    low = deg[rows] < 32
-    err32 = (got - w32).abs()
-    ours64, ref64 = float((got.double() - w64).abs().max()), float((w32.double() - w64).abs().max())
-    res = {"rows_sampled": int(rows.shape[0]), "edges_in_sample": int(s_sub.shape[0]), "hub_rows_in_sample": n_hubs,
-           "max_abs_rows_below_32_in_edges": float(err32[low].max()), "tol": PARITY_TOL,
-           "max_abs_all_sampled_rows": float(err32.max()),
-           "ours_vs_fp64": ours64, "oracle_fp32_vs_fp64": ref64,
-           "against": "oracle/mp_oracle.py (fp32 and float64) on the in-neighbourhood closure of the row sample"}
-    res["ok"] = bool(res["max_abs_rows_below_32_in_edges"] <= PARITY_TOL and ours64 <= max(PARITY_TOL, 2.0 * ref64))
-    # the literal bar on EVERY sampled row (hub rows included), next to the float64-attributed `ok` (ADVICE r03)
-    res["strict_1e-5"] = bool(res["max_abs_all_sampled_rows"] <= PARITY_TOL)
-    return res
-
-
 def config5_shard(dev, parity=True):
     """configs[4] at its per-GPU size (an 8-way dst-range shard of N=10M / E=100M: 1.25M rows, 12.5M in-edges with
     Zipf-0.8 destinations, H=256): the only BASELINE shape whose node table (1.28 GB) exceeds the 256 MiB
     Infinity Cache.  One GGNN layer AND one MLP-MP layer (sum; SURVEY.md 8d "1 layer (GGNN and MLP-MP)") through the
-    layer API, the plan build and the aggregation kernel on their own, and oracle parity on a row sample."""
+    layer API, the plan build and the aggregation kernel on their own, and oracle parity on EVERY row (oracle/fullrow.py:
+    the chunked CPU oracle, fp32 + float64 attribution of the rows fp32 itself cannot hold to 1e-5)."""
     from ptgnn_amd import layers as L, ops, workloads
     N, E, H = 1_250_000, 12_500_000, 256
     adj = workloads.power_law_graph(N, E, alpha=0.8, seed=1234)
@@ -660,8 +619,15 @@ def config5_shard(dev, parity=True):
                  "edges_per_sec_per_layer": round(E / dt, 1),
                  "nodes_per_sec_per_layer": round(N / dt, 1), "kernels": ktab}
         if parity:
-            entry["parity"] = sampled_layer_parity(kind, spec, adj, x_cpu, out, deg)
+            # EVERY row of the shard against the chunked CPU oracle (round 5; rounds 2-4: a 4 104-row sample)
+            from oracle import fullrow
+            got_cpu = out.cpu()
+            del out
+            torch.cuda.empty_cache()
+            entry["parity"] = fullrow.full_row_parity(spec, adj, x_cpu, got_cpu)
+            _log(f"cfg5 {kind} full-row parity: {entry['parity']}")
             ok = ok and entry["parity"]["ok"]
+            out = None
         res["ggnn_layer" if kind == "ggnn" else "mlp_mp_layer"] = entry
         del layer, out
     # headline fields = the GGNN layer (the figure rounds 1-2 reported under these keys)

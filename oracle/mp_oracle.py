@@ -128,6 +128,54 @@ def mlp_mp_layer(node_states, adjacency_lists: Adj, edge_features, w: Dict,
     return (x, aggregated) if return_aggregate else x
 
 
+def layer_on_rows(node_states, adjacency_lists: Adj, w: Dict, rows: torch.Tensor):
+    """`ggnn_layer` / `mlp_mp_layer` (no edge features) evaluated for the destination rows `rows` (sorted, unique
+    int64) only -> [len(rows), H'].  A message-passing layer computes every output row from its own in-edges and its
+    own previous state (gatedmessagepassing.py:63-69, mlpmessagepassing.py:107-117), so this is the SAME arithmetic
+    -- the selected edges keep their type-major order, i.e. every row folds its messages exactly as in the whole-graph
+    call -- for graphs whose [E, H] gathered message input does not fit the host (BASELINE config 5: 12.8 GB per
+    shard).  tests/test_oracle_golden.py pins it to the whole-graph functions."""
+    n = node_states.shape[0]
+    pick = torch.zeros(n, dtype=torch.bool)
+    pick[rows] = True
+    targets, messages = [], []
+    for t, (src, dst) in enumerate(adjacency_lists):
+        sel = pick[dst]
+        s, d = src[sel], dst[sel]
+        targets.append(torch.searchsorted(rows, d))
+        inp = node_states.index_select(0, s)
+        if w["kind"] == "ggnn":
+            messages.append(linear(inp, w["edge_w"][t]))                               # gatedmessagepassing.py:54-61
+        else:
+            if w["use_target"]:
+                inp = torch.cat([inp, node_states.index_select(0, d)], -1)            # mlpmessagepassing.py:88-92
+            messages.append(mlp(inp, w["edge_mlp"][t]))                                # :96-98
+    agg = aggregate_messages(torch.cat(messages, 0), torch.cat(targets, 0), int(rows.shape[0]), w["agg"])
+    if w["kind"] == "ggnn":
+        return gru_cell(agg, node_states.index_select(0, rows), w["w_ih"], w["w_hh"], w["b_ih"], w["b_hh"])
+    x = gelu(agg) if w.get("gelu", True) else agg
+    if w.get("ln_w") is not None:
+        x = layer_norm(x, w["ln_w"], w["ln_b"])
+    if w.get("dense_w") is not None:
+        x = linear(x, w["dense_w"], w["dense_b"])
+        if w.get("tanh", True):
+            x = torch.tanh(x)
+    return x
+
+
+def row_chunks(in_degree: torch.Tensor, max_edges: int):
+    """Consecutive destination-row ranges [lo, hi) holding <= max_edges in-edges each (a single row beyond that gets a
+    range of its own): the chunking `layer_on_rows` is driven with for a whole large graph."""
+    csum = torch.cumsum(in_degree.to(torch.int64), 0)
+    n, lo, base = int(in_degree.shape[0]), 0, 0
+    while lo < n:
+        hi = int(torch.searchsorted(csum, torch.tensor(base + max_edges), right=True))
+        hi = min(n, max(hi, lo + 1))
+        yield lo, hi
+        base = int(csum[hi - 1])
+        lo = hi
+
+
 def global_gru_exchange(node_states, node_to_graph_idx, w: Dict):
     """GruGlobalStateUpdate with WeightedSum / Simple pooling (eval mode):
     globalgraphexchange.py:29-64 + varsizedsummary.py:28-41,68-81.

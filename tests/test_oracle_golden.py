@@ -128,3 +128,36 @@ def test_oracle_autograd_matches_reference_gradients(name):
     np.testing.assert_allclose(x.grad.numpy(), g["g.x"], rtol=0, atol=1e-5 * max(1.0, np.abs(g["g.x"]).max()))
     for t, want in _grad_pairs(spec, g):
         np.testing.assert_allclose(t.grad.numpy(), want, rtol=0, atol=1e-5 * max(1.0, np.abs(want).max()))
+
+
+@pytest.mark.parametrize("kind,agg", [("ggnn", "sum"), ("ggnn", "max"), ("mlp", "sum"), ("mlp", "mean")])
+def test_row_restricted_oracle_equals_the_whole_graph_oracle(kind, agg):
+    """oracle/mp_oracle.py `layer_on_rows` + `row_chunks` (the every-row checker of the config-5 shard,
+    oracle/fullrow.py) against the whole-graph restatement that the reference fixtures pin: chunks of destination rows,
+    concatenated, and an arbitrary row subset -- same arithmetic up to BLAS blocking (<= 1e-6)."""
+    import torch
+    from oracle import fullrow, mp_oracle as O
+    from ptgnn_amd import layers as L
+    torch.manual_seed(0)
+    N, H, T = 3000, 32, 3
+    adj = [(torch.randint(0, N, (e,)), torch.randint(0, N // 3, (e,))) for e in (5000, 100, 9000)]
+    x = torch.randn(N, H)
+    deg = torch.bincount(torch.cat([d for _, d in adj]), minlength=N)
+    layer = (L.GatedMessagePassingLayer(H, 48, T, agg) if kind == "ggnn"
+             else L.MlpMessagePassingLayer(H, H, 40, T, agg, use_target_state_as_message_input=agg == "sum"))
+    spec = layer.export_weights()
+    feats = [torch.empty(a[0].shape[0], 0) for a in adj]
+    with torch.no_grad():
+        want = (O.ggnn_layer if kind == "ggnn" else O.mlp_mp_layer)(x, adj, feats, spec)
+        chunks = list(O.row_chunks(deg, 1500))
+        got = torch.cat([O.layer_on_rows(x, adj, spec, torch.arange(lo, hi)) for lo, hi in chunks])
+        rows = torch.tensor([0, 5, 17, 999, 2999])
+        some = O.layer_on_rows(x, adj, spec, rows)
+    assert len(chunks) > 5 and chunks[0][0] == 0 and chunks[-1][1] == N
+    assert all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
+    assert float((got - want).abs().max()) <= 1e-6 and float((some - want[rows]).abs().max()) <= 1e-6
+    res = fullrow.full_row_parity(spec, adj, x, want.clone(), max_edges=2000)
+    assert res["ok"] and res["strict_1e-5"] and res["rows_checked"] == N and res["edges_checked"] == 14100
+    bad = want.clone()
+    bad[17] += 1e-4
+    assert not fullrow.full_row_parity(spec, adj, x, bad, max_edges=2000)["ok"]
