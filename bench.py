@@ -62,6 +62,8 @@ def parse():
     p.add_argument("--gemm", default=None, choices=["tile", "stream", "split"],
                    help="kernel family / arithmetic of the dense blocks for the PRIMARY line (default: stream = exact fp32)")
     p.add_argument("--no-secondary", action="store_true")
+    p.add_argument("--no-rotation", action="store_true",
+                   help="cfg3: replay ONE minibatch in the timed region (the rounds 1-4 form) instead of rotating over four")
     p.add_argument("--no-sustained", action="store_true", help="skip the >= 10 s sustained block of the primary step")
     p.add_argument("--sustained-seconds", type=float, default=10.0)
     p.add_argument("--force-sharded", action="store_true",
@@ -293,6 +295,9 @@ def train_cfg3(dev, dropout, steps=8, warmup=4, arch="ggnn", H=128, forward_too=
         res.update(ms_per_forward=round(df * 1e3, 3), inference_edges_per_sec_readme_convention=round(E / df, 1),
                    vs_readme_v100_inference_2527k=round(E / df / 2.527e6, 2))
     return res
+
+
+ROTATE_MINIBATCHES = 4
 
 
 def step_cfg3(st):
@@ -877,22 +882,38 @@ def main():
     gemm_names = {0: "f32 (exact fp32 MFMA, 128x128 tile kernels)", 1: "f32 (exact fp32 MFMA, streaming kernels)",
                   2: "f32 via 3xbf16 split (bf16 MFMA, fp32 accumulate)"}
 
+    rotation = None
     if args.workload == "cfg2":
         st = make_cfg2(dev, rank, world, args.force_sharded or args.global_ids, args.cut_edges)
         step = lambda: step_cfg2(st, world)  # noqa: E731
     else:
         if args.force_sharded:
             raise SystemExit("the sharded variants are cfg2 runs: add --workload cfg2")
-        st = make_cfg3(dev, rank)
-        step = lambda: step_cfg3(st)  # noqa: E731
+        # The timed K steps ROTATE over four minibatches of different seeds (round 5): replaying one minibatch keeps its
+        # states, messages and weights warm in the 256 MiB Infinity Cache and flattered the round-4 headline by ~2 %
+        # (3.84 vs 3.92 ms sustained).  Rank r draws minibatches r, r + world, r + 2 world, ...; parity and the CPU
+        # baseline use the first one; the single-minibatch replay figure is reported beside the headline.
+        rotation = [make_cfg3(dev, rank + world * i) for i in range(1 if args.no_rotation else ROTATE_MINIBATCHES)]
+        st = rotation[0]
+        turn = {"i": 0}
+
+        def step():
+            cur = rotation[turn["i"] % len(rotation)]
+            turn["i"] += 1
+            return step_cfg3(cur)
 
     _log(f"workload {args.workload} built; timing the primary region")
     seconds, summary = timed_region(step, args.steps, args.warmup, world, dev)
     ms_per_step = seconds / args.steps * 1e3
     _log(f"primary: {ms_per_step:.3f} ms/step")
     layers = st["layers_per_step"]
-    edges_all_ranks = sum_over_ranks(st["E"], world, dev)      # per-rank batches differ in size
-    nodes_all_ranks = sum_over_ranks(st["N"], world, dev)
+    if rotation is not None:   # mean over the K timed steps (step i of the run uses minibatch i mod 4; W warm-ups came first)
+        timed = [rotation[(args.warmup + i) % len(rotation)] for i in range(args.steps)]
+        e_mine, n_mine = sum(t["E"] for t in timed) / args.steps, sum(t["N"] for t in timed) / args.steps
+    else:
+        e_mine, n_mine = st["E"], st["N"]
+    edges_all_ranks = sum_over_ranks(e_mine, world, dev)       # per-rank batches differ in size
+    nodes_all_ranks = sum_over_ranks(n_mine, world, dev)
     value = edges_all_ranks / (seconds / args.steps / layers)
     ktab = kernel_table(summary)
     dominant = max(ktab, key=lambda k: ktab[k]["total_ms"])
@@ -924,6 +945,18 @@ def main():
         "roofline": roof, "kernels": ktab,
     }
     exit_code = 0
+    if rotation is not None and len(rotation) > 1:
+        result["config"]["minibatches_rotated"] = len(rotation)
+        result["config"]["nodes_per_minibatch"] = [t["N"] for t in rotation]
+        result["config"]["edges_per_minibatch"] = [t["E"] for t in rotation]
+        try:      # the round-1..4 form of the headline (one minibatch replayed), beside the rotating one
+            sec1, _ = timed_region(lambda: step_cfg3(st), args.steps, 2, world, dev)
+            result["single_minibatch_replay"] = {
+                "ms_per_step": round(sec1 / args.steps * 1e3, 4),
+                "value": round(sum_over_ranks(st["E"], world, dev) / (sec1 / args.steps / layers), 1),
+                "note": "one minibatch replayed K times (the rounds 1-4 headline form): its working set stays cache-warm"}
+        except Exception as exc:  # noqa: BLE001
+            result["single_minibatch_replay"] = {"error": f"{type(exc).__name__}: {exc}"}
     if args.workload == "cfg3":
         result["vs_readme_v100_inference_2527k"] = round(result["edges_per_sec_readme_convention"] / world / 2.527e6, 2)
 
@@ -1070,8 +1103,9 @@ def main():
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             _log("cpu baseline (thread sweep) + full-size parity")
+            first = (lambda: step_cfg3(st)) if rotation is not None else step     # parity: the FIRST minibatch of the rotation
             with torch.no_grad():
-                gpu_out = step()
+                gpu_out = first()
             gpu_out = gpu_out.output_node_representations if args.workload == "cfg3" else gpu_out
             base, parity = (cpu_baseline_cfg2 if args.workload == "cfg2" else cpu_baseline_cfg3)(st, gpu_out)
             result["cpu_baseline"], result["parity"] = base, parity
@@ -1086,13 +1120,13 @@ def main():
                     sec_s, sum_s = timed_region(step, args.steps, args.warmup, 1, dev)
                     kt_s = kernel_table(sum_s)
                     with torch.no_grad():
-                        out_s = step().output_node_representations.cpu()
+                        out_s = first().output_node_representations.cpu()
                         want = O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True)[0]
                     err_s = float((out_s - want).abs().max())
                     result["split_bf16"] = {
                         "dtype": "f32 via 3xbf16 split", "gemm_mode": gemm_names[2],
                         "ms_per_step": round(sec_s / args.steps * 1e3, 4),
-                        "value": round(st["E"] / (sec_s / args.steps / layers), 1), "unit": "edges/s",
+                        "value": round(e_mine / (sec_s / args.steps / layers), 1), "unit": "edges/s",
                         "speedup_vs_primary": round(ms_per_step / (sec_s / args.steps * 1e3), 3),
                         "parity": {"max_abs": err_s, "tol": PARITY_TOL, "n": st["N"]},
                         "kernels": {k: {kk: v[kk] for kk in ("calls", "avg_ms", "achieved", "unit")} for k, v in kt_s.items()}}

@@ -286,6 +286,23 @@ int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_ysrc,
                                 const int32_t *hub_count /* nullable */, void *hub_ws /* nullable */,
                                 size_t hub_ws_bytes, int32_t *hub_tickets /* nullable */,
                                 void *stream);
+/* The same aggregation for the destination rows [row_begin, row_end) only (every pointer and count keeps its
+ * whole-plan meaning; rows outside the range are neither read nor written, hub rows outside it are skipped).  A
+ * layer's aggregation -> node update chain (gatedmessagepassing.py:63-69) is row-wise after the aggregation, so the
+ * host can pipeline it over row ranges: the update of the first range (MFMA-bound) overlaps the aggregation of the
+ * second (latency-bound) on another stream -- ptgnn_amd.ops.aggregate_update_pipelined.  Launches over one plan
+ * must not overlap EACH OTHER in time (they share `hub_tickets`). */
+int ptgnn_amd_gather_reduce_rows_f32(const float *ysrc, int64_t ld_ysrc,
+                                     const float *ydst /* nullable */, int64_t ld_ydst,
+                                     const int32_t *rowptr, const int32_t *col,
+                                     int32_t type_bits, int64_t num_nodes, int32_t msg_dim,
+                                     int reduce, int epilogue, const float *ln_gamma,
+                                     const float *ln_beta, float ln_eps, float *out, int64_t ld_out,
+                                     int32_t *argout /* nullable */, int64_t num_edges,
+                                     int32_t hub_threshold, const int32_t *hub_entries /* nullable */,
+                                     const int32_t *hub_count /* nullable */, void *hub_ws /* nullable */,
+                                     size_t hub_ws_bytes, int32_t *hub_tickets /* nullable */,
+                                     int64_t row_begin, int64_t row_end, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * reduce = "mul" of the scatter seam: abstractmessagepassing.py:44-50 hands the aggregation name to
@@ -325,6 +342,12 @@ int ptgnn_amd_gather_reduce_masked_f32(const float *grad, int64_t ld_grad, const
 int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int64_t ld_x, const float *w,
                          int32_t n_out, const float *bias, int act, float *y, int64_t ld_y,
                          void *stream);
+/* y = act(x W^T + b) + addend, the add folded into the GEMM's store epilogue (training: the GRU cell's backward
+ * `d_h + d_gh W_hh`, which torch ran as a separate pass over [N, H] per layer).  Streaming shapes only (K % 64 == 0,
+ * n_out % 32 == 0, 16-byte aligned rows): others return PTGNN_AMD_EUNSUPPORTED without touching `y`. */
+int ptgnn_amd_linear_add_f32(const float *x, int64_t rows, int32_t k, int64_t ld_x, const float *w, int32_t n_out,
+                             const float *bias /* nullable */, int act, const float *addend, int64_t ld_add, float *y,
+                             int64_t ld_y, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Minibatch assembly on the device (GraphNeuralNetworkModel.extend_minibatch_with / finalize_minibatch,

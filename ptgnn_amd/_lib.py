@@ -45,11 +45,16 @@ SIGNATURES = {
     "ptgnn_amd_gather_reduce_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i64, _i32, _c.c_int,
                                                _c.c_int, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _i32, _vp,
                                                _vp, _vp, _c.c_size_t, _vp, _vp]),
+    "ptgnn_amd_gather_reduce_rows_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i64, _i32, _c.c_int,
+                                                    _c.c_int, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _i32, _vp,
+                                                    _vp, _vp, _c.c_size_t, _vp, _i64, _i64, _vp]),
     "ptgnn_amd_gather_reduce_masked_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64,
                                                       _i64, _i32, _vp, _vp, _vp, _c.c_size_t, _vp, _vp]),
     "ptgnn_amd_segment_mul_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "ptgnn_amd_linear_f32": (_c.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _c.c_int, _vp, _i64,
                                         _vp]),
+    "ptgnn_amd_linear_add_f32": (_c.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _c.c_int, _vp, _i64, _vp, _i64,
+                                            _vp]),
     "ptgnn_amd_batch_offsets_i64": (_c.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _vp, _vp]),
     "ptgnn_amd_edge_linear_f32": (_c.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _c.c_int, _vp,
                                              _i64, _vp]),

@@ -438,6 +438,26 @@ extern "C" int ptgnn_amd_linear_f32(const float *x, int64_t rows, int32_t k, int
   return PTGNN_AMD_OK;
 }
 
+// y = act(x W^T + b) + addend in ONE launch: the streaming kernels add the block in their store epilogue.  Shapes the
+// streaming core does not take answer EUNSUPPORTED (the host then runs ptgnn_amd_linear_f32 and adds).
+extern "C" int ptgnn_amd_linear_add_f32(const float *x, int64_t rows, int32_t k, int64_t ld_x, const float *w,
+                                        int32_t n_out, const float *bias, int act, const float *addend,
+                                        int64_t ld_add, float *y, int64_t ld_y, void *stream_) {
+  PTGNN_REQUIRE(rows >= 0 && k > 0 && n_out > 0, PTGNN_AMD_EINVAL, "linear_add: bad sizes");
+  PTGNN_REQUIRE(act >= 0 && act <= PTGNN_AMD_ACT_RELU, PTGNN_AMD_EINVAL, "linear_add: bad act");
+  if (rows == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(x && w && y && addend && ld_x >= k && ld_y >= n_out && ld_add >= n_out, PTGNN_AMD_EINVAL,
+                "linear_add: null/ld");
+  PTGNN_REQUIRE(addend != y, PTGNN_AMD_EINVAL, "linear_add: in-place accumulation is not supported");
+  if (stream_linear(x, rows, k, ld_x, w, n_out, bias, act, y, ld_y, (hipStream_t)stream_, addend, ld_add)) {
+    PTGNN_LAUNCH_CHECK();
+    return PTGNN_AMD_OK;
+  }
+  set_error("linear_add: rows=%lld k=%d n_out=%d is not a shape of the streaming GEMM (use ptgnn_amd_linear_f32 and add)",
+            (long long)rows, k, n_out);
+  return PTGNN_AMD_EUNSUPPORTED;
+}
+
 static int gru_launch(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const float *w_ih,
                       const float *w_hh, const float *b_ih, const float *b_hh, int64_t n, int32_t m,
                       int32_t hd, float *out, int64_t ld_out, float *gates, void *stream_) {

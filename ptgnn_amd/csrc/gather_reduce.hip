@@ -57,7 +57,8 @@ struct Args {
   const int32_t *rowptr;
   const int32_t *col;
   int32_t type_bits;
-  int64_t num_nodes;
+  int64_t num_nodes;         // one past the last row of this launch
+  int64_t row_begin;         // first row of this launch (0 unless a row range was asked for); pointers stay absolute
   int32_t msg_dim;
   const float *ln_gamma;
   const float *ln_beta;
@@ -410,6 +411,7 @@ __device__ __forceinline__ void hub_chunks_body(const Args &a, int first, int st
   for (int e = first; e < count; e += stride) {
     const int64_t chunk = a.hub_entries[2 * e];
     const int64_t row = a.hub_entries[2 * e + 1];
+    if (row < a.row_begin || row >= a.num_nodes) continue;   // a row-range launch: the hub belongs to another piece
     const int64_t cbeg = chunk * kHubChunk;
     const int64_t cend = (cbeg + kHubChunk < a.num_edges) ? cbeg + kHubChunk : a.num_edges;
     const int rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
   }
   const int64_t tile = xcd_swizzle(blockIdx.x - a.hub_blocks, gridDim.x - a.hub_blocks);
   if (tile >= a.num_tiles) return;
-  const int64_t row = tile * ROWS_PER_BLOCK + threadIdx.x / LPR;
+  const int64_t row = a.row_begin + tile * ROWS_PER_BLOCK + threadIdx.x / LPR;
   if (row >= a.num_nodes) return;  // whole lane-group exits together (no cross-group shuffles)
   const int beg = a.rowptr[row], end = a.rowptr[row + 1];
   if (a.hub_threshold > 0 && end - beg > a.hub_threshold) return;  // hub: the chunk kernel owns it
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void k_long_rows(Args a) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
-  for (int64_t base = wave * 64; base < a.num_nodes; base += nwaves * 64) {
+  for (int64_t base = a.row_begin + wave * 64; base < a.num_nodes; base += nwaves * 64) {
     const int64_t r = base + lane;
     int beg = 0, deg = 0;
     if (r < a.num_nodes) {
@@ -618,7 +620,7 @@ template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool
 int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
   constexpr int ROWS_PER_BLOCK = 256 / LPR;
   Args a = a0;
-  a.num_tiles = (a.num_nodes + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  a.num_tiles = (a.num_nodes - a.row_begin + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   a.hub_blocks = 0;
   SideStream *side = nullptr;
   // large plans only: on a minibatch-sized graph the launches are ~0.1 ms, have no tail worth hiding, and the
@@ -650,7 +652,7 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
         a.long_threshold = kLongRow;
         long_launch = true;
         PTGNN_HIP(hipStreamWaitEvent(side->stream2, side->fork, 0));
-        const int64_t lb = (a.num_nodes + 255) / 256;
+        const int64_t lb = (a.num_nodes - a.row_begin + 255) / 256;
         dim3 lgrid((unsigned)(lb < 2048 ? lb : 2048), (unsigned)col_blocks);
         k_long_rows<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG><<<lgrid, 256, 0, side->stream2>>>(a);
         PTGNN_LAUNCH_CHECK();
@@ -790,8 +792,28 @@ extern "C" int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_y, cons
                                            int32_t hub_threshold, const int32_t *hub_entries,
                                            const int32_t *hub_count, void *hub_ws,
                                            size_t hub_ws_bytes, int32_t *hub_tickets, void *stream_) {
+  return ptgnn_amd_gather_reduce_rows_f32(ysrc, ld_y, ydst, ld_yd, rowptr, col, type_bits, num_nodes, msg_dim, reduce,
+                                          epilogue, ln_gamma, ln_beta, ln_eps, out, ld_out, argout, num_edges,
+                                          hub_threshold, hub_entries, hub_count, hub_ws, hub_ws_bytes, hub_tickets, 0,
+                                          num_nodes, stream_);
+}
+
+extern "C" int ptgnn_amd_gather_reduce_rows_f32(const float *ysrc, int64_t ld_y, const float *ydst,
+                                                int64_t ld_yd, const int32_t *rowptr, const int32_t *col,
+                                                int32_t type_bits, int64_t num_nodes, int32_t msg_dim,
+                                                int reduce, int epilogue, const float *ln_gamma,
+                                                const float *ln_beta, float ln_eps, float *out,
+                                                int64_t ld_out, int32_t *argout, int64_t num_edges,
+                                                int32_t hub_threshold, const int32_t *hub_entries,
+                                                const int32_t *hub_count, void *hub_ws,
+                                                size_t hub_ws_bytes, int32_t *hub_tickets, int64_t row_begin,
+                                                int64_t row_end, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PTGNN_REQUIRE(num_nodes >= 0 && msg_dim > 0 && num_edges >= 0, PTGNN_AMD_EINVAL, "gather_reduce: bad sizes");
+  PTGNN_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= num_nodes, PTGNN_AMD_EINVAL,
+                "gather_reduce: row range [%lld, %lld) outside [0, %lld]", (long long)row_begin, (long long)row_end,
+                (long long)num_nodes);
+  if (row_begin == row_end) return PTGNN_AMD_OK;
   PTGNN_REQUIRE(reduce >= PTGNN_AMD_SUM && reduce <= PTGNN_AMD_MIN, PTGNN_AMD_EINVAL,
                 "gather_reduce: unknown reduce %d", reduce);
   PTGNN_REQUIRE(epilogue >= 0 && epilogue <= 3, PTGNN_AMD_EINVAL, "gather_reduce: bad epilogue");
@@ -806,7 +828,7 @@ extern "C" int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_y, cons
 
   Args a{};
   a.ysrc = ysrc; a.ydst = ydst; a.ld_y = ld_y; a.ld_yd = ydst ? ld_yd : ld_y;
-  a.rowptr = rowptr; a.col = col; a.type_bits = type_bits; a.num_nodes = num_nodes; a.msg_dim = msg_dim;
+  a.rowptr = rowptr; a.col = col; a.type_bits = type_bits; a.num_nodes = row_end; a.row_begin = row_begin; a.msg_dim = msg_dim;
   a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.out = out; a.ld_out = ld_out;
   a.argout = argout; a.epi = epilogue;
   const int rc = setup_hub(a, num_edges, hub_threshold, hub_entries, hub_count, hub_ws, hub_ws_bytes,

@@ -23,8 +23,10 @@ int num_compute_units();
 int stream_gemm_mode();          // 0 tile kernels, 1 streaming exact fp32, 2 streaming 3xbf16 split
 void stream_gemm_set_mode(int mode);
 
+// `addend` (nullable): y = act(x W^T + b) + addend, [rows, n_out] with leading dimension ld_add
 int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const float *w, int32_t n_out,
-                  const float *bias, int act, float *y, int64_t ld_y, hipStream_t st);
+                  const float *bias, int act, float *y, int64_t ld_y, hipStream_t st, const float *addend = nullptr,
+                  int64_t ld_add = 0);
 int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const float *w_ih,
                const float *w_hh, const float *b_ih, const float *b_hh, int64_t n, int32_t m, int32_t hd,
                float *out, int64_t ld_out, float *gates, hipStream_t st);

@@ -373,15 +373,29 @@ __device__ __forceinline__ void store_row4(__amdgpu_buffer_rsrc_t rsrc, int lane
 // one 32 x 32 C block -> y (bias + activation on the way), 4 dwordx4 stores per lane
 // BIAS = false: no bias add at all (the edge GEMMs: `c + 0.f` is not foldable under IEEE rules -- it turns -0 into +0 --
 // so the literal zero they passed cost 64 v_add_f32 per unit, 1.5 % of the unit's MFMA time)
+// `addblk` (nullable, wave-uniform): the same block of a matrix that is ADDED to the result after the activation
+// (y = act(x W^T + b) + addend: the GRU backward's `d_h + d_gh W_hh`, dense.py) -- one dwordx4 load per store, in
+// the stores' own row / column layout.
 template <int ACT, bool BIAS = true>
 __device__ __forceinline__ void store_block_tq(const f32x16 &c, float *tq, float *yblk /* row0, col0 of the block */,
-                                               int64_t ld_y, float bv, int64_t rows_left, int lane, int li, int hi) {
+                                               int64_t ld_y, float bv, int64_t rows_left, int lane, int li, int hi,
+                                               const float *addblk = nullptr, int64_t ld_add = 0) {
   auto val = [&](int r) { return BIAS ? act_apply<ACT>(c[r] + bv) : act_apply<ACT>(c[r]); };
+  float4 addv[4];
+  if (addblk) {    // uniform branch; rows past the end re-read the last valid row (their stores are dropped)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int64_t r = 8 * q + (lane >> 3);
+      r = r < rows_left ? r : rows_left - 1;
+      addv[q] = *reinterpret_cast<const float4 *>(addblk + r * ld_add + (lane & 7) * 4);
+    }
+  }
 #ifdef PTGNN_GLOBAL_STORES   // A/B (scripts/build_variant.sh): the round-1..3 form, global_store_dwordx4 per lane
   float *yp = yblk + (int64_t)(lane >> 3) * ld_y + (lane & 7) * 4;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float4 o = tq_transpose(tq, lane, li, hi, val(4 * q), val(4 * q + 1), val(4 * q + 2), val(4 * q + 3));
+    float4 o = tq_transpose(tq, lane, li, hi, val(4 * q), val(4 * q + 1), val(4 * q + 2), val(4 * q + 3));
+    if (addblk) { o.x += addv[q].x; o.y += addv[q].y; o.z += addv[q].z; o.w += addv[q].w; }
     if (8 * q + (lane >> 3) < rows_left) *reinterpret_cast<float4 *>(yp + (int64_t)(8 * q) * ld_y) = o;
   }
 #else
@@ -390,7 +404,8 @@ __device__ __forceinline__ void store_block_tq(const f32x16 &c, float *tq, float
   const int lane_bytes = (lane >> 3) * ldb + (lane & 7) * 16;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float4 o = tq_transpose(tq, lane, li, hi, val(4 * q), val(4 * q + 1), val(4 * q + 2), val(4 * q + 3));
+    float4 o = tq_transpose(tq, lane, li, hi, val(4 * q), val(4 * q + 1), val(4 * q + 2), val(4 * q + 3));
+    if (addblk) { o.x += addv[q].x; o.y += addv[q].y; o.z += addv[q].z; o.w += addv[q].w; }
     store_row4(rsrc, lane_bytes, 8 * q * ldb, o);
   }
 #endif
@@ -400,6 +415,7 @@ struct LinearArgs {
   const float *x; int64_t rows; int K; int64_t ld_x;
   const float *w; int n_out; const float *bias; int act;
   float *y; int64_t ld_y;
+  const float *addend; int64_t ld_add;   // nullable: y = act(x W^T + b) + addend (vec_store launches only)
   int nrb, ncs, rps, run_len;
   int lds_floats;            // slab size in floats (the unit counter sits behind it)
   int vec_store;             // y rows are 16-byte aligned: float4 stores through the transposing slab
@@ -440,9 +456,10 @@ __device__ __forceinline__ void linear_epilogue(const LinearArgs &p, f32x16 (&ac
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[n][r] += bv;
         }
-        if (p.act == PTGNN_AMD_ACT_TANH) store_block_tq<PTGNN_AMD_ACT_TANH, false>(acc[n], tq, yb, p.ld_y, 0.f, left, lane, li, hi);
-        else if (p.act == PTGNN_AMD_ACT_RELU) store_block_tq<PTGNN_AMD_ACT_RELU, false>(acc[n], tq, yb, p.ld_y, 0.f, left, lane, li, hi);
-        else store_block_tq<PTGNN_AMD_ACT_NONE, false>(acc[n], tq, yb, p.ld_y, 0.f, left, lane, li, hi);
+        const float *ab = p.addend ? p.addend + row0 * p.ld_add + col_base + n * 32 : nullptr;
+        if (p.act == PTGNN_AMD_ACT_TANH) store_block_tq<PTGNN_AMD_ACT_TANH, false>(acc[n], tq, yb, p.ld_y, 0.f, left, lane, li, hi, ab, p.ld_add);
+        else if (p.act == PTGNN_AMD_ACT_RELU) store_block_tq<PTGNN_AMD_ACT_RELU, false>(acc[n], tq, yb, p.ld_y, 0.f, left, lane, li, hi, ab, p.ld_add);
+        else store_block_tq<PTGNN_AMD_ACT_NONE, false>(acc[n], tq, yb, p.ld_y, 0.f, left, lane, li, hi, ab, p.ld_add);
       } else {
         float *yp = p.y + (row0 + 4 * hi) * p.ld_y + col;
         if (p.act == PTGNN_AMD_ACT_TANH) store_block<PTGNN_AMD_ACT_TANH>(acc[n], yp, p.ld_y, bv, row0, p.rows, hi);
@@ -1429,9 +1446,12 @@ void stream_gemm_set_mode(int mode) { g_mode = mode; }
   }
 
 int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const float *w, int32_t n_out,
-                  const float *bias, int act, float *y, int64_t ld_y, hipStream_t st) {
+                  const float *bias, int act, float *y, int64_t ld_y, hipStream_t st, const float *addend,
+                  int64_t ld_add) {
   const int mode = stream_gemm_mode();
   if (mode == 0) return 0;
+  // the add-epilogue lives in the dwordx4 store path only
+  if (addend && (ld_y % 4 != 0 || !aligned16(y) || ld_add % 4 != 0 || !aligned16(addend))) return 0;
   if (k % 64 != 0 || n_out % 32 != 0 || ld_x % 4 != 0 || !aligned16(x) || !aligned16(w)) return 0;
   if (rows >= ((int64_t)1 << 31) * 32) return 0;
   const int bn = n_out >= 128 ? 128 : n_out;
@@ -1458,7 +1478,7 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
   LinearArgs p;
   p.x = x; p.rows = rows; p.K = k; p.ld_x = ld_x; p.w = w; p.n_out = n_out; p.bias = bias; p.act = act;
-  p.y = y; p.ld_y = ld_y;
+  p.y = y; p.ld_y = ld_y; p.addend = addend; p.ld_add = ld_add;
   p.nrb = (int)((rows + 31) / 32);
   p.ncs = (n_out + bn - 1) / bn;
   p.vec_store = (ld_y % 4 == 0 && aligned16(y)) ? 1 : 0;

@@ -157,7 +157,7 @@ class _GruCell(torch.autograd.Function):
         d_gi, d_gh, d_h = ops.gru_gates_backward(g.contiguous(), gates, h)
         need = ctx.needs_input_grad
         d_a = ops.linear(d_gi, _transposed(w_ih)) if need[0] else None
-        d_hx = d_h + ops.linear(d_gh, _transposed(w_hh)) if need[1] else None
+        d_hx = ops.linear_add(d_gh, _transposed(w_hh), d_h) if need[1] else None      # d_h + d_gh W_hh, one launch
         d_wih = d_bih = d_whh = d_bhh = None
         if need[2] or need[4]:
             d_wih, d_bih = ops.linear_weight_grad(a, d_gi, want_bias=True)

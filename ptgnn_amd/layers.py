@@ -343,12 +343,13 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
                 # aggregation reads it per edge -- same bits, fewer rows.
                 weights = [l.weight for l in self.__edge_message_transformation_layers]
                 msgs, col = _edge_messages(node_states, adjacency_lists, plan, weights)
-                agg = ops.gather_reduce(msgs, plan, M, self.__aggregation_fn, type_bits=0, col=col)
+                tb = 0
             else:
-                y = ops.linear(node_states, self._stacked_edge_weights())      # [N, T*M]
-                agg = ops.gather_reduce(y, plan, M, self.__aggregation_fn)
-            return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh,
-                                out=_take_output_hint(num_nodes, self.__state_dimension, node_states))
+                msgs, col, tb = ops.linear(node_states, self._stacked_edge_weights()), None, None      # [N, T*M]
+            # aggregation -> GRU cell, pipelined over destination-row ranges on large minibatches (ops.aggregate_gru)
+            return ops.aggregate_gru(msgs, plan, M, self.__aggregation_fn, node_states, gru.weight_ih, gru.weight_hh,
+                                     gru.bias_ih, gru.bias_hh, type_bits=tb, col=col,
+                                     out=_take_output_hint(num_nodes, self.__state_dimension, node_states))
 
         no_feats = self._edge_feature_dimension == 0 and not any(
             f is not None and f.shape[-1] != 0 for f in edge_features)

@@ -715,9 +715,11 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
                   ydst: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
                   ln_weight: Optional[torch.Tensor] = None, ln_bias: Optional[torch.Tensor] = None,
                   ln_eps: float = 1e-5, return_arg: bool = False, type_bits: Optional[int] = None,
-                  col: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+                  col: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                  rows: Optional[Tuple[int, int]] = None):
     """out[v] = EPI(reduce_{slots of v} ysrc[src, t*M:(t+1)*M] (+ ydst[v, t*M:(t+1)*M])).
-    `out`: optional caller-owned [num_nodes, msg_dim] fp32 destination (e.g. one half of a stacked buffer)."""
+    `out`: optional caller-owned [num_nodes, msg_dim] fp32 destination (e.g. one half of a stacked buffer).
+    `rows` = (lo, hi): only the destination rows [lo, hi) are computed and written (needs `out`, no arg)."""
     lib = _lib.load()
     _require_cuda_f32("ysrc", ysrc)
     ysrc = _rowmajor(ysrc)
@@ -747,9 +749,12 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
     nbytes = (plan.num_edges * (4.0 * msg_dim + 4) + N * (4.0 * msg_dim + 4)
               + (N * 4.0 * msg_dim if ydst is not None else 0.0)
               + (N * 4.0 * msg_dim if arg is not None else 0.0))
+    lo, hi = (0, N) if rows is None else (int(rows[0]), int(rows[1]))
+    if rows is not None:
+        nbytes *= (hi - lo) / max(N, 1)
     hub_ws, hub_bytes = _hub_workspace(plan, msg_dim, arg is not None, ysrc.device)
     with _timed("gather_reduce", bytes=nbytes):
-        rc = lib.ptgnn_amd_gather_reduce_f32(
+        rc = lib.ptgnn_amd_gather_reduce_rows_f32(
             ysrc.data_ptr(), ld_y, ydst.data_ptr() if ydst is not None else None, ld_yd,
             plan.rowptr.data_ptr(), colt.data_ptr(), tb, N, msg_dim,
             REDUCE_IDS[reduce], epilogue,
@@ -760,8 +765,8 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
             plan.hub_entries.data_ptr() if hub_ws is not None else None,
             plan.hub_count.data_ptr() if hub_ws is not None else None,
             hub_ws.data_ptr() if hub_ws is not None else None, hub_bytes,
-            plan.hub_tickets(msg_dim).data_ptr() if hub_ws is not None else None, _stream(out))
-    _lib.check(rc, "ptgnn_amd_gather_reduce_f32")
+            plan.hub_tickets(msg_dim).data_ptr() if hub_ws is not None else None, lo, hi, _stream(out))
+    _lib.check(rc, "ptgnn_amd_gather_reduce_rows_f32")
     return (out, arg) if return_arg else out
 
 
@@ -843,6 +848,33 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
                                       bias.data_ptr() if bias is not None else None, ACT_IDS[act],
                                       out.data_ptr(), _ld(out), _stream(out))
     _lib.check(rc, "ptgnn_amd_linear_f32")
+    return out
+
+
+def linear_add(x: torch.Tensor, weight: torch.Tensor, addend: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               act: Optional[str] = None) -> torch.Tensor:
+    """act(x W^T + b) + addend.  One launch where the streaming GEMM takes the shape (the add rides its store epilogue:
+    ptgnn_amd_linear_add_f32), else the GEMM followed by torch's add -- the same sum either way."""
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    _require_cuda_f32("weight", weight)
+    _require_cuda_f32("addend", addend)
+    x, weight, addend = _rowmajor(x), weight.contiguous(), _rowmajor(addend)
+    rows, k = x.shape
+    n_out = weight.shape[0]
+    if weight.shape[1] != k or tuple(addend.shape) != (rows, n_out):
+        raise _lib.PtgnnAmdError(f"linear_add: shapes x {tuple(x.shape)}, weight {tuple(weight.shape)}, addend "
+                                 f"{tuple(addend.shape)} do not agree")
+    out = torch.empty(rows, n_out, dtype=torch.float32, device=x.device)
+    if bias is not None:
+        bias = bias.contiguous()
+    with _timed("linear", flops=2.0 * rows * k * n_out, bytes=4.0 * (rows * k + n_out * k + 2 * rows * n_out)):
+        rc = lib.ptgnn_amd_linear_add_f32(x.data_ptr(), rows, k, _ld(x), weight.data_ptr(), n_out,
+                                          bias.data_ptr() if bias is not None else None, ACT_IDS[act],
+                                          addend.data_ptr(), _ld(addend), out.data_ptr(), _ld(out), _stream(out))
+    if rc == _lib.EUNSUPPORTED:
+        return linear(x, weight, bias, act=act, out=out).add_(addend)
+    _lib.check(rc, "ptgnn_amd_linear_add_f32")
     return out
 
 
@@ -1178,6 +1210,56 @@ def gru_cell(a: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh, out: Opti
                                         b_ih.contiguous().data_ptr(), b_hh.contiguous().data_ptr(),
                                         n, m, hd, out.data_ptr(), _ld(out), _stream(out))
     _lib.check(rc, "ptgnn_amd_gru_cell_f32")
+    return out
+
+
+# Aggregation -> GRU of one GGNN layer, pipelined over destination-row ranges (round 5).  The aggregation is latency /
+# HBM-bound (cfg3: 73 us, 0.59 of the HBM peak, most wave cycles waiting on memory), the fused GRU cell MFMA-bound (191 us,
+# 0.77 of the fp32 peak), and after the aggregation the layer is row-wise (gatedmessagepassing.py:63-69): row range i of the
+# GRU only needs row range i of the aggregate.  So the ranges' aggregations run back to back on a side stream while the
+# main stream runs the GRU of the ranges that are done -- the two kernels want different resources (LDS: only the GRU;
+# matrix pipes: only the GRU; outstanding loads: the aggregation).  Same kernels, same per-row arithmetic: bit-identical
+# to the unsplit pair.  PTGNN_AMD_AGG_PIPELINE = number of row ranges (1 = off).
+AGG_PIPELINE = int(os.environ.get("PTGNN_AMD_AGG_PIPELINE", "2"))
+AGG_PIPELINE_MIN_ROWS = int(os.environ.get("PTGNN_AMD_AGG_PIPELINE_MIN_ROWS", "65536"))
+
+
+def aggregate_gru(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str, h: torch.Tensor, w_ih, w_hh, b_ih,
+                  b_hh, type_bits: Optional[int] = None, col: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GRUCell(aggregate(ysrc over plan), h) -- `gather_reduce` followed by `gru_cell`, pipelined over row ranges on
+    large minibatches (see above)."""
+    N = plan.num_nodes
+    pieces = AGG_PIPELINE
+    if (pieces < 2 or N < AGG_PIPELINE_MIN_ROWS or N < 64 * pieces or torch.cuda.is_current_stream_capturing()):
+        agg = gather_reduce(ysrc, plan, msg_dim, reduce, type_bits=type_bits, col=col)
+        return gru_cell(agg, h, w_ih, w_hh, b_ih, b_hh, out=out)
+    dev = h.device
+    hd = h.shape[1]
+    agg = torch.empty(N, msg_dim, dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty(N, hd, dtype=torch.float32, device=dev)
+    bounds = [min(N, (N * i // pieces + 31) // 32 * 32) for i in range(pieces)] + [N]
+    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    plan.wait()
+    gather_reduce(ysrc, plan, msg_dim, reduce, type_bits=type_bits, col=col, out=agg, rows=(bounds[0], bounds[1]))
+    first_done = torch.cuda.Event()
+    first_done.record(main)
+    ready = []
+    with torch.cuda.stream(side):
+        side.wait_event(first_done)          # the ranges' aggregations never overlap each other (shared hub tickets)
+        for i in range(1, pieces):
+            gather_reduce(ysrc, plan, msg_dim, reduce, type_bits=type_bits, col=col, out=agg,
+                          rows=(bounds[i], bounds[i + 1]))
+            ev = torch.cuda.Event()
+            ev.record(side)
+            ready.append(ev)
+    for i in range(pieces):
+        if i > 0:
+            main.wait_event(ready[i - 1])
+        lo, hi = bounds[i], bounds[i + 1]
+        if hi > lo:
+            gru_cell(agg[lo:hi], h[lo:hi], w_ih, w_hh, b_ih, b_hh, out=out[lo:hi])
     return out
 
 
