@@ -1213,14 +1213,17 @@ def gru_cell(a: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh, out: Opti
     return out
 
 
-# Aggregation -> GRU of one GGNN layer, pipelined over destination-row ranges (round 5).  The aggregation is latency /
-# HBM-bound (cfg3: 73 us, 0.59 of the HBM peak, most wave cycles waiting on memory), the fused GRU cell MFMA-bound (191 us,
-# 0.77 of the fp32 peak), and after the aggregation the layer is row-wise (gatedmessagepassing.py:63-69): row range i of the
-# GRU only needs row range i of the aggregate.  So the ranges' aggregations run back to back on a side stream while the
-# main stream runs the GRU of the ranges that are done -- the two kernels want different resources (LDS: only the GRU;
-# matrix pipes: only the GRU; outstanding loads: the aggregation).  Same kernels, same per-row arithmetic: bit-identical
-# to the unsplit pair.  PTGNN_AMD_AGG_PIPELINE = number of row ranges (1 = off).
-AGG_PIPELINE = int(os.environ.get("PTGNN_AMD_AGG_PIPELINE", "2"))
+# Aggregation -> GRU of one GGNN layer, pipelined over destination-row ranges (round 5; OFF by default -- it measured
+# slower).  The aggregation is latency / HBM-bound (cfg3: 73-76 us, most wave cycles waiting on memory), the fused GRU cell
+# MFMA-bound (191-240 us), and after the aggregation the layer is row-wise (gatedmessagepassing.py:63-69): row range i
+# of the GRU only needs row range i of the aggregate.  So the ranges' aggregations can run back to back on a side stream
+# while the main stream runs the GRU of the ranges that are done.  Same kernels, same per-row arithmetic: bit-identical to
+# the unsplit pair (tests/test_gpu_pipeline.py).  Measured on the cfg3 headline step (profiles/r05_notes.md 1): 3.93 ms
+# unsplit, 4.19 ms with 2 ranges, 4.25 with 3, 4.36 with 4 -- the persistent GRU workgroups hold every CU's LDS and most
+# of its wave slots, so the co-resident aggregation crawls (99 us per HALF against 76 us for the whole matrix alone) and
+# each extra GRU launch pays its weight-slab fill again (2 x 136 us against 240 us).  PTGNN_AMD_AGG_PIPELINE = number of row
+# ranges (default 1 = the unsplit pair).
+AGG_PIPELINE = int(os.environ.get("PTGNN_AMD_AGG_PIPELINE", "1"))
 AGG_PIPELINE_MIN_ROWS = int(os.environ.get("PTGNN_AMD_AGG_PIPELINE_MIN_ROWS", "65536"))
 
 
