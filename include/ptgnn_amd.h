@@ -113,6 +113,7 @@ enum {
   PTGNN_AMD_KERNEL_TILE_GRU,
   PTGNN_AMD_KERNEL_TILE_EDGE,
   PTGNN_AMD_KERNEL_TILE_WGRAD,
+  PTGNN_AMD_KERNEL_GATHER_UPDATE,
   PTGNN_AMD_KERNEL_COUNT_
 };
 int64_t ptgnn_amd_launch_count(int kernel_id);
@@ -303,6 +304,21 @@ int ptgnn_amd_gather_reduce_rows_f32(const float *ysrc, int64_t ld_ysrc,
                                      const int32_t *hub_count /* nullable */, void *hub_ws /* nullable */,
                                      size_t hub_ws_bytes, int32_t *hub_tickets /* nullable */,
                                      int64_t row_begin, int64_t row_end, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MlpMessagePassingLayer, aggregation AND node update in one launch (mlpmessagepassing.py:107-117 with the update
+ * network of :56-66):   out[v, :] = act(W . EPI(reduce over the CSR slots i of row v of msg[col[i] >> type_bits, :]) + b)
+ * i.e. ptgnn_amd_gather_reduce_f32 (no destination term, no argout) followed by ptgnn_amd_linear_f32, bit for bit,
+ * without the [num_nodes, msg_dim] aggregate ever existing in memory.  msg_dim must be 64 (the README's default
+ * architecture; BASELINE config 4), out_dim a multiple of 32 up to 128: ptgnn_amd_gather_update_supported.  Every row
+ * folds serially in slot order (no hub / long-row launches): meant for minibatch-sized plans.
+ * ---------------------------------------------------------------------------------------- */
+int ptgnn_amd_gather_update_supported(int32_t msg_dim, int32_t out_dim);
+int ptgnn_amd_gather_update_f32(const float *msg, int64_t ld_msg, const int32_t *rowptr, const int32_t *col,
+                                int32_t type_bits, int64_t num_nodes, int32_t msg_dim, int reduce, int epilogue,
+                                const float *ln_gamma /* nullable */, const float *ln_beta /* nullable */, float ln_eps,
+                                const float *w /* [out_dim, msg_dim] */, const float *bias /* nullable */,
+                                int32_t out_dim, int act, float *out, int64_t ld_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * reduce = "mul" of the scatter seam: abstractmessagepassing.py:44-50 hands the aggregation name to

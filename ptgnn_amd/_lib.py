@@ -48,6 +48,9 @@ SIGNATURES = {
     "ptgnn_amd_gather_reduce_rows_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i64, _i32, _c.c_int,
                                                     _c.c_int, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _i32, _vp,
                                                     _vp, _vp, _c.c_size_t, _vp, _i64, _i64, _vp]),
+    "ptgnn_amd_gather_update_supported": (_c.c_int, [_i32, _i32]),
+    "ptgnn_amd_gather_update_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _c.c_int, _c.c_int, _vp, _vp, _f32,
+                                               _vp, _vp, _i32, _c.c_int, _vp, _i64, _vp]),
     "ptgnn_amd_gather_reduce_masked_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64,
                                                       _i64, _i32, _vp, _vp, _vp, _c.c_size_t, _vp, _vp]),
     "ptgnn_amd_segment_mul_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),

@@ -33,7 +33,7 @@ extern "C" const char *ptgnn_amd_launch_name(int kernel_id) {
   static const char *const names[PTGNN_AMD_KERNEL_COUNT_] = {
       "k_stream_linear", "k_stream_linear_ring", "k_stream_gru", "k_stream_gru_ring", "k_stream_edge",
       "k_stream_edge_shared", "k_stream_edge_v2", "k_wgrad_stream", "k_linear_tlp", "k_gru", "k_edge_linear",
-      "k_edge_wgrad"};
+      "k_edge_wgrad", "k_gather_update"};
   return kernel_id >= 0 && kernel_id < PTGNN_AMD_KERNEL_COUNT_ ? names[kernel_id] : nullptr;
 }
 

@@ -30,7 +30,7 @@
 
 #include <mutex>
 
-#include "common.h"
+#include "dense_common.h"   // f32x16, kcol(), act_apply(): the fused node update below multiplies like the GEMM kernels
 
 namespace ptgnn_amd {
 namespace {
@@ -327,6 +327,12 @@ struct RowOp {
 
   // mean / empty-segment rule / row epilogue / store
   __device__ __forceinline__ void finish_and_store(int64_t row, int deg) {
+    finish(deg);
+    store(a.out + row * a.ld_out, HAS_ARG ? a.argout + row * (int64_t)M : nullptr);
+  }
+
+  // mean / empty-segment rule / row epilogue, left in `acc`
+  __device__ __forceinline__ void finish(int deg) {
     const int EPI = a.epi;  // wave-uniform
     if (REDUCE == PTGNN_AMD_MEAN) {
       const float cnt = (float)(deg < 1 ? 1 : deg);
@@ -371,7 +377,6 @@ struct RowOp {
           if (colx < M) acc[c][v] = (acc[c][v] - mean) * rstd * a.ln_gamma[colx] + a.ln_beta[colx];
         }
     }
-    store(a.out + row * a.ld_out, HAS_ARG ? a.argout + row * (int64_t)M : nullptr);
   }
 
   __device__ __forceinline__ void load_partial(const float *prow, const int32_t *parow,
@@ -553,6 +558,115 @@ __global__ __launch_bounds__(256) void k_long_rows(Args a) {
         op.finish_and_store(base + b, rdeg);
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// aggregation + node update of the MLP-MP layer in ONE kernel (hidden 64: the README's default architecture, BASELINE
+// config 4):  out[v] = act(W . LayerNorm(GELU(aggregate[v])) + b)       (mlpmessagepassing.py:107-117, :56-66)
+// ------------------------------------------------------------------------------------------------
+// At M = 64 the dense update is a [N, 64] x [64, H'] GEMM with 16 KB of weights: as a launch of its own it reads and
+// writes [N, 64] once more and costs 17-21 us per layer against an ~11 us copy floor (profiles/r04: `linear` 0.33 of the MFMA
+// peak, i.e. it is a memory pass).  Here a workgroup of 8 waves aggregates 32 destination rows exactly as k_gather_reduce
+// does (a row per 16-lane group, CSR order, the same prefetched groups of 8 slots, GELU + LayerNorm in registers), parks
+// the 32 normalised rows in LDS, and H' / 32 of its waves multiply the tile with the weight matrix -- copied into LDS at the
+// start of the workgroup, behind the first gather round trip -- on v_mfma_f32_32x32x2_f32 in the library's one K order
+// (`kcol`), add the bias, apply the activation, and the tile leaves as 256-byte rows.  Same bits as
+// ptgnn_amd_gather_reduce_f32 followed by ptgnn_amd_linear_f32.  The aggregate never exists in memory.
+// Every row folds serially in slot order here, whatever its length (no hub / long-row launches): the host takes this
+// kernel for minibatch-sized plans only, where a row beyond a few hundred in-edges is an oddity, not a workload.
+struct UpdateArgs {
+  const float *w;      // [out_dim, M] row-major (nn.Linear layout)
+  const float *bias;   // nullable
+  int32_t out_dim;     // 32 | 64 | 96 | 128
+  int32_t act;
+  float *out;          // [num_nodes, out_dim]
+  int64_t ld_out;
+};
+
+constexpr int kUpdM = 64;             // message width of the fused form
+constexpr int kUpdLd = kUpdM + 4;     // LDS row stride: 16-byte aligned rows, conflict-free ds_read_b128 of the MFMA fragments
+
+template <int REDUCE>
+__global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
+  extern __shared__ __attribute__((aligned(16))) float upd_smem[];
+  constexpr int LPR = 16, ROWS = 32;
+  float *const Ws = upd_smem;                                   // [out_dim][kUpdLd]
+  float *const As = Ws + u.out_dim * kUpdLd;                    // [32][kUpdLd]  normalised rows
+  float *const Cs = As + ROWS * kUpdLd;                         // [32][out_dim + 4] results
+  const int ldc = u.out_dim + 4;
+  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile >= a.num_tiles) return;                               // workgroup-uniform
+  // the weights: issued first, they travel behind the rowptr / col / row round trips of the gather below
+  // (held in registers until the gather is done: a load -> ds_write pair up front would wait for the load right here)
+  const int wq = u.out_dim * (kUpdM / 4);                        // float4 pieces of W: 512 .. 2048
+  float4 wv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = (int)threadIdx.x + j * 512;
+    const int ic = i < wq ? i : wq - 1;
+    wv[j] = *reinterpret_cast<const float4 *>(u.w + (int64_t)(ic >> 4) * kUpdM + (ic & 15) * 4);
+  }
+  const int grp = threadIdx.x / LPR, g = threadIdx.x % LPR;
+  const int64_t row0 = a.row_begin + tile * ROWS;
+  const int64_t row = row0 + grp;
+  {
+    RowOp<4, LPR, 1, REDUCE, false, false, false> op(a, g, 0);
+    if (row < a.num_nodes) {
+      const int beg = a.rowptr[row], end = a.rowptr[row + 1];
+      op.template reduce_pf<8>(row, beg, end, 1);
+      op.finish(end - beg);
+    } else {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) op.acc[0][v] = 0.f;            // rows past the end: computed, never stored
+    }
+    *reinterpret_cast<float4 *>(As + grp * kUpdLd + g * 4) = make_float4(op.acc[0][0], op.acc[0][1], op.acc[0][2], op.acc[0][3]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = (int)threadIdx.x + j * 512;
+    if (i < wq) *reinterpret_cast<float4 *>(Ws + (i >> 4) * kUpdLd + (i & 15) * 4) = wv[j];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // column block n of the result on wave (n + blockIdx) % 8: consecutive workgroups put their MFMA waves on different SIMDs
+  const int nblk = u.out_dim >> 5;
+  const int n = (wave + 8 - (int)(blockIdx.x & 7)) & 7;
+  if (n < nblk) {
+    const int li = lane & 31, hi = lane >> 5;
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    const float *al = As + li * kUpdLd + hi * 4;
+    const float *bl = Ws + (n * 32 + li) * kUpdLd + hi * 4;
+#pragma unroll
+    for (int ch = 0; ch < kUpdM / 32; ++ch)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {       // steps 4 q .. 4 q + 3 of the chunk: columns 32 ch + 8 q + 4 hi + {0..3} (kcol)
+        const float4 av = *reinterpret_cast<const float4 *>(al + ch * 32 + q * 8);
+        const float4 bv = *reinterpret_cast<const float4 *>(bl + ch * 32 + q * 8);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, c, 0, 0, 0);
+      }
+    const int colx = n * 32 + li;
+    const float b = u.bias ? u.bias[colx] : 0.f;
+    // C fragment: column li, rows (r & 3) + 8 (r >> 2) + 4 hi
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = u.bias ? c[r] + b : c[r];
+      const float o = u.act == PTGNN_AMD_ACT_TANH ? act_apply<PTGNN_AMD_ACT_TANH>(v)
+                      : (u.act == PTGNN_AMD_ACT_RELU ? act_apply<PTGNN_AMD_ACT_RELU>(v) : v);
+      Cs[((r & 3) + 8 * (r >> 2) + 4 * hi) * ldc + colx] = o;
+    }
+  }
+  __syncthreads();
+  const int nq = u.out_dim >> 2;                                  // float4 per output row
+  for (int i = threadIdx.x; i < ROWS * nq; i += 512) {
+    const int r = i / nq, q = i - r * nq;
+    if (row0 + r < a.num_nodes)
+      *reinterpret_cast<float4 *>(u.out + (row0 + r) * u.ld_out + q * 4) = *reinterpret_cast<const float4 *>(Cs + r * ldc + q * 4);
   }
 }
 
@@ -841,6 +955,51 @@ extern "C" int ptgnn_amd_gather_reduce_rows_f32(const float *ysrc, int64_t ld_y,
   return dispatch_geometry(vec4, msg_dim, row_epi, [&](auto V, auto L, auto C, int col_blocks) {
     return launch1<decltype(V)::value, decltype(L)::value, decltype(C)::value>(a, reduce, col_blocks, stream);
   });
+}
+
+extern "C" int ptgnn_amd_gather_update_supported(int32_t msg_dim, int32_t out_dim) {
+  return msg_dim == kUpdM && out_dim >= 32 && out_dim <= 128 && out_dim % 32 == 0 ? 1 : 0;
+}
+
+extern "C" int ptgnn_amd_gather_update_f32(const float *msg, int64_t ld_msg, const int32_t *rowptr, const int32_t *col,
+                                           int32_t type_bits, int64_t num_nodes, int32_t msg_dim, int reduce,
+                                           int epilogue, const float *ln_gamma, const float *ln_beta, float ln_eps,
+                                           const float *w, const float *bias, int32_t out_dim, int act, float *out,
+                                           int64_t ld_out, void *stream_) {
+  PTGNN_REQUIRE(num_nodes >= 0, PTGNN_AMD_EINVAL, "gather_update: bad sizes");
+  PTGNN_REQUIRE(reduce >= PTGNN_AMD_SUM && reduce <= PTGNN_AMD_MIN, PTGNN_AMD_EINVAL, "gather_update: unknown reduce %d", reduce);
+  PTGNN_REQUIRE(epilogue >= 0 && epilogue <= 3, PTGNN_AMD_EINVAL, "gather_update: bad epilogue");
+  PTGNN_REQUIRE(act >= 0 && act <= PTGNN_AMD_ACT_RELU, PTGNN_AMD_EINVAL, "gather_update: bad act");
+  PTGNN_REQUIRE(type_bits >= 0 && type_bits < 16, PTGNN_AMD_EINVAL, "gather_update: bad type_bits");
+  PTGNN_REQUIRE(ptgnn_amd_gather_update_supported(msg_dim, out_dim), PTGNN_AMD_EUNSUPPORTED,
+                "gather_update: msg_dim=%d out_dim=%d is not a shape of the fused kernel (msg_dim 64, out_dim 32..128 in "
+                "steps of 32)", msg_dim, out_dim);
+  if (num_nodes == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(msg && rowptr && col && w && out && ld_out >= out_dim, PTGNN_AMD_EINVAL, "gather_update: null/ld");
+  PTGNN_REQUIRE(!(epilogue & PTGNN_AMD_EPI_LAYERNORM) || (ln_gamma && ln_beta), PTGNN_AMD_EINVAL,
+                "gather_update: LayerNorm epilogue needs gamma/beta");
+  PTGNN_REQUIRE(ld_msg % 4 == 0 && ld_out % 4 == 0 && aligned16(msg) && aligned16(out) && aligned16(w), PTGNN_AMD_EUNSUPPORTED,
+                "gather_update: rows must be 16-byte aligned");
+  Args a{};
+  a.ysrc = msg; a.ydst = nullptr; a.ld_y = ld_msg; a.ld_yd = ld_msg;
+  a.rowptr = rowptr; a.col = col; a.type_bits = type_bits; a.num_nodes = num_nodes; a.row_begin = 0; a.msg_dim = msg_dim;
+  a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.out = nullptr; a.ld_out = 0; a.argout = nullptr;
+  a.epi = epilogue;
+  a.num_tiles = (num_nodes + 31) / 32;
+  UpdateArgs u;
+  u.w = w; u.bias = bias; u.out_dim = out_dim; u.act = act; u.out = out; u.ld_out = ld_out;
+  const size_t lds = ((size_t)out_dim * kUpdLd + 32 * kUpdLd + 32 * (out_dim + 4)) * sizeof(float);
+  const unsigned grid = (unsigned)xcd_padded_blocks(a.num_tiles);
+  hipStream_t st = (hipStream_t)stream_;
+  switch (reduce) {
+    case PTGNN_AMD_SUM: k_gather_update<PTGNN_AMD_SUM><<<grid, 512, lds, st>>>(a, u); break;
+    case PTGNN_AMD_MEAN: k_gather_update<PTGNN_AMD_MEAN><<<grid, 512, lds, st>>>(a, u); break;
+    case PTGNN_AMD_MAX: k_gather_update<PTGNN_AMD_MAX><<<grid, 512, lds, st>>>(a, u); break;
+    default: k_gather_update<PTGNN_AMD_MIN><<<grid, 512, lds, st>>>(a, u); break;
+  }
+  PTGNN_LAUNCH_CHECK();
+  count_launch(PTGNN_AMD_KERNEL_GATHER_UPDATE);
+  return PTGNN_AMD_OK;
 }
 
 extern "C" int ptgnn_amd_gather_reduce_masked_f32(const float *grad, int64_t ld_grad,

@@ -592,6 +592,20 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
             from ptgnn_amd import sharded
             shard, work, table_of = two_block
             agg = sharded.aggregate_two_blocks(shard, work, table_of, M, self.__aggregation_fn, ydst=ydst, **epi)
+        elif (fused and ydst is None and self._dense is not None
+              and (self._dense_act is None or isinstance(self._dense_act, (nn.Tanh, nn.ReLU)))
+              and not (self.training and getattr(self._dropout, "p", 0.0) > 0)
+              and ops.gather_update_supported(M, self._dense.out_features, plan)
+              and _no_grad_needed(ysrc, *self._dense.parameters())):
+            # hidden 64 (the README's default architecture, BASELINE config 4), edge form: aggregation, GELU, LayerNorm,
+            # Linear and Tanh in ONE launch -- the [N, M] aggregate never exists in memory (gather_reduce.hip)
+            act = "tanh" if isinstance(self._dense_act, nn.Tanh) else ("relu" if isinstance(self._dense_act, nn.ReLU) else None)
+            hint = _take_output_hint(plan.num_nodes, self._dense.out_features, ysrc)
+            out = ops.gather_update(ysrc, plan, self.__aggregation_fn, plan.col if col is None else col,
+                                    plan.type_bits if type_bits is None else type_bits, epi.get("epilogue", 0),
+                                    epi.get("ln_weight"), epi.get("ln_bias"), epi.get("ln_eps", 1e-5),
+                                    self._dense.weight, self._dense.bias, act, out=hint)
+            return self._dropout(out)
         else:
             agg = ops.gather_reduce(ysrc, plan, M, self.__aggregation_fn, ydst=ydst, col=col, type_bits=type_bits, **epi)
         return self._update(agg, fused)

@@ -770,6 +770,50 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
     return (out, arg) if return_arg else out
 
 
+# The fused aggregation + node update serves minibatch-sized plans (every row folds serially: no hub launches)
+GATHER_UPDATE = os.environ.get("PTGNN_AMD_GATHER_UPDATE", "1") not in ("", "0")
+GATHER_UPDATE_MAX_EDGES = 1 << 21
+
+
+def gather_update_supported(msg_dim: int, out_dim: int, plan: "GraphPlan") -> bool:
+    return (GATHER_UPDATE and plan.num_edges < GATHER_UPDATE_MAX_EDGES
+            and bool(_lib.load().ptgnn_amd_gather_update_supported(int(msg_dim), int(out_dim))))
+
+
+def gather_update(msgs: torch.Tensor, plan: GraphPlan, reduce: str, col: torch.Tensor, type_bits: int, epilogue: int,
+                  ln_weight: Optional[torch.Tensor], ln_bias: Optional[torch.Tensor], ln_eps: float,
+                  weight: torch.Tensor, bias: Optional[torch.Tensor], act: Optional[str],
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(W . EPI(reduce_{slots of v} msgs[col >> type_bits]) + b) in ONE launch (ptgnn_amd_gather_update_f32): the
+    aggregation of `gather_reduce` and the Linear of `linear`, same bits, without the [N, M] aggregate in memory."""
+    lib = _lib.load()
+    _require_cuda_f32("msgs", msgs)
+    _require_cuda_f32("weight", weight)
+    msgs, weight = _rowmajor(msgs), weight.contiguous()
+    N, M, out_dim = plan.num_nodes, msgs.shape[1], weight.shape[0]
+    if weight.shape[1] != M or reduce not in REDUCE_IDS:
+        raise _lib.PtgnnAmdError(f"gather_update: weight {tuple(weight.shape)} / reduce {reduce!r} do not fit messages of width {M}")
+    if out is None:
+        out = torch.empty(N, out_dim, dtype=torch.float32, device=msgs.device)
+    elif tuple(out.shape) != (N, out_dim) or out.dtype != torch.float32 or out.stride(1) != 1 or not out.is_cuda:
+        raise _lib.PtgnnAmdError(f"gather_update: `out` must be a float32 CUDA [{N}, {out_dim}] view with unit inner stride")
+    if epilogue & EPI_LAYERNORM:
+        ln_weight, ln_bias = ln_weight.contiguous(), ln_bias.contiguous()
+    if bias is not None:
+        bias = bias.contiguous()
+    plan.wait()
+    E = plan.num_edges
+    with _timed("gather_update", bytes=E * (4.0 * M + 4) + N * (4.0 * out_dim + 4) + 4.0 * out_dim * M,
+                flops=2.0 * N * M * out_dim):
+        rc = lib.ptgnn_amd_gather_update_f32(
+            msgs.data_ptr(), _ld(msgs), plan.rowptr.data_ptr(), col.data_ptr(), int(type_bits), N, M, REDUCE_IDS[reduce],
+            int(epilogue), ln_weight.data_ptr() if epilogue & EPI_LAYERNORM else None,
+            ln_bias.data_ptr() if epilogue & EPI_LAYERNORM else None, float(ln_eps), weight.data_ptr(),
+            bias.data_ptr() if bias is not None else None, out_dim, ACT_IDS[act], out.data_ptr(), _ld(out), _stream(out))
+    _lib.check(rc, "ptgnn_amd_gather_update_f32")
+    return out
+
+
 def gather_reduce_masked(grad: torch.Tensor, arg: torch.Tensor, bplan: GraphPlan,
                          slot_of: torch.Tensor, msg_dim: int) -> torch.Tensor:
     """out[r] = sum_{i in row r} [arg[col_i] == slot_of[i]] * grad[col_i] over a backward plan."""
