@@ -79,15 +79,14 @@ enum { PTGNN_AMD_ACT_NONE = 0, PTGNN_AMD_ACT_TANH = 1, PTGNN_AMD_ACT_RELU = 2 };
 int ptgnn_amd_version(void);
 const char *ptgnn_amd_last_error(void);
 
-/* Arithmetic / kernel family of the dense blocks (ptgnn_amd_linear_f32, ptgnn_amd_gru_cell*_f32,
+/* Kernel family of the dense blocks (ptgnn_amd_linear_f32, ptgnn_amd_gru_cell*_f32,
  * ptgnn_amd_edge_linear_f32) -- i.e. of what replaces nn.Linear / nn.GRUCell at
  * gatedmessagepassing.py:57-69 and mlpmessagepassing.py:96-117.  Process-wide; initial value from the
  * environment variable PTGNN_AMD_GEMM (default 1).
  *   0  128 x 128 tile kernels, exact fp32 MFMA
  *   1  streaming weight-stationary kernels, exact fp32 MFMA (v_mfma_f32_32x32x2_f32: an fmaf chain)
- *   2  streaming kernels, "f32 via 3xbf16 split": operands split exactly into 3 bf16 pieces, the 6 largest
- *      piece products on the bf16 MFMA with fp32 accumulation (error vs float64 = that of mode 1; results
- *      are not bit-identical to mode 0/1).  Shapes a mode does not tile run on mode 0. */
+ * Both produce the same bits (one K accumulation order); shapes the streaming kernels do not tile run on mode 0.
+ * (Mode 2 of rounds 2-4 -- f32 emulated by a 3 x bf16 operand split -- was removed in round 5; it answers EINVAL.) */
 int ptgnn_amd_set_gemm_mode(int mode);
 int ptgnn_amd_get_gemm_mode(void);
 

@@ -587,13 +587,20 @@ struct UpdateArgs {
 constexpr int kUpdM = 64;             // message width of the fused form
 constexpr int kUpdLd = kUpdM + 4;     // LDS row stride: 16-byte aligned rows, conflict-free ds_read_b128 of the MFMA fragments
 
-template <int REDUCE>
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+
+// M16 = true: the tile product on v_mfma_f32_16x16x4_f32, one 16 x 16 output tile per wave -- all eight waves of the
+// workgroup multiply (16 MFMAs each) instead of out_dim / 32 waves with 32 MFMAs of 32x32x2 each while the others wait: the
+// tail behind the gather, during which the workgroup holds its wave slots and LDS without issuing loads, shrinks 4x.
+// The four k of an instruction are (kcol(s), kcol(s) + 4, kcol(s + 1), kcol(s + 1) + 4): the products of a row meet the
+// accumulator in the SAME order as in two 32x32x2 steps, hence the same bits (asserted on the GPU, tests/test_gpu_gather_update.py).
+template <int REDUCE, bool M16>
 __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
   extern __shared__ __attribute__((aligned(16))) float upd_smem[];
   constexpr int LPR = 16, ROWS = 32;
   float *const Ws = upd_smem;                                   // [out_dim][kUpdLd]
   float *const As = Ws + u.out_dim * kUpdLd;                    // [32][kUpdLd]  normalised rows
-  float *const Cs = As + ROWS * kUpdLd;                         // [32][out_dim + 4] results
+  float *const Cs = As + ROWS * kUpdLd;                         // [32][out_dim + 4] results (32x32x2 form only)
   const int ldc = u.out_dim + 4;
   const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= a.num_tiles) return;                               // workgroup-uniform
@@ -629,6 +636,39 @@ __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto activate = [&](float v) {
+    return u.act == PTGNN_AMD_ACT_TANH ? act_apply<PTGNN_AMD_ACT_TANH>(v)
+                                       : (u.act == PTGNN_AMD_ACT_RELU ? act_apply<PTGNN_AMD_ACT_RELU>(v) : v);
+  };
+  if constexpr (M16) {
+    // tile t = (row half, 16-column block): waves stride over the 2 * out_dim / 16 tiles (8 at out_dim 64: one each)
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int koff = (kq & 1) * 4 + (kq >> 1);                   // this lane's k inside an instruction: base + {0, 4, 1, 5}[kq]
+    const int ntiles = u.out_dim >> 3;                           // 2 * (out_dim / 16)
+    for (int t = wave; t < ntiles; t += 8) {
+      const int rh = t & 1, cb = t >> 1;
+      const float *al = As + (rh * 16 + r16) * kUpdLd + koff;
+      const float *bl = Ws + (cb * 16 + r16) * kUpdLd + koff;
+      f32x4v c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ch = 0; ch < kUpdM / 32; ++ch)
+#pragma unroll
+        for (int jp = 0; jp < 8; ++jp) {                          // MFMA steps 2 jp, 2 jp + 1 of the 32x32x2 kernels
+          const int base = ch * 32 + (jp >> 1) * 8 + (jp & 1) * 2;
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(al[base], bl[base], c, 0, 0, 0);
+        }
+      const int colx = cb * 16 + r16;
+      const float b = u.bias ? u.bias[colx] : 0.f;
+      // C fragment: column r16, rows 4 kq + {0..3} of the 16-row half
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t orow = row0 + rh * 16 + 4 * kq + i;
+        const float v = u.bias ? c[i] + b : c[i];
+        if (orow < a.num_nodes) u.out[orow * u.ld_out + colx] = activate(v);
+      }
+    }
+    return;
+  }
   // column block n of the result on wave (n + blockIdx) % 8: consecutive workgroups put their MFMA waves on different SIMDs
   const int nblk = u.out_dim >> 5;
   const int n = (wave + 8 - (int)(blockIdx.x & 7)) & 7;
@@ -656,9 +696,7 @@ __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float v = u.bias ? c[r] + b : c[r];
-      const float o = u.act == PTGNN_AMD_ACT_TANH ? act_apply<PTGNN_AMD_ACT_TANH>(v)
-                      : (u.act == PTGNN_AMD_ACT_RELU ? act_apply<PTGNN_AMD_ACT_RELU>(v) : v);
-      Cs[((r & 3) + 8 * (r >> 2) + 4 * hi) * ldc + colx] = o;
+      Cs[((r & 3) + 8 * (r >> 2) + 4 * hi) * ldc + colx] = activate(v);
     }
   }
   __syncthreads();
@@ -988,15 +1026,24 @@ extern "C" int ptgnn_amd_gather_update_f32(const float *msg, int64_t ld_msg, con
   a.num_tiles = (num_nodes + 31) / 32;
   UpdateArgs u;
   u.w = w; u.bias = bias; u.out_dim = out_dim; u.act = act; u.out = out; u.ld_out = ld_out;
-  const size_t lds = ((size_t)out_dim * kUpdLd + 32 * kUpdLd + 32 * (out_dim + 4)) * sizeof(float);
+  // A/B + bit-identity test knob: PTGNN_AMD_GATHER_UPDATE_MFMA=32 takes the 32x32x2 form of the tile product
+  const char *mf = getenv("PTGNN_AMD_GATHER_UPDATE_MFMA");
+  const bool m16 = !(mf && mf[0] == '3');
+  const size_t lds = ((size_t)out_dim * kUpdLd + 32 * kUpdLd + (m16 ? 0 : 32 * (out_dim + 4))) * sizeof(float);
   const unsigned grid = (unsigned)xcd_padded_blocks(a.num_tiles);
   hipStream_t st = (hipStream_t)stream_;
+#define PTGNN_GU(R)                                                          \
+  do {                                                                       \
+    if (m16) k_gather_update<R, true><<<grid, 512, lds, st>>>(a, u);         \
+    else k_gather_update<R, false><<<grid, 512, lds, st>>>(a, u);            \
+  } while (0)
   switch (reduce) {
-    case PTGNN_AMD_SUM: k_gather_update<PTGNN_AMD_SUM><<<grid, 512, lds, st>>>(a, u); break;
-    case PTGNN_AMD_MEAN: k_gather_update<PTGNN_AMD_MEAN><<<grid, 512, lds, st>>>(a, u); break;
-    case PTGNN_AMD_MAX: k_gather_update<PTGNN_AMD_MAX><<<grid, 512, lds, st>>>(a, u); break;
-    default: k_gather_update<PTGNN_AMD_MIN><<<grid, 512, lds, st>>>(a, u); break;
+    case PTGNN_AMD_SUM: PTGNN_GU(PTGNN_AMD_SUM); break;
+    case PTGNN_AMD_MEAN: PTGNN_GU(PTGNN_AMD_MEAN); break;
+    case PTGNN_AMD_MAX: PTGNN_GU(PTGNN_AMD_MAX); break;
+    default: PTGNN_GU(PTGNN_AMD_MIN); break;
   }
+#undef PTGNN_GU
   PTGNN_LAUNCH_CHECK();
   count_launch(PTGNN_AMD_KERNEL_GATHER_UPDATE);
   return PTGNN_AMD_OK;

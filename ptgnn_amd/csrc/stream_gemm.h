@@ -20,7 +20,7 @@ struct StreamEdgeTable {
 
 int num_compute_units();
 
-int stream_gemm_mode();          // 0 tile kernels, 1 streaming exact fp32, 2 streaming 3xbf16 split
+int stream_gemm_mode();          // 0 tile kernels, 1 streaming kernels (both exact fp32, same bits)
 void stream_gemm_set_mode(int mode);
 
 // `addend` (nullable): y = act(x W^T + b) + addend, [rows, n_out] with leading dimension ld_add

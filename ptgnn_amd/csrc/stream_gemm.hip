@@ -33,14 +33,16 @@
 // The accumulation order over K inside a row is ONE fixed permutation shared with the tile kernels, so a
 // result does not depend on the kernel, the tile position, the shard or the layer form that produced it.
 //
-// Arithmetic modes (ptgnn_amd_set_gemm_mode / PTGNN_AMD_GEMM):
-//   1  exact fp32: v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain (default);
-//   2  "f32 via 3xbf16 split": every operand is split exactly into three bf16 pieces (8+8+8 significand
-//      bits) and the product formed from the six largest piece products on v_mfma_f32_32x32x16_bf16 with
-//      fp32 accumulation (dropped terms <= 2^-24 |a b|).  Same error against float64 as mode 1, not
-//      bit-identical to it; opt-in.
-//   0  the round-1 tile kernels (dense_f32.hip / edge_gemm.hip), also the fallback for shapes this file
-//      does not take (K % 64 != 0, unaligned rows, slabs that do not fit LDS).
+// Kernel families (ptgnn_amd_set_gemm_mode / PTGNN_AMD_GEMM), both exact fp32 -- v_mfma_f32_32x32x2_f32, bit for bit an
+// fmaf chain in ONE K order:
+//   1  the streaming kernels of this file (default);
+//   0  the round-1 tile kernels (dense_f32.hip / edge_gemm.hip), also the fallback for shapes this file does not take
+//      (K % 64 != 0, unaligned rows, slabs that do not fit LDS).
+// (Rounds 2-4 carried a third, opt-in mode: f32 emulated by an exact 3 x bf16 operand split on the bf16 MFMA.  It ran
+//  the headline step 1.17x faster at the same error against float64, never reached a useful fraction of the bf16 peak
+//  -- 0.35 of a six-product ceiling: the unit is bound by its ~40 wave-wide memory instructions, not by the split VALU --
+//  and was removed in round 5 rather than carried as a second arithmetic nobody benchmarks against;
+//  profiles/r02_notes.md, r04_notes.md and DESIGN.md 9 hold its numbers.)
 #include <stdlib.h>
 
 #include <mutex>
@@ -52,7 +54,6 @@
 namespace ptgnn_amd {
 namespace {
 
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
 constexpr int kLdsBudget = 160 * 1024;
@@ -73,35 +74,17 @@ struct ARows {
 
 // float4 piece g of chunk cc of the lane's row; cc >= nch addresses the NEXT unit (cross-unit prefetch).
 // All conditions are wave-uniform: selects, no branches (a branch around a load costs a vmcnt(0) drain).
-template <bool SPLIT>
 __device__ __forceinline__ float4 load_piece(const ARows &r, int cc, int ch0, int nch, int g) {
   const bool nx = cc >= nch;
   const int c = nx ? cc - nch : cc;
   const float *b0 = nx ? r.n0 : r.c0;
   const float *b1 = nx ? r.n1 : r.c1;
   const float *p = c < ch0 ? b0 + c * 32 : b1 + (c - ch0) * 32;
-  // fp32 MFMA (K = 2 per step): pieces 8g + 4hi;  bf16 MFMA (K = 16 per step): pieces 16 (g>>1) + 8hi + 4 (g&1)
-  const int off = SPLIT ? (g >> 1) * 16 + (g & 1) * 4 : g * 8;
-  return *reinterpret_cast<const float4 *>(p + off);
+  // fp32 MFMA (K = 2 per step): pieces 8 g + 4 hi
+  return *reinterpret_cast<const float4 *>(p + g * 8);
 }
 
-template <bool SPLIT>
-__device__ __forceinline__ int lane_piece_offset(int hi) { return SPLIT ? hi * 8 : hi * 4; }
-
-// ---- exact 3-way bf16 split ---------------------------------------------------------------------
-// two fp32 -> one dword of two bf16 (element 0 in the low half) per piece.  v_perm_b32 picks the upper
-// halves of both inputs in one op, so only the values that feed a subtraction need the explicit mask.
-__device__ __forceinline__ uint32_t pack_hi16(float x0, float x1) {
-  return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-}
-__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
-  const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
-  const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
-  const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
-  const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
-  h = pack_hi16(x0, x1); m = pack_hi16(r0, r1); l = pack_hi16(q0, q1);
-}
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ int lane_piece_offset(int hi) { return hi * 4; }
 
 // ---- one K chunk (32 columns) of one unit ---------------------------------------------------------
 // NBLK column blocks of the slab per step; GRU maps block 2 to accumulator 3 in phase 1 (h_n).
@@ -136,76 +119,20 @@ __device__ __forceinline__ void chunk_f32(f32x16 (&acc)[NACC], float4 (&buf)[4],
   }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    buf[g] = load_piece<false>(rows, cnext, ch0, nch, g);
+    buf[g] = load_piece(rows, cnext, ch0, nch, g);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// split mode: the slab holds three bf16 planes (hi | mid | lo), each [rows][ldb] bf16; `bl` is the lane's
-// base in plane 0 (uint16 units), `plane` the plane stride, cbs the column-block stride.
-template <int NBLK, int NACC, int PH, bool GRU>
-__device__ __forceinline__ void chunk_split(f32x16 (&acc)[NACC], float4 (&buf)[4], const uint16_t *bl, int cbs,
-                                            int plane, int kofs, const ARows &rows, int cnext, int ch0,
-                                            int nch) {
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {   // two bf16 MFMA K-steps of 16 per chunk
-    const float4 v0 = buf[2 * s], v1 = buf[2 * s + 1];
-    u32x4 ah, am, al;
-    {
-      uint32_t h, m, l;
-      split_pair(v0.x, v0.y, h, m, l); ah[0] = h; am[0] = m; al[0] = l;
-      split_pair(v0.z, v0.w, h, m, l); ah[1] = h; am[1] = m; al[1] = l;
-      split_pair(v1.x, v1.y, h, m, l); ah[2] = h; am[2] = m; al[2] = l;
-      split_pair(v1.z, v1.w, h, m, l); ah[3] = h; am[3] = m; al[3] = l;
-    }
-    buf[2 * s] = load_piece<true>(rows, cnext, ch0, nch, 2 * s);
-    __builtin_amdgcn_sched_barrier(0);   // keep the refill order = the prologue order (counted vmcnt)
-    buf[2 * s + 1] = load_piece<true>(rows, cnext, ch0, nch, 2 * s + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    const bf16x8 a1 = as_bf16x8(ah), a2 = as_bf16x8(am), a3 = as_bf16x8(al);
-#pragma unroll
-    for (int n = 0; n < NBLK; ++n) {
-      const uint16_t *p = bl + n * cbs + kofs + s * 16;
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(p);
-      const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(p + plane);
-      const bf16x8 b3 = *reinterpret_cast<const bf16x8 *>(p + 2 * plane);
-      const int t = (GRU && PH == 1 && n == 2) ? 3 : n;
-      f32x16 c = acc[t];   // smallest terms first
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
-      acc[t] = c;
-    }
-  }
-}
-
-// The slab in LDS.  fp32: [rows][K + 4] floats.  split: 3 planes of [rows][K + 8] bf16.
-template <bool SPLIT>
+// The slab in LDS: [rows][K + 4] floats.
 struct Slab {
-  int ld;       // row stride (floats | bf16)
-  int plane;    // plane stride in bf16 (split only)
-  __device__ __forceinline__ Slab(int K, int rows) {
-    ld = SPLIT ? K + 8 : K + 4;
-    plane = rows * ld;
-  }
-  static size_t bytes(int K, int rows) { return SPLIT ? (size_t)3 * rows * (K + 8) * 2 : (size_t)rows * (K + 4) * 4; }
+  int ld;       // row stride in floats
+  __device__ __forceinline__ Slab(int K, int /*rows*/) { ld = K + 4; }
+  static size_t bytes(int K, int rows) { return (size_t)rows * (K + 4) * 4; }
 
   // store 4 consecutive K values of slab row r
   __device__ __forceinline__ void put4(float *smem, int r, int k, float4 v) const {
-    if constexpr (!SPLIT) {
-      *reinterpret_cast<float4 *>(smem + r * ld + k) = v;
-    } else {
-      uint16_t *p = reinterpret_cast<uint16_t *>(smem) + r * ld + k;
-      uint32_t h0, m0, l0, h1, m1, l1;
-      split_pair(v.x, v.y, h0, m0, l0);
-      split_pair(v.z, v.w, h1, m1, l1);
-      *reinterpret_cast<uint2 *>(p) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2 *>(p + plane) = make_uint2(m0, m1);
-      *reinterpret_cast<uint2 *>(p + 2 * plane) = make_uint2(l0, l1);
-    }
+    *reinterpret_cast<float4 *>(smem + r * ld + k) = v;
   }
 };
 
@@ -213,8 +140,8 @@ struct Slab {
 // row is real (else zeros).  The loads of a batch of 8 are ALL issued before the first LDS store: written as one load ->
 // store per iteration the compiler waits for every float4 at once, and the fill is 8-18 dependent L2 round trips --
 // 4-9 us of every launch, most of the kernels' size-independent cost (profiles/r04_notes.md 9).
-template <bool SPLIT, int NT, typename SrcFn, typename LiveFn>
-__device__ __forceinline__ void fill_slab(float *smem, const Slab<SPLIT> &sl, int rows, int kq, SrcFn src, LiveFn live) {
+template <int NT, typename SrcFn, typename LiveFn>
+__device__ __forceinline__ void fill_slab(float *smem, const Slab &sl, int rows, int kq, SrcFn src, LiveFn live) {
   constexpr int UB = 8;
   const int total = rows * kq;
   for (int i0 = threadIdx.x; i0 < total; i0 += NT * UB) {
@@ -241,42 +168,26 @@ __device__ __forceinline__ void fill_slab(float *smem, const Slab<SPLIT> &sl, in
 
 // K loop of one unit: chunks [0, ch0) are phase 0, [ch0, nch) phase 1; a0/a1 hold chunks 0/1 on entry
 // and the next unit's chunks 0/1 on exit.  ch0 and nch are even.
-template <int NBLK, int NACC, bool GRU, bool SPLIT>
+template <int NBLK, int NACC, bool GRU>
 __device__ __forceinline__ void unit_kloop(f32x16 (&acc)[NACC], float4 (&a0)[4], float4 (&a1)[4],
-                                           const float *smem, const Slab<SPLIT> &sl, int li, int hi,
+                                           const float *smem, const Slab &sl, int li, int hi,
                                            const ARows &rows, int ch0, int nch) {
-  if constexpr (!SPLIT) {
-    const float *bl = smem + li * sl.ld + hi * 4;
-    const int cbs = 32 * sl.ld;
-    const int e0 = GRU ? ch0 : nch;
-    float4 bcur[NBLK];
+  const float *bl = smem + li * sl.ld + hi * 4;
+  const int cbs = 32 * sl.ld;
+  const int e0 = GRU ? ch0 : nch;
+  float4 bcur[NBLK];
 #pragma unroll
-    for (int n = 0; n < NBLK; ++n) bcur[n] = *reinterpret_cast<const float4 *>(bl + n * cbs);
-    for (int c = 0; c < e0; c += 2) {
-      const int kn = c + 2 < nch ? c * 32 + 64 : 0;   // the chunk after next (0: first chunk of the next unit)
-      chunk_f32<NBLK, NACC, 0, GRU>(acc, a0, bcur, bl, cbs, c * 32, c * 32 + 32, rows, c + 2, ch0, nch);
-      chunk_f32<NBLK, NACC, 0, GRU>(acc, a1, bcur, bl, cbs, c * 32 + 32, kn, rows, c + 3, ch0, nch);
-    }
-    if constexpr (GRU) {
-      for (int c = ch0; c < nch; c += 2) {
-        const int kn = c + 2 < nch ? c * 32 + 64 : 0;
-        chunk_f32<NBLK, NACC, 1, GRU>(acc, a0, bcur, bl, cbs, c * 32, c * 32 + 32, rows, c + 2, ch0, nch);
-        chunk_f32<NBLK, NACC, 1, GRU>(acc, a1, bcur, bl, cbs, c * 32 + 32, kn, rows, c + 3, ch0, nch);
-      }
-    }
-  } else {
-    const uint16_t *bl = reinterpret_cast<const uint16_t *>(smem) + li * sl.ld + hi * 8;
-    const int cbs = 32 * sl.ld;
-    const int e0 = GRU ? ch0 : nch;
-    for (int c = 0; c < e0; c += 2) {
-      chunk_split<NBLK, NACC, 0, GRU>(acc, a0, bl, cbs, sl.plane, c * 32, rows, c + 2, ch0, nch);
-      chunk_split<NBLK, NACC, 0, GRU>(acc, a1, bl, cbs, sl.plane, c * 32 + 32, rows, c + 3, ch0, nch);
-    }
-    if constexpr (GRU) {
-      for (int c = ch0; c < nch; c += 2) {
-        chunk_split<NBLK, NACC, 1, GRU>(acc, a0, bl, cbs, sl.plane, c * 32, rows, c + 2, ch0, nch);
-        chunk_split<NBLK, NACC, 1, GRU>(acc, a1, bl, cbs, sl.plane, c * 32 + 32, rows, c + 3, ch0, nch);
-      }
+  for (int n = 0; n < NBLK; ++n) bcur[n] = *reinterpret_cast<const float4 *>(bl + n * cbs);
+  for (int c = 0; c < e0; c += 2) {
+    const int kn = c + 2 < nch ? c * 32 + 64 : 0;   // the chunk after next (0: first chunk of the next unit)
+    chunk_f32<NBLK, NACC, 0, GRU>(acc, a0, bcur, bl, cbs, c * 32, c * 32 + 32, rows, c + 2, ch0, nch);
+    chunk_f32<NBLK, NACC, 0, GRU>(acc, a1, bcur, bl, cbs, c * 32 + 32, kn, rows, c + 3, ch0, nch);
+  }
+  if constexpr (GRU) {
+    for (int c = ch0; c < nch; c += 2) {
+      const int kn = c + 2 < nch ? c * 32 + 64 : 0;
+      chunk_f32<NBLK, NACC, 1, GRU>(acc, a0, bcur, bl, cbs, c * 32, c * 32 + 32, rows, c + 2, ch0, nch);
+      chunk_f32<NBLK, NACC, 1, GRU>(acc, a1, bcur, bl, cbs, c * 32 + 32, kn, rows, c + 3, ch0, nch);
     }
   }
 }
@@ -286,17 +197,16 @@ __device__ __forceinline__ void unit_kloop(f32x16 (&acc)[NACC], float4 (&a0)[4],
 // the first unit's loads are pinned in steady-state order, and each unit starts from a drained queue
 // (`unit_fence`): the epilogue's stores share the counter with the prefetched loads, and a mixed
 // load/store queue makes the compiler fall back to vmcnt(0) on EVERY chunk instead of once per unit.
-template <bool SPLIT>
 __device__ __forceinline__ void prologue_loads(float4 (&a0)[4], float4 (&a1)[4], const ARows &rows, int ch0,
                                                int nch) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    a0[g] = load_piece<SPLIT>(rows, 0, ch0, nch, g);
+    a0[g] = load_piece(rows, 0, ch0, nch, g);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    a1[g] = load_piece<SPLIT>(rows, 1, ch0, nch, g);
+    a1[g] = load_piece(rows, 1, ch0, nch, g);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -471,7 +381,7 @@ __device__ __forceinline__ void linear_epilogue(const LinearArgs &p, f32x16 (&ac
   }
 }
 
-template <int NB, bool SPLIT>
+template <int NB>
 __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 512, BN = 32 * NB;
@@ -490,12 +400,12 @@ __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
   if (rb0 >= rb1) return;
   const int count = rb1 - rb0;
 
-  const Slab<SPLIT> sl(p.K, BN);
+  const Slab sl(p.K, BN);
   int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
   float *const tq = smem + p.lds_floats + 4 + (threadIdx.x >> 6) * kTqFloats;   // this wave's transposing slab
   if (threadIdx.x == 0) *counter = 0;
   const int col_base = slab * BN;
-  fill_slab<SPLIT, NT>(smem, sl, BN, p.K >> 2,
+  fill_slab<NT>(smem, sl, BN, p.K >> 2,
                        [&](int r, int q) {
                          const int wr = col_base + r < p.n_out ? col_base + r : p.n_out - 1;
                          return p.w + (int64_t)wr * p.K + q * 4;
@@ -506,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int nch = p.K >> 5;
-  const int lofs = lane_piece_offset<SPLIT>(hi);
+  const int lofs = lane_piece_offset(hi);
   auto rowp = [&](int u) {   // u: unit index inside the run (clamped to the run)
     int64_t row = (int64_t)(rb0 + (u < count ? u : count - 1)) * 32 + li;
     row = row < p.rows ? row : p.rows - 1;
@@ -519,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
   rows.c0 = rows.c1 = rowp(cur);
   rows.n0 = rows.n1 = rowp(nxt);
   float4 a0[4], a1[4];
-  prologue_loads<SPLIT>(a0, a1, rows, nch, nch);
+  prologue_loads(a0, a1, rows, nch, nch);
   f32x16 acc[NB];
 #pragma unroll
   for (int n = 0; n < NB; ++n) acc[n] = zero16();
@@ -527,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_linear(LinearArgs p) {
   while (cur < count) {
     const int nn = claim_unit(counter);
     unit_fence();
-    unit_kloop<NB, NB, false, SPLIT>(acc, a0, a1, smem, sl, li, hi, rows, nch, nch);
+    unit_kloop<NB, NB, false>(acc, a0, a1, smem, sl, li, hi, rows, nch, nch);
     const int64_t row0 = (int64_t)(rb0 + cur) * 32;
     linear_epilogue<NB>(p, acc, tq, row0, col_base, lane, li, hi);
     cur = nxt;
@@ -638,7 +548,6 @@ __device__ __forceinline__ void gru_epilogue(const GruArgs &p, const f32x16 (&ac
   }
 }
 
-template <bool SPLIT>
 __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 512;
@@ -658,14 +567,14 @@ __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
   const int count = rb1 - rb0;
 
   const int K = p.M + p.H;
-  const Slab<SPLIT> sl(K, 96);
+  const Slab sl(K, 96);
   int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
   float *const tq = smem + p.lds_floats + 4 + (threadIdx.x >> 6) * kTqFloats;
   if (threadIdx.x == 0) *counter = 0;
   const int j0 = slab * 32;
   {
     const int mq = p.M >> 2;
-    fill_slab<SPLIT, NT>(smem, sl, 96, K >> 2,
+    fill_slab<NT>(smem, sl, 96, K >> 2,
                          [&](int r, int q) {
                            const int gate = r >> 5, jj = j0 + (r & 31);   // H % 32 == 0: always a valid feature
                            return q < mq ? p.w_ih + ((int64_t)gate * p.H + jj) * p.M + q * 4
@@ -678,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int ch0 = p.M >> 5, nch = K >> 5;
-  const int lofs = lane_piece_offset<SPLIT>(hi);
+  const int lofs = lane_piece_offset(hi);
   auto clampr = [&](int u) {
     const int64_t row = (int64_t)(rb0 + (u < count ? u : count - 1)) * 32 + li;
     return row < p.n ? row : p.n - 1;
@@ -693,7 +602,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
     rows.n0 = p.a + r1 * p.ld_a + lofs; rows.n1 = p.h + r1 * p.ld_h + lofs;
   }
   float4 a0[4], a1[4];
-  prologue_loads<SPLIT>(a0, a1, rows, ch0, nch);
+  prologue_loads(a0, a1, rows, ch0, nch);
   f32x16 acc[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) acc[n] = zero16();
@@ -705,7 +614,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_gru(GruArgs p) {
   while (cur < count) {
     const int nn = claim_unit(counter);
     unit_fence();
-    unit_kloop<3, 4, true, SPLIT>(acc, a0, a1, smem, sl, li, hi, rows, ch0, nch);
+    unit_kloop<3, 4, true>(acc, a0, a1, smem, sl, li, hi, rows, ch0, nch);
     gru_epilogue(p, acc, tq, (int64_t)(rb0 + cur) * 32, j0, lane, li, hi, bir, biz, bin, bhr, bhz, bhn);
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = zero16();
@@ -776,7 +685,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void k_stream_gru_ring(GruArgs 
   }
   __syncthreads();
 
-  const int lofs = lane_piece_offset<false>(hi);
+  const int lofs = lane_piece_offset(hi);
   auto clampr = [&](int u) {
     const int64_t row = (int64_t)(rb0 + (u < count ? u : count - 1)) * 32 + li;
     return row < p.n ? row : p.n - 1;
@@ -788,7 +697,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void k_stream_gru_ring(GruArgs 
     rows.n0 = p.a + r1 * p.ld_a + lofs; rows.n1 = p.h + r1 * p.ld_h + lofs;
   }
   float4 a0[4], a1[4];
-  prologue_loads<false>(a0, a1, rows, ch0, nch);
+  prologue_loads(a0, a1, rows, ch0, nch);
   f32x16 acc[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) acc[n] = zero16();
@@ -888,7 +797,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void k_stream_linear_ring(Linea
   }
   __syncthreads();
 
-  const int lofs = lane_piece_offset<false>(hi);
+  const int lofs = lane_piece_offset(hi);
   auto rowp = [&](int u) {
     int64_t row = (int64_t)(rb0 + (u < count ? u : count - 1)) * 32 + li;
     row = row < p.rows ? row : p.rows - 1;
@@ -898,7 +807,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void k_stream_linear_ring(Linea
   rows.c0 = rows.c1 = rowp(wave);
   rows.n0 = rows.n1 = rowp(wave + kRingWaves);
   float4 a0[4], a1[4];
-  prologue_loads<false>(a0, a1, rows, nch, nch);
+  prologue_loads(a0, a1, rows, nch, nch);
   f32x16 acc[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) acc[n] = zero16();
@@ -999,7 +908,7 @@ struct EdgeArgs {
 #endif
 constexpr int kEdgeWaves = PTGNN_EDGE_WAVES;
 
-template <int NB, bool SPLIT, bool INDIRECT>
+template <int NB, bool INDIRECT>
 __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_stream_edge(EdgeArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = kEdgeWaves * 64, BN = 32 * NB;
@@ -1022,13 +931,13 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
   tp.run_of_workgroup((int)blockIdx.x, u, u_end);
   if (u >= u_end) return;
   const int K = p.use_dst ? 2 * p.H : p.H;
-  const Slab<SPLIT> sl(K, BN);
+  const Slab sl(K, BN);
   int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
   float *const tq = smem + p.lds_floats + 4 + (threadIdx.x >> 6) * kTqFloats;
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int ch0 = p.H >> 5, nch = K >> 5;
-  const int lofs = lane_piece_offset<SPLIT>(hi);
+  const int lofs = lane_piece_offset(hi);
 
   while (u < u_end) {
     int t, t_u0, t_u1;                  // edge type of unit u and the type's unit range
@@ -1055,7 +964,7 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
     if (threadIdx.x == 0) *counter = 0;
     {
       const float *w = p.tab.w[t];
-      fill_slab<SPLIT, NT>(smem, sl, BN, K >> 2,
+      fill_slab<NT>(smem, sl, BN, K >> 2,
                            [&](int r, int q) { return w + (int64_t)(r < p.M ? r : p.M - 1) * K + q * 4; },
                            [&](int r) { return r < p.M; });
     }
@@ -1080,7 +989,7 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
         rows.n0 = node_row(src[e1]); rows.n1 = node_row(dst[e1]);
       }
       float4 a0[4], a1[4];
-      prologue_loads<SPLIT>(a0, a1, rows, ch0, nch);
+      prologue_loads(a0, a1, rows, ch0, nch);
       f32x16 acc[NB];
 #pragma unroll
       for (int n = 0; n < NB; ++n) acc[n] = zero16();
@@ -1089,7 +998,7 @@ __global__ __launch_bounds__(kEdgeWaves * 64, kEdgeWaves == 8 ? 2 : 3) void k_st
         const int64_t e_nn = edge_of(nn);
         unit_fence();
         const int64_t s_nn = src[e_nn], d_nn = dst[e_nn];   // lands under this unit's MFMAs
-        unit_kloop<NB, NB, false, SPLIT>(acc, a0, a1, smem, sl, li, hi, rows, ch0, nch);
+        unit_kloop<NB, NB, false>(acc, a0, a1, smem, sl, li, hi, rows, ch0, nch);
         const int64_t e_row0 = (int64_t)(ub + cur) * 32;
         const int64_t out_row0 = p.msg_row_base + type_row0 + e_row0;
 #pragma unroll
@@ -1213,7 +1122,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
   int u, u_end;
   tp.run_of_workgroup((int)blockIdx.x, u, u_end);
   if (u >= u_end) return;
-  const Slab<false> sl(K, BN);
+  const Slab sl(K, BN);
   int *counter = reinterpret_cast<int *>(smem + p.lds_floats);
   float *const tq = smem + p.lds_floats + 4 + (threadIdx.x >> 6) * kTqFloats;
   const int lane = threadIdx.x & 63;
@@ -1239,7 +1148,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
     if (threadIdx.x == 0) *counter = 0;
     {
       const float *w = p.tab.w[t];
-      fill_slab<false, NT>(smem, sl, BN, K >> 2, [&](int r, int q) { return w + (int64_t)r * K + q * 4; },
+      fill_slab<NT>(smem, sl, BN, K >> 2, [&](int r, int q) { return w + (int64_t)r * K + q * 4; },
                            [](int) { return true; });
     }
     __syncthreads();
@@ -1430,7 +1339,7 @@ int stream_gemm_mode() {
   if (g_mode < 0) {
     const char *e = getenv("PTGNN_AMD_GEMM");
     int m = e ? atoi(e) : 1;
-    g_mode = (m >= 0 && m <= 2) ? m : 1;
+    g_mode = (m == 0 || m == 1) ? m : 1;
   }
   return g_mode;
 }
@@ -1456,25 +1365,19 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   if (rows >= ((int64_t)1 << 31) * 32) return 0;
   const int bn = n_out >= 128 ? 128 : n_out;
   const int nb = bn / 32;
-  bool split = mode == 2;
   const char *ring_env = getenv("PTGNN_AMD_LINEAR_RING");                     // "1": force (A/B, parity tests at small K)
   const bool force_ring = ring_env && ring_env[0] == '1', no_ring = ring_env && ring_env[0] == '0';
   const char *force = getenv("PTGNN_AMD_FORCE_STREAM");        // tests: replay small reference fixtures on these kernels
   const bool forced = force && force[0] == '1';
   const bool ring_shape = n_out % 128 == 0 && (int64_t)n_out * k < ((int64_t)1 << 30) && (rows >= 32 * 64 || forced);
-  const bool ring = ring_shape && (force_ring || (!no_ring && Slab<false>::bytes(k, bn) + kEpiBytes > (size_t)kLdsBudget));
+  const bool ring = ring_shape && (force_ring || (!no_ring && Slab::bytes(k, bn) + kEpiBytes > (size_t)kLdsBudget));
   if (!ring) {
     // measured (profiles/r02_notes.md): the persistent kernel pays one slab copy per workgroup and re-reads
-    // A once per column slab, so in exact fp32 it only beats the tile kernel with >= 3 units per wave and
-    // few slabs; the split mode has no tile counterpart and always streams
+    // A once per column slab, so it only beats the tile kernel with >= 3 units per wave and few slabs
     const int64_t units = (rows + 31) / 32 * ((n_out + bn - 1) / bn);
-    if (!split && !forced && (units < (int64_t)num_compute_units() * 8 * 3 || (n_out + bn - 1) / bn > 4)) return 0;
+    if (!forced && (units < (int64_t)num_compute_units() * 8 * 3 || (n_out + bn - 1) / bn > 4)) return 0;
   }
-  size_t slab = split ? Slab<true>::bytes(k, bn) : Slab<false>::bytes(k, bn);
-  if (split && slab + kEpiBytes > (size_t)kLdsBudget) {   // three bf16 planes do not fit: this shape stays exact fp32
-    split = false;
-    slab = Slab<false>::bytes(k, bn);
-  }
+  const size_t slab = Slab::bytes(k, bn);
   const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
   LinearArgs p;
   p.x = x; p.rows = rows; p.K = k; p.ld_x = ld_x; p.w = w; p.n_out = n_out; p.bias = bias; p.act = act;
@@ -1483,7 +1386,7 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   p.ncs = (n_out + bn - 1) / bn;
   p.vec_store = (ld_y % 4 == 0 && aligned16(y)) ? 1 : 0;
   if (ring) {
-    // the slab does not fit: stream the weights through the panel ring (exact fp32 in both arithmetic modes)
+    // the slab does not fit: stream the weights through the panel ring
     const size_t rlds = (size_t)(2 * kLinRingPanelFloats + kRingWaves * kTqFloats) * sizeof(float);
     dense_runs(p.nrb, p.ncs, p.rps, p.run_len, 2 * num_compute_units());   // two 4-wave workgroups per CU
     p.lds_floats = 0;
@@ -1497,13 +1400,13 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   dense_runs(p.nrb, p.ncs, p.rps, p.run_len);
   p.lds_floats = (int)(slab / 4);
   const unsigned grid = (unsigned)(p.ncs * p.rps);
-#define PTGNN_K(NBV, SP)                                                            \
+#define PTGNN_K(NBV, UNUSED)                                                        \
   do {                                                                              \
-    auto kern = k_stream_linear<NBV, SP>;                                           \
+    auto kern = k_stream_linear<NBV>;                                               \
     if (!set_lds(kern, lds)) return 0;                                              \
     kern<<<grid, 512, lds, st>>>(p);                                                \
   } while (0)
-  if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
+  PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, 0);
 #undef PTGNN_K
   count_launch(PTGNN_AMD_KERNEL_STREAM_LINEAR);
   return 1;
@@ -1518,13 +1421,8 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
       !aligned16(h) || !aligned16(out) || (gates && !aligned16(gates)) || !aligned16(w_ih) || !aligned16(w_hh))
     return 0;
   if (n >= ((int64_t)1 << 31) * 32) return 0;
-  bool split = mode == 2;
   const int K = m + hd;
-  size_t slab = split ? Slab<true>::bytes(K, 96) : Slab<false>::bytes(K, 96);
-  if (split && slab + kEpiBytes > (size_t)kLdsBudget) {
-    split = false;
-    slab = Slab<false>::bytes(K, 96);
-  }
+  const size_t slab = Slab::bytes(K, 96);
   const size_t lds = slab + 16 + 8 * kTqFloats * sizeof(float);
   GruArgs p;
   p.a = a; p.ld_a = ld_a; p.h = h; p.ld_h = ld_h; p.w_ih = w_ih; p.w_hh = w_hh; p.b_ih = b_ih; p.b_hh = b_hh;
@@ -1533,9 +1431,8 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
   p.ncs = hd / 32;
   const char *ring_env = getenv("PTGNN_AMD_GRU_RING");                        // "1": A/B + parity tests at small K
   const bool force_ring = ring_env && ring_env[0] == '1';
-  if ((lds > (size_t)kLdsBudget && !(ring_env && ring_env[0] == '0')) || (force_ring && !split)) {
-    // the slab does not fit (K > ~400): stream the weights through the panel ring (exact fp32, also in the split
-    // mode, whose three bf16 planes fit even less)
+  if ((lds > (size_t)kLdsBudget && !(ring_env && ring_env[0] == '0')) || force_ring) {
+    // the slab does not fit (K > ~400): stream the weights through the panel ring
     const size_t rlds = (size_t)(2 * kRingPanelFloats + kRingWaves * kTqFloats) * sizeof(float);
     dense_runs(p.nrb, p.ncs, p.rps, p.run_len, 2 * num_compute_units());   // two 4-wave workgroups per CU
     p.lds_floats = 0;
@@ -1549,14 +1446,11 @@ int stream_gru(const float *a, int64_t ld_a, const float *h, int64_t ld_h, const
   dense_runs(p.nrb, p.ncs, p.rps, p.run_len);
   p.lds_floats = (int)(slab / 4);
   const unsigned grid = (unsigned)(p.ncs * p.rps);
-#define PTGNN_K(SP)                                      \
-  do {                                                   \
-    auto kern = k_stream_gru<SP>;                        \
-    if (!set_lds(kern, lds)) return 0;                   \
-    kern<<<grid, 512, lds, st>>>(p);                     \
-  } while (0)
-  if (split) PTGNN_K(true); else PTGNN_K(false);
-#undef PTGNN_K
+  {
+    auto kern = k_stream_gru;
+    if (!set_lds(kern, lds)) return 0;
+    kern<<<grid, 512, lds, st>>>(p);
+  }
   count_launch(PTGNN_AMD_KERNEL_STREAM_GRU);
   return 1;
 }
@@ -1567,7 +1461,7 @@ static bool edge_v2_shape(int32_t state_dim, int32_t msg_dim, int use_dst, int a
   const int K = state_dim;
   if (!(K == 64 || K == 128 || K == 256)) return false;
   if (!(msg_dim == 64 || msg_dim == 128)) return false;
-  return Slab<false>::bytes(K, msg_dim) + kEpiBytes <= (size_t)kLdsBudget;
+  return Slab::bytes(K, msg_dim) + kEpiBytes <= (size_t)kLdsBudget;
 }
 
 template <int DROP>
@@ -1593,7 +1487,7 @@ static int edge_v2_launch(const EdgeV2Args &q, int K, int msg_dim, unsigned grid
   return 0;
 }
 
-// 0 = not taken, 1 = exact fp32 streaming, 2 = split streaming
+// 0 = not taken, 1 = streaming
 constexpr size_t kEdgeEpiBytes = 16 + (size_t)kEdgeWaves * kTqFloats * sizeof(float);   // = kEpiBytes at 8 waves
 
 static int edge_plan(int32_t state_dim, int32_t msg_dim, int use_dst, size_t *slab_bytes) {
@@ -1601,13 +1495,9 @@ static int edge_plan(int32_t state_dim, int32_t msg_dim, int use_dst, size_t *sl
   if (mode == 0) return 0;
   const int K = use_dst ? 2 * state_dim : state_dim;
   if (K % 64 != 0 || state_dim % 32 != 0 || msg_dim % 32 != 0 || msg_dim > 128) return 0;
-  if (mode == 2 && Slab<true>::bytes(K, msg_dim) + kEdgeEpiBytes <= (size_t)kLdsBudget) {
-    *slab_bytes = Slab<true>::bytes(K, msg_dim);
-    return 2;
-  }
-  // exact fp32: 12 % ahead of the tile kernel at K = 128 and 9 % at K = 256 (cfg3's last layer, 133 KB slab)
-  if (Slab<false>::bytes(K, msg_dim) + kEdgeEpiBytes <= (size_t)kLdsBudget) {
-    *slab_bytes = Slab<false>::bytes(K, msg_dim);
+  // 12 % ahead of the tile kernel at K = 128 and 9 % at K = 256 (cfg3's last layer, 133 KB slab)
+  if (Slab::bytes(K, msg_dim) + kEdgeEpiBytes <= (size_t)kLdsBudget) {
+    *slab_bytes = Slab::bytes(K, msg_dim);
     return 1;
   }
   return 0;
@@ -1630,7 +1520,6 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
   const bool v2 = edge_v2_shape(state_dim, msg_dim, use_dst, act);
   if (mask && mask->mode != 0 && !v2) return 0;        // the dropout forms exist in k_stream_edge_v2 only
   if (kind == 0) return 0;
-  const bool split = kind == 2;
   const int nb = msg_dim / 32;
   const size_t lds = slab + 16 + kEdgeWaves * kTqFloats * sizeof(float);
   const int total = tab.unit_off[tab.num_types];
@@ -1685,13 +1574,13 @@ int stream_edge(const StreamEdgeTable &tab, const float *x, int64_t ld_x, int64_
     return mask->mode == 1 ? edge_v2_launch<1>(q, state_dim, msg_dim, grid, lds, st)
                            : edge_v2_launch<2>(q, state_dim, msg_dim, grid, lds, st);
   }
-#define PTGNN_K(NBV, SP)                                      \
+#define PTGNN_K(NBV, UNUSED)                                  \
   do {                                                        \
-    auto kern = k_stream_edge<NBV, SP, false>;                \
+    auto kern = k_stream_edge<NBV, false>;                    \
     if (!set_lds(kern, lds)) return 0;                        \
     kern<<<grid, kEdgeWaves * 64, lds, st>>>(p);              \
   } while (0)
-  if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
+  PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, 0);
 #undef PTGNN_K
   count_launch(PTGNN_AMD_KERNEL_STREAM_EDGE);
   return 1;
@@ -1707,7 +1596,6 @@ int stream_edge_indirect(const StreamEdgeTable *tab_dev, const float *const *w_p
   size_t slab = 0;
   const int kind = edge_plan(state_dim, msg_dim, 0, &slab);      // the arithmetic the per-edge launch would use
   if (kind == 0) return 0;
-  const bool split = kind == 2;
   const int nb = msg_dim / 32;
   const size_t lds = slab + 16 + kEdgeWaves * kTqFloats * sizeof(float);
   EdgeArgs p;
@@ -1719,13 +1607,13 @@ int stream_edge_indirect(const StreamEdgeTable *tab_dev, const float *const *w_p
   p.run_len = 0;
   p.lds_floats = (int)(slab / 4);
   const unsigned grid = (unsigned)edge_table_budget();
-#define PTGNN_K(NBV, SP)                                      \
+#define PTGNN_K(NBV, UNUSED)                                  \
   do {                                                        \
-    auto kern = k_stream_edge<NBV, SP, true>;                 \
+    auto kern = k_stream_edge<NBV, true>;                     \
     if (!set_lds(kern, lds)) return 0;                        \
     kern<<<grid, kEdgeWaves * 64, lds, st>>>(p);              \
   } while (0)
-  if (split) { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, true); } else { PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, false); }
+  PTGNN_STREAM_DISPATCH_NB(nb, PTGNN_K, 0);
 #undef PTGNN_K
   count_launch(PTGNN_AMD_KERNEL_STREAM_EDGE_SHARED);
   return 1;
@@ -1739,8 +1627,9 @@ int edge_table_budget() {
 }  // namespace ptgnn_amd
 
 extern "C" int ptgnn_amd_set_gemm_mode(int mode) {
-  if (mode < 0 || mode > 2) {
-    ptgnn_amd::set_error("set_gemm_mode: mode must be 0 (tile kernels), 1 (streaming fp32) or 2 (streaming 3xbf16 split)");
+  if (mode != 0 && mode != 1) {
+    ptgnn_amd::set_error("set_gemm_mode: mode must be 0 (tile kernels) or 1 (streaming kernels); the 3 x bf16 split mode "
+                         "of rounds 2-4 was removed");
     return PTGNN_AMD_EINVAL;
   }
   ptgnn_amd::stream_gemm_set_mode(mode);

@@ -18,17 +18,18 @@ EPI_NONE, EPI_GELU, EPI_LAYERNORM, EPI_GELU_LAYERNORM = 0, 1, 2, 3
 ACT_IDS = {None: 0, "none": 0, "tanh": 1, "relu": 2}
 
 
-GEMM_MODES = {"tile": 0, "stream": 1, "split": 2}
+GEMM_MODES = {"tile": 0, "stream": 1}
 
 
 def set_gemm_mode(mode) -> int:
-    """Kernel family / arithmetic of the dense blocks (ptgnn_amd_set_gemm_mode): "tile" = round-1 128x128
-    tile kernels, "stream" = weight-stationary streaming kernels, both exact fp32 MFMA; "split" = streaming
-    kernels with f32 emulated by an exact 3 x bf16 operand split on the bf16 MFMA (opt-in).  Returns the
-    previous mode id."""
+    """Kernel family of the dense blocks (ptgnn_amd_set_gemm_mode): "tile" = round-1 128x128 tile kernels, "stream" =
+    weight-stationary streaming kernels; both exact fp32 MFMA with the same bits.  Returns the previous mode id.
+    (The opt-in 3 x bf16 split arithmetic of rounds 2-4 was removed in round 5.)"""
     lib = _lib.load()
     prev = lib.ptgnn_amd_get_gemm_mode()
-    _lib.check(lib.ptgnn_amd_set_gemm_mode(GEMM_MODES.get(mode, mode)), "ptgnn_amd_set_gemm_mode")
+    if isinstance(mode, str) and mode not in GEMM_MODES:
+        raise _lib.PtgnnAmdError(f"unknown GEMM mode {mode!r} (have {sorted(GEMM_MODES)}; the split mode was removed)")
+    _lib.check(lib.ptgnn_amd_set_gemm_mode(int(GEMM_MODES.get(mode, mode))), "ptgnn_amd_set_gemm_mode")
     return prev
 
 

@@ -5,8 +5,8 @@ cd $ROOT
 out=gpurun_out/r05d; mkdir -p $out
 timeout 900 python -m pytest tests/test_gpu_gather_update.py tests/test_gpu_pipeline.py tests/test_gpu_two_rank.py -x -q -m gpu > $out/tests.log 2>&1
 echo "tests rc=$?" >> $out/tests.log; tail -6 $out/tests.log
-for f in 0 1 0 1; do
-  PTGNN_AMD_GATHER_UPDATE=$f timeout 300 python scripts/profile_cfg4.py 40 2>&1 | tail -1 | sed "s/^/fused=$f /"
+for f in 0 1 0 1 32; do
+  PTGNN_AMD_GATHER_UPDATE_MFMA=$f PTGNN_AMD_GATHER_UPDATE=$f timeout 300 python scripts/profile_cfg4.py 40 2>&1 | tail -1 | sed "s/^/fused=$f /"
 done
 for f in 0 1; do
   PTGNN_AMD_GATHER_UPDATE=$f timeout 300 python - <<'PY' 2>&1 | tail -2

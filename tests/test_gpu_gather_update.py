@@ -11,10 +11,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
+@pytest.mark.parametrize("mfma", ["16", "32"])      # tile product on v_mfma_f32_16x16x4 (default) / 32x32x2: the same K order
 @pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
 @pytest.mark.parametrize("out_dim,act,bias", [(64, "tanh", True), (128, None, False), (32, "relu", True), (96, "tanh", False)])
-def test_gather_update_equals_gather_reduce_then_linear_bit_for_bit(reduce, out_dim, act, bias):
+def test_gather_update_equals_gather_reduce_then_linear_bit_for_bit(reduce, out_dim, act, bias, mfma, monkeypatch):
     from ptgnn_amd import ops
+    monkeypatch.setenv("PTGNN_AMD_GATHER_UPDATE_MFMA", mfma)
     g = torch.Generator().manual_seed(11)
     N, E, M = 50_019, 270_000, 64                     # ragged last tile; some rows without in-edges
     src = torch.randint(0, N, (E,), generator=g)
@@ -36,7 +38,7 @@ def test_gather_update_equals_gather_reduce_then_linear_bit_for_bit(reduce, out_
         rows = torch.ones(N, dtype=torch.bool, device="cuda")
         if reduce in ("sum", "mean"):
             rows[17] = False                          # the hub row: another fp32 association (serial vs chunk partials)
-            assert float((got[17] - want[17]).abs().max()) <= 1e-4
+            assert float((got[17] - want[17]).abs().max()) <= 1e-5 * max(1.0, float(want[17].abs().max()))
         assert torch.equal(got[rows], want[rows]), (reduce, out_dim, act, epi)
     # a strided destination (the right half of a concat residual's buffer)
     buf = torch.zeros(N, 2 * out_dim, device="cuda")

@@ -750,13 +750,13 @@ def test_config4_varmisuse_mlp_stack_vs_oracle():
 
 @pytest.mark.parametrize("kind", ["ggnn", "mlp"])
 @pytest.mark.parametrize("agg", ["sum", "max"])
-@pytest.mark.parametrize("gemm_mode", ["stream", "split"])
+@pytest.mark.parametrize("gemm_mode", ["stream", "tile"])
 def test_config5_scaled_layer_vs_oracle(kind, agg, gemm_mode):
     """BASELINE config 5's own layer configuration -- ONE GGNN / ONE MLP-MP layer at H = M = 256 over a power-law
     graph (Zipf-0.8 destinations through a node permutation, uniform sources) -- scaled to a size the
     CPU oracle finishes in seconds (N = 125 k, E = 1.25 M: ~20 hub rows above the 2048-edge threshold, the largest
     ~24 k in-edges), against oracle/mp_oracle.py (gatedmessagepassing.py:37-69, mlpmessagepassing.py:68-117):
-    the K = 512 GRU, the 256 -> 256 pre-transform, hub rows inside a full layer, exact and split GEMM mode."""
+    the K = 512 GRU, the 256 -> 256 pre-transform, hub rows inside a full layer, streaming and tile kernels."""
     from oracle import mp_oracle as O
     from ptgnn_amd import layers as L, ops, workloads
     N, E, H = 125_000, 1_250_000, 256
@@ -1048,7 +1048,7 @@ def test_unique_sources_equal_the_numpy_bookkeeping(n, counts, src_pool, monkeyp
     assert ((wgs > 0) == (units > 0)).all() and (wgs <= np.maximum(units, 0)).all() and wg_off[-1] <= 256
 
 
-@pytest.mark.parametrize("mode", ["stream", "split"])
+@pytest.mark.parametrize("mode", ["stream"])   # the shared-row launch exists on the streaming kernels only
 @pytest.mark.parametrize("agg", ["sum", "max", "mean"])
 def test_ggnn_layer_with_shared_message_rows_gives_the_same_bits(agg, mode, monkeypatch):
     """GGNN inference, edge form: one message row per distinct (edge type, source) pair (GraphPlan.unique_messages)
@@ -1754,7 +1754,7 @@ def _run_container(net, x, mb, **kw):
                num_graphs=mb["num_graphs"], **kw)
 
 
-@pytest.mark.parametrize("gemm_mode", ["stream", "split", "tile"])
+@pytest.mark.parametrize("gemm_mode", ["stream", "tile"])
 def test_config3_full_size_vs_oracle(gemm_mode):
     """BASELINE config 3 at the size bench.py measures it: 48 graphs / 115 772 nodes / T = 17 / 625 130 edges,
     the Typilus GGNN stack (8 GGNN layers, hidden 128, max) -- end to end against the CPU oracle, 1e-5, in
@@ -1820,7 +1820,7 @@ def _varmisuse_mlp_stack(H, T, seed):
     return mods, specs
 
 
-@pytest.mark.parametrize("gemm_mode", ["stream", "split"])
+@pytest.mark.parametrize("gemm_mode", ["stream", "tile"])
 def test_config4_varmisuse_full_size_per_layer_and_end_to_end(gemm_mode):
     """BASELINE config 4 at the reference's batch cap (varmisuse/train.py:119: 80 000 nodes): 40 graphs x ~2000
     nodes, T0 = 10 -> T = 21, the 8-layer VarMisuse MLP-MP stack at hidden 64.
@@ -2412,19 +2412,23 @@ def test_row_epilogue_equals_the_fused_inference_epilogue_bitwise_and_handles_ed
 
 
 # ------------------------------------------------------------------------------------------------
-# the opt-in "f32 via 3 x bf16 split" GEMM mode over the configs it had not been checked on
+# the round-1 tile kernels (GEMM mode 0: the fallback of every shape the streaming core does not take) on the same bars
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", ["cfg1_ppi", "cfg2_sum", "cfg2_max", "golden_ggnn_max_edge", "golden_ggnn_sum_table",
                                   "golden_mlp_sum_edge", "golden_mlp_max_table", "autograd_ggnn_sum_edge",
                                   "autograd_mlp_mean_table"])
-def test_split_gemm_mode_parity_matrix(case, monkeypatch):
-    """ptgnn_amd_set_gemm_mode(2) against the SAME bars as the exact mode: BASELINE configs 1 and 2 at full size vs
+def test_tile_gemm_mode_parity_matrix(case, monkeypatch):
+    """ptgnn_amd_set_gemm_mode(0) against the SAME bars as the streaming kernels: BASELINE configs 1 and 2 at full size vs
     the oracle (1e-5), and the training step -- outputs, d x and every parameter gradient -- vs the reference's own
-    gradients (tests/golden/train_*.npz) and vs oracle autograd.  (Configs 3, 4 and 5 carry a `split` parameter in
-    their own tests.)  The split mode replaces the forward / input-gradient GEMMs; the weight-gradient kernels are
-    exact fp32 in every mode."""
-    from ptgnn_amd import ops
-    prev = ops.set_gemm_mode("split")
+    gradients (tests/golden/train_*.npz) and vs oracle autograd.  (Configs 3, 4 and 5 carry a `tile` parameter in their
+    own tests.)  Rounds 2-4 ran this matrix on the opt-in 3 x bf16 split arithmetic, removed in round 5: mode 2 now
+    answers EINVAL (asserted below)."""
+    from ptgnn_amd import PtgnnAmdError, ops
+    with pytest.raises(PtgnnAmdError):
+        ops.set_gemm_mode(2)
+    with pytest.raises(PtgnnAmdError):
+        ops.set_gemm_mode("split")
+    prev = ops.set_gemm_mode("tile")
     try:
         if case == "cfg1_ppi":
             test_config1_ppi_ggnn_full_size_vs_oracle()
