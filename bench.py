@@ -14,9 +14,9 @@ hidden 128, max aggregation, fp32, forward).  `value` = E / t_layer (edges per s
 layer, E counted after reverse + self augmentation).  At N=1 the same run also reports configs[1]
 (synthetic 200k-node / 1.1M-edge graph, one MLP-MP layer) under "config2", configs[3] (VarMisuse batch, T = 21,
 8 MLP-MP layers hidden 64) on one GPU under "config4", the per-GPU shard of configs[4]
-(power-law, 1.25M nodes / 12.5M edges, H=256) under "config5_shard", the same primary workload in the opt-in
-"f32 via 3xbf16 split" GEMM mode under "split_bf16", the training step of the Graph2Class stack under
-"graph2class_train", and the CPU restatement under "cpu_baseline".  The GPU output of the primary workload and
+(power-law, 1.25M nodes / 12.5M edges, H=256; every row checked against the chunked CPU oracle) under "config5_shard",
+the training step of the Graph2Class stack under "graph2class_train", the README's own architecture under
+"readme_default_arch", and the CPU restatement under "cpu_baseline".  The GPU output of the primary workload and
 of config 2 is compared with the CPU oracle's at FULL size ("parity"); a miss fails the run (exit code 3).
 
 N>1: the path partitions over whole graphs (a minibatch is a disjoint union; the reference's own
@@ -59,7 +59,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--gemm", default=None, choices=["tile", "stream", "split"],
+    p.add_argument("--gemm", default=None, choices=["tile", "stream"],
                    help="kernel family / arithmetic of the dense blocks for the PRIMARY line (default: stream = exact fp32)")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--no-rotation", action="store_true",
@@ -879,8 +879,7 @@ def main():
     from ptgnn_amd import _lib, ops
     _lib.load()
     ops.set_gemm_mode(args.gemm or "stream")
-    gemm_names = {0: "f32 (exact fp32 MFMA, 128x128 tile kernels)", 1: "f32 (exact fp32 MFMA, streaming kernels)",
-                  2: "f32 via 3xbf16 split (bf16 MFMA, fp32 accumulate)"}
+    gemm_names = {0: "f32 (exact fp32 MFMA, 128x128 tile kernels)", 1: "f32 (exact fp32 MFMA, streaming kernels)"}
 
     rotation = None
     if args.workload == "cfg2":
@@ -926,7 +925,7 @@ def main():
         "metric": "edges/sec per MP layer", "value": round(value, 1), "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if ops.get_gemm_mode() != 2 else "f32 via 3xbf16 split",
+        "vs_baseline": None, "dtype": "f32",
         "data": "synthetic", "gemm_mode": gemm_names[ops.get_gemm_mode()],
         "config": {"workload": st["desc"], "nodes_per_gpu": st["N"], "edges_per_gpu": st["E"],
                    "hidden": st["H"], "mp_layers_per_step": layers, "mode": "forward (inference), fp32",
@@ -1111,29 +1110,6 @@ def main():
             result["cpu_baseline"], result["parity"] = base, parity
             if not parity["max_abs"] <= PARITY_TOL:
                 exit_code = 3
-            if args.workload == "cfg3" and not args.no_secondary and ops.get_gemm_mode() != 2:
-                # the same primary workload in the opt-in split-precision GEMM mode, with its own parity
-                from oracle import mp_oracle as O
-                prev = ops.set_gemm_mode("split")
-                _log("split-precision GEMM mode line")
-                try:
-                    sec_s, sum_s = timed_region(step, args.steps, args.warmup, 1, dev)
-                    kt_s = kernel_table(sum_s)
-                    with torch.no_grad():
-                        out_s = first().output_node_representations.cpu()
-                        want = O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True)[0]
-                    err_s = float((out_s - want).abs().max())
-                    result["split_bf16"] = {
-                        "dtype": "f32 via 3xbf16 split", "gemm_mode": gemm_names[2],
-                        "ms_per_step": round(sec_s / args.steps * 1e3, 4),
-                        "value": round(e_mine / (sec_s / args.steps / layers), 1), "unit": "edges/s",
-                        "speedup_vs_primary": round(ms_per_step / (sec_s / args.steps * 1e3), 3),
-                        "parity": {"max_abs": err_s, "tol": PARITY_TOL, "n": st["N"]},
-                        "kernels": {k: {kk: v[kk] for kk in ("calls", "avg_ms", "achieved", "unit")} for k, v in kt_s.items()}}
-                except Exception as exc:  # noqa: BLE001
-                    result["split_bf16"] = {"error": f"{type(exc).__name__}: {exc}"}
-                finally:
-                    ops.set_gemm_mode(prev)
     if world > 1 or args.force_sharded or args.sharded_variants:
         import torch.distributed as dist
         dist.barrier()
