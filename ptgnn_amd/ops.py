@@ -791,9 +791,10 @@ def gather_update(msgs: torch.Tensor, plan: GraphPlan, reduce: str, col: torch.T
     _require_cuda_f32("msgs", msgs)
     _require_cuda_f32("weight", weight)
     msgs, weight = _rowmajor(msgs), weight.contiguous()
-    N, M, out_dim = plan.num_nodes, msgs.shape[1], weight.shape[0]
-    if weight.shape[1] != M or reduce not in REDUCE_IDS:
-        raise _lib.PtgnnAmdError(f"gather_update: weight {tuple(weight.shape)} / reduce {reduce!r} do not fit messages of width {M}")
+    N, M, out_dim = plan.num_nodes, weight.shape[1], weight.shape[0]      # msgs: [E, M] rows or a [rows, T * M] table
+    if msgs.shape[1] % M != 0 or reduce not in REDUCE_IDS:
+        raise _lib.PtgnnAmdError(f"gather_update: weight {tuple(weight.shape)} / reduce {reduce!r} do not fit messages of "
+                                 f"width {msgs.shape[1]}")
     if out is None:
         out = torch.empty(N, out_dim, dtype=torch.float32, device=msgs.device)
     elif tuple(out.shape) != (N, out_dim) or out.dtype != torch.float32 or out.stride(1) != 1 or not out.is_cuda:

@@ -64,8 +64,8 @@ def test_gather_update_table_form_with_types_and_refusals():
     want = ops.linear(ops.gather_reduce(y, plan, M, "max", epilogue=ops.EPI_GELU), w, None, act="tanh")
     assert torch.equal(got, want)
     assert not ops.gather_update_supported(128, 64, plan) and not ops.gather_update_supported(64, 48, plan)
-    with pytest.raises(PtgnnAmdError):
-        ops.gather_update(torch.randn(N, 128).cuda(), plan, "max", plan.perm, 0, 0, None, None, 1e-5,
+    with pytest.raises(PtgnnAmdError):      # message width 128: not a shape of the fused kernel
+        ops.gather_update(torch.randn(N, 128).cuda(), plan, "max", plan.col, plan.type_bits, 0, None, None, 1e-5,
                           torch.randn(64, 128).cuda(), None, None)
 
 
