@@ -594,8 +594,14 @@ using f32x4v = __attribute__((ext_vector_type(4))) float;
 // tail behind the gather, during which the workgroup holds its wave slots and LDS without issuing loads, shrinks 4x.
 // The four k of an instruction are (kcol(s), kcol(s) + 4, kcol(s + 1), kcol(s + 1) + 4): the products of a row meet the
 // accumulator in the SAME order as in two 32x32x2 steps, hence the same bits (asserted on the GPU, tests/test_gpu_gather_update.py).
-template <int REDUCE, bool M16>
+// FORM 2: the product WAVE-LOCAL on v_mfma_f32_4x4x1_16b_f32 -- sixteen 4 x 4 blocks per instruction: a wave's own four rows
+// (one per 16-lane group) against output columns 4 b .. 4 b + 3 in block b, i.e. all 64 columns, one k per instruction in
+// `kcol` order (a plain fma chain: the same bits again).  No workgroup barrier behind the gather: the weights are in LDS
+// before it starts (one barrier at the top, where the eight waves are in step anyway), every wave multiplies and stores its
+// rows the moment ITS rows are aggregated and retires -- like the lane groups of k_gather_reduce.
+template <int REDUCE, int FORM>
 __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
+  constexpr bool M16 = FORM == 1;
   extern __shared__ __attribute__((aligned(16))) float upd_smem[];
   constexpr int LPR = 16, ROWS = 32;
   float *const Ws = upd_smem;                                   // [out_dim][kUpdLd]
@@ -617,6 +623,63 @@ __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
   const int grp = threadIdx.x / LPR, g = threadIdx.x % LPR;
   const int64_t row0 = a.row_begin + tile * ROWS;
   const int64_t row = row0 + grp;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if constexpr (FORM == 2) {
+    int beg = 0, end = 0;
+    if (row < a.num_nodes) { beg = a.rowptr[row]; end = a.rowptr[row + 1]; }      // in flight next to the weight loads
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = (int)threadIdx.x + j * 512;
+      if (i < wq) *reinterpret_cast<float4 *>(Ws + (i >> 4) * kUpdLd + (i & 15) * 4) = wv[j];
+    }
+    __syncthreads();                                              // the only workgroup barrier: W is in LDS
+    RowOp<4, LPR, 1, REDUCE, false, false, false> op(a, g, 0);
+    if (row < a.num_nodes) {
+      op.template reduce_pf<8>(row, beg, end, 1);
+      op.finish(end - beg);
+    } else {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) op.acc[0][v] = 0.f;
+    }
+    // this wave's four normalised rows -> its private 4 x 64 slab (rows of 64 floats: every read below is a broadcast)
+    float *const Aw = As + wave * (4 * kUpdM);
+    *reinterpret_cast<float4 *>(Aw + (lane >> 4) * kUpdM + g * 4) = make_float4(op.acc[0][0], op.acc[0][1], op.acc[0][2], op.acc[0][3]);
+    __builtin_amdgcn_wave_barrier();
+    const float *const ar = Aw + (lane & 3) * kUpdM;             // A: lane = i + 4 b holds row i of the wave, any block b
+    const int nset = (u.out_dim + 63) >> 6;                      // output columns lane + 64 cs
+#pragma unroll 1
+    for (int cs = 0; cs < nset; ++cs) {
+      const int colx = cs * 64 + lane;
+      const float *const br = Ws + (colx < u.out_dim ? colx : u.out_dim - 1) * kUpdLd;   // B: lane = j + 4 b holds column 4 b + j
+      f32x4v c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < kUpdM / 8; ++q) {                       // k = 8 q + {0, 4, 1, 5, 2, 6, 3, 7}: kcol order
+        const float4 a0 = *reinterpret_cast<const float4 *>(ar + 8 * q), a1 = *reinterpret_cast<const float4 *>(ar + 8 * q + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(br + 8 * q), b1 = *reinterpret_cast<const float4 *>(br + 8 * q + 4);
+        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b0.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b1.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b0.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b1.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b0.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b1.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b0.w, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b1.w, c, 0, 0, 0);
+      }
+      if (colx < u.out_dim) {
+        const float b = u.bias ? u.bias[colx] : 0.f;
+        // D: VGPR i = row i of the wave (the row of lane group i), this lane's column
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t orow = row0 + wave * 4 + i;
+          const float v = u.bias ? c[i] + b : c[i];
+          const float o = u.act == PTGNN_AMD_ACT_TANH ? act_apply<PTGNN_AMD_ACT_TANH>(v)
+                          : (u.act == PTGNN_AMD_ACT_RELU ? act_apply<PTGNN_AMD_ACT_RELU>(v) : v);
+          if (orow < a.num_nodes) u.out[orow * u.ld_out + colx] = o;
+        }
+      }
+    }
+    return;
+  }
   {
     RowOp<4, LPR, 1, REDUCE, false, false, false> op(a, g, 0);
     if (row < a.num_nodes) {
@@ -635,7 +698,6 @@ __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
     if (i < wq) *reinterpret_cast<float4 *>(Ws + (i >> 4) * kUpdLd + (i & 15) * 4) = wv[j];
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   auto activate = [&](float v) {
     return u.act == PTGNN_AMD_ACT_TANH ? act_apply<PTGNN_AMD_ACT_TANH>(v)
                                        : (u.act == PTGNN_AMD_ACT_RELU ? act_apply<PTGNN_AMD_ACT_RELU>(v) : v);
@@ -1027,15 +1089,18 @@ extern "C" int ptgnn_amd_gather_update_f32(const float *msg, int64_t ld_msg, con
   UpdateArgs u;
   u.w = w; u.bias = bias; u.out_dim = out_dim; u.act = act; u.out = out; u.ld_out = ld_out;
   // A/B + bit-identity test knob: PTGNN_AMD_GATHER_UPDATE_MFMA=32 takes the 32x32x2 form of the tile product
+  // A/B + bit-identity test knob: PTGNN_AMD_GATHER_UPDATE_MFMA = 4 (wave-local 4x4x1 products, the default), 16 (workgroup
+  // tile on 16x16x4, all eight waves), 32 (workgroup tile on 32x32x2, out_dim / 32 waves)
   const char *mf = getenv("PTGNN_AMD_GATHER_UPDATE_MFMA");
-  const bool m16 = !(mf && mf[0] == '3');
-  const size_t lds = ((size_t)out_dim * kUpdLd + 32 * kUpdLd + (m16 ? 0 : 32 * (out_dim + 4))) * sizeof(float);
+  const int form = mf && mf[0] == '3' ? 0 : (mf && mf[0] == '1' && mf[1] == '6' ? 1 : 2);
+  const size_t lds = ((size_t)out_dim * kUpdLd + 32 * kUpdLd + (form == 0 ? 32 * (out_dim + 4) : 0)) * sizeof(float);
   const unsigned grid = (unsigned)xcd_padded_blocks(a.num_tiles);
   hipStream_t st = (hipStream_t)stream_;
 #define PTGNN_GU(R)                                                          \
   do {                                                                       \
-    if (m16) k_gather_update<R, true><<<grid, 512, lds, st>>>(a, u);         \
-    else k_gather_update<R, false><<<grid, 512, lds, st>>>(a, u);            \
+    if (form == 2) k_gather_update<R, 2><<<grid, 512, lds, st>>>(a, u);      \
+    else if (form == 1) k_gather_update<R, 1><<<grid, 512, lds, st>>>(a, u); \
+    else k_gather_update<R, 0><<<grid, 512, lds, st>>>(a, u);                \
   } while (0)
   switch (reduce) {
     case PTGNN_AMD_SUM: PTGNN_GU(PTGNN_AMD_SUM); break;

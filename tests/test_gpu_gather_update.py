@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-@pytest.mark.parametrize("mfma", ["16", "32"])      # tile product on v_mfma_f32_16x16x4 (default) / 32x32x2: the same K order
+@pytest.mark.parametrize("mfma", ["4", "16", "32"])   # wave-local 4x4x1 (default) / workgroup tile on 16x16x4 / 32x32x2: one K order
 @pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
 @pytest.mark.parametrize("out_dim,act,bias", [(64, "tanh", True), (128, None, False), (32, "relu", True), (96, "tanh", False)])
 def test_gather_update_equals_gather_reduce_then_linear_bit_for_bit(reduce, out_dim, act, bias, mfma, monkeypatch):
