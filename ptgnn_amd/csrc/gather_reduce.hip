@@ -31,6 +31,7 @@
 #include <mutex>
 
 #include "dense_common.h"   // f32x16, kcol(), act_apply(): the fused node update below multiplies like the GEMM kernels
+#include "stream_gemm.h"    // num_compute_units()
 
 namespace ptgnn_amd {
 namespace {
@@ -608,8 +609,8 @@ __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
   float *const As = Ws + u.out_dim * kUpdLd;                    // [32][kUpdLd]  normalised rows
   float *const Cs = As + ROWS * kUpdLd;                         // [32][out_dim + 4] results (32x32x2 form only)
   const int ldc = u.out_dim + 4;
-  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  if (tile >= a.num_tiles) return;                               // workgroup-uniform
+  const int64_t tile = FORM == 2 ? 0 : xcd_swizzle(blockIdx.x, gridDim.x);
+  if (FORM != 2 && tile >= a.num_tiles) return;                  // workgroup-uniform
   // the weights: issued first, they travel behind the rowptr / col / row round trips of the gather below
   // (held in registers until the gather is done: a load -> ds_write pair up front would wait for the load right here)
   const int wq = u.out_dim * (kUpdM / 4);                        // float4 pieces of W: 512 .. 2048
@@ -625,58 +626,67 @@ __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
   const int64_t row = row0 + grp;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if constexpr (FORM == 2) {
-    int beg = 0, end = 0;
-    if (row < a.num_nodes) { beg = a.rowptr[row]; end = a.rowptr[row + 1]; }      // in flight next to the weight loads
+    // PERSISTENT: the weights go to LDS once per workgroup, then every wave walks row quads on its own -- no barrier, no
+    // waiting for a neighbour's long row; quads of one XCD are consecutive rows (as the tiles of k_gather_reduce)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = (int)threadIdx.x + j * 512;
       if (i < wq) *reinterpret_cast<float4 *>(Ws + (i >> 4) * kUpdLd + (i & 15) * 4) = wv[j];
     }
     __syncthreads();                                              // the only workgroup barrier: W is in LDS
-    RowOp<4, LPR, 1, REDUCE, false, false, false> op(a, g, 0);
-    if (row < a.num_nodes) {
-      op.template reduce_pf<8>(row, beg, end, 1);
-      op.finish(end - beg);
-    } else {
+    const int64_t nquads = (a.num_nodes - a.row_begin + 3) >> 2;
+    const int64_t per = (nquads + kNumXcd - 1) / kNumXcd;         // quads per XCD
+    const int xcd = blockIdx.x % kNumXcd, jb = blockIdx.x / kNumXcd, nj = gridDim.x / kNumXcd;   // grid % 8 == 0
+    float *const Aw = As + wave * (4 * kUpdM);                    // this wave's 4 x 64 slab (every read is a broadcast)
+    const float *const ar = Aw + (lane & 3) * kUpdM;              // A: lane = i + 4 b holds row i of the wave, any block b
+    const int nset = (u.out_dim + 63) >> 6;                       // output columns lane + 64 cs
+    for (int64_t q = (int64_t)jb * 8 + wave; q < per; q += (int64_t)nj * 8) {
+      const int64_t quad = xcd * per + q;
+      if (quad >= nquads) break;
+      const int64_t qrow0 = a.row_begin + quad * 4;
+      const int64_t qrow = qrow0 + (lane >> 4);
+      RowOp<4, LPR, 1, REDUCE, false, false, false> op(a, g, 0);
+      if (qrow < a.num_nodes) {
+        const int beg = a.rowptr[qrow], end = a.rowptr[qrow + 1];
+        op.template reduce_pf<8>(qrow, beg, end, 1);
+        op.finish(end - beg);
+      } else {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) op.acc[0][v] = 0.f;
-    }
-    // this wave's four normalised rows -> its private 4 x 64 slab (rows of 64 floats: every read below is a broadcast)
-    float *const Aw = As + wave * (4 * kUpdM);
-    *reinterpret_cast<float4 *>(Aw + (lane >> 4) * kUpdM + g * 4) = make_float4(op.acc[0][0], op.acc[0][1], op.acc[0][2], op.acc[0][3]);
-    __builtin_amdgcn_wave_barrier();
-    const float *const ar = Aw + (lane & 3) * kUpdM;             // A: lane = i + 4 b holds row i of the wave, any block b
-    const int nset = (u.out_dim + 63) >> 6;                      // output columns lane + 64 cs
-#pragma unroll 1
-    for (int cs = 0; cs < nset; ++cs) {
-      const int colx = cs * 64 + lane;
-      const float *const br = Ws + (colx < u.out_dim ? colx : u.out_dim - 1) * kUpdLd;   // B: lane = j + 4 b holds column 4 b + j
-      f32x4v c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < kUpdM / 8; ++q) {                       // k = 8 q + {0, 4, 1, 5, 2, 6, 3, 7}: kcol order
-        const float4 a0 = *reinterpret_cast<const float4 *>(ar + 8 * q), a1 = *reinterpret_cast<const float4 *>(ar + 8 * q + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(br + 8 * q), b1 = *reinterpret_cast<const float4 *>(br + 8 * q + 4);
-        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b0.x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b1.x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b0.y, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b1.y, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b0.z, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b1.z, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b0.w, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b1.w, c, 0, 0, 0);
+        for (int v = 0; v < 4; ++v) op.acc[0][v] = 0.f;
       }
-      if (colx < u.out_dim) {
-        const float b = u.bias ? u.bias[colx] : 0.f;
-        // D: VGPR i = row i of the wave (the row of lane group i), this lane's column
+      *reinterpret_cast<float4 *>(Aw + (lane >> 4) * kUpdM + g * 4) = make_float4(op.acc[0][0], op.acc[0][1], op.acc[0][2], op.acc[0][3]);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+      for (int cs = 0; cs < nset; ++cs) {
+        const int colx = cs * 64 + lane;
+        const float *const br = Ws + (colx < u.out_dim ? colx : u.out_dim - 1) * kUpdLd;   // B: lane = j + 4 b holds column 4 b + j
+        f32x4v c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t orow = row0 + wave * 4 + i;
-          const float v = u.bias ? c[i] + b : c[i];
-          const float o = u.act == PTGNN_AMD_ACT_TANH ? act_apply<PTGNN_AMD_ACT_TANH>(v)
-                          : (u.act == PTGNN_AMD_ACT_RELU ? act_apply<PTGNN_AMD_ACT_RELU>(v) : v);
-          if (orow < a.num_nodes) u.out[orow * u.ld_out + colx] = o;
+        for (int qq = 0; qq < kUpdM / 8; ++qq) {                  // k = 8 qq + {0, 4, 1, 5, 2, 6, 3, 7}: kcol order
+          const float4 a0 = *reinterpret_cast<const float4 *>(ar + 8 * qq), a1 = *reinterpret_cast<const float4 *>(ar + 8 * qq + 4);
+          const float4 b0 = *reinterpret_cast<const float4 *>(br + 8 * qq), b1 = *reinterpret_cast<const float4 *>(br + 8 * qq + 4);
+          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b0.x, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b1.x, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b0.y, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b1.y, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b0.z, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b1.z, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b0.w, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b1.w, c, 0, 0, 0);
+        }
+        if (colx < u.out_dim) {
+          const float b = u.bias ? u.bias[colx] : 0.f;
+          // D: VGPR i = row i of the quad (the row of lane group i), this lane's column
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = u.bias ? c[i] + b : c[i];
+            const float o = u.act == PTGNN_AMD_ACT_TANH ? act_apply<PTGNN_AMD_ACT_TANH>(v)
+                            : (u.act == PTGNN_AMD_ACT_RELU ? act_apply<PTGNN_AMD_ACT_RELU>(v) : v);
+            if (qrow0 + i < a.num_nodes) u.out[(qrow0 + i) * u.ld_out + colx] = o;
+          }
         }
       }
+      __builtin_amdgcn_wave_barrier();                            // the slab is reused by the next quad
     }
     return;
   }
@@ -1095,10 +1105,16 @@ extern "C" int ptgnn_amd_gather_update_f32(const float *msg, int64_t ld_msg, con
   const int form = mf && mf[0] == '3' ? 0 : (mf && mf[0] == '1' && mf[1] == '6' ? 1 : 2);
   const size_t lds = ((size_t)out_dim * kUpdLd + 32 * kUpdLd + (form == 0 ? 32 * (out_dim + 4) : 0)) * sizeof(float);
   const unsigned grid = (unsigned)xcd_padded_blocks(a.num_tiles);
+  // FORM 2 is persistent: four 8-wave workgroups per CU (what its 26 KB of LDS and 8 wave slots per SIMD allow), fewer on a
+  // small matrix (one quad per wave at least)
+  int64_t pgrid = (int64_t)num_compute_units() * 4;
+  const int64_t want = ((num_nodes + 3) / 4 + 7) / 8;
+  if (pgrid > want) pgrid = want;
+  pgrid = (pgrid + kNumXcd - 1) / kNumXcd * kNumXcd;
   hipStream_t st = (hipStream_t)stream_;
 #define PTGNN_GU(R)                                                          \
   do {                                                                       \
-    if (form == 2) k_gather_update<R, 2><<<grid, 512, lds, st>>>(a, u);      \
+    if (form == 2) k_gather_update<R, 2><<<(unsigned)pgrid, 512, lds, st>>>(a, u); \
     else if (form == 1) k_gather_update<R, 1><<<grid, 512, lds, st>>>(a, u); \
     else k_gather_update<R, 0><<<grid, 512, lds, st>>>(a, u);                \
   } while (0)

@@ -808,6 +808,51 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
                 return self._aggregate_and_update(messages, None, plan, col=plan.perm, type_bits=0)
             return self._update(segment_reduce(messages, plan, self.__aggregation_fn), False)
 
+        no_feats = self._features_dimension == 0 and not any(f is not None and f.shape[-1] != 0 for f in edge_features)
+        H = self.__input_state_dim
+        if (no_feats and isinstance(self.__aggregation_fn, str) and node_states.dtype == torch.float32
+                and all(l.bias is None for l in first) and len({tuple(l.weight.shape) for l in first}) == 1
+                and _edge_training_ok(H, first[0].weight.shape[0])
+                and not any(isinstance(m, nn.Dropout) and m.p > 0 and self.training for e in mlps for m in e.modules_in_order)):
+            # deeper edge MLPs (mlp_hidden_layers > 0, mlp.py:50-77) without edge features: the FIRST Linear of every edge
+            # type is the grouped per-edge GEMM (it gathers [x[src] | x[dst]] itself: no index_select, no [E, 2H] concat --
+            # inference and training alike, `_EdgeLinear` carries the gradients); the rest of each MLP runs on the type's
+            # [E_t, hidden] rows on the HIP Linear
+            plan = ops.plan_for(adjacency_lists, num_nodes)
+            grad = not _no_grad_needed(node_states, *self.parameters())
+            use_dst = self.__use_target_state_as_message_input
+            if grad:
+                w_stack = _scoped(self, "edge_w0", lambda: torch.stack([l.weight for l in first]))
+                hid = edge_linear_autograd(node_states, plan, w_stack, use_dst)
+            else:
+                hid = ops.edge_linear(node_states, adjacency_lists, [l.weight for l in first], use_dst)
+            out_dim = mlps[0].linears[-1].out_features
+            messages = None if grad else torch.empty(hid.shape[0], out_dim, dtype=torch.float32, device=hid.device)
+            outs, off = [], 0
+            for (src, _), edge_mlp in zip(adjacency_lists, mlps):
+                n = int(src.shape[0])
+                mods = edge_mlp.modules_in_order
+                rest = mods[next(i for i, m in enumerate(mods) if isinstance(m, nn.Linear)) + 1:]
+                h = hid[off:off + n]
+                last = max((i for i, m in enumerate(rest) if isinstance(m, nn.Linear)), default=-1)
+                for i, m in enumerate(rest):
+                    if not isinstance(m, nn.Linear):
+                        h = m(h)
+                    elif grad:
+                        h = dense.linear(h, m.weight, m.bias)
+                    else:   # the type's last Linear writes its block of the message matrix in place: no concat
+                        h = ops.linear(h, m.weight, m.bias, out=messages[off:off + n] if i == last and n > 0 else None)
+                if grad:
+                    outs.append(h)
+                elif last < 0 and n > 0:
+                    messages[off:off + n].copy_(h)
+                off += n
+            if grad:
+                messages = torch.cat(outs, dim=0)
+            if (not grad) and self.__aggregation_fn in ops.REDUCE_IDS and messages.shape[1] % 4 == 0:
+                return self._aggregate_and_update(messages, None, plan, col=plan.perm, type_bits=0)
+            return self._update(segment_reduce(messages, plan, self.__aggregation_fn), False)
+
         # general per-edge path
         all_targets, all_messages = [], []
         for (src, dst), feats, edge_mlp in zip(adjacency_lists, edge_features,

@@ -98,3 +98,57 @@ def test_mlp_layer_hidden_64_takes_the_fused_kernel_and_matches_the_oracle(agg, 
         assert ("k_gather_update" in ran) == fused, ran
     assert torch.equal(outs[True], outs[False])
     np.testing.assert_allclose(outs[True].cpu().numpy(), want.numpy(), rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("hidden", [[64], [32, 64]])
+@pytest.mark.parametrize("use_target", [True, False])
+def test_deeper_edge_mlps_run_their_first_linear_on_the_grouped_gemm(hidden, use_target, monkeypatch):
+    """mlp_hidden_layers > 0 (mlp.py:50-77) without edge features: no index_select / [E, 2H] concat -- the first Linear of
+    every edge type is the grouped per-edge GEMM (inference and training), the rest runs on the type's rows.  Checked
+    against the layer's own CPU-tensor route (= the reference's arithmetic, tests/test_torch_route_cpu.py): outputs 1e-5,
+    every gradient 2e-5 relative."""
+    import copy
+    from ptgnn_amd import layers as L, ops, workloads
+    mb = workloads.batched_graphs(5, 800, 3, 2.5, seed=3)
+    N, H = mb["num_nodes"], 64
+    adj = mb["adjacency_lists"]
+    adj = adj + [(d, s) for s, d in adj] + [(torch.arange(N), torch.arange(N))]
+    T = len(adj)
+    torch.manual_seed(8)
+    cpu_layer = L.MlpMessagePassingLayer(H, H, 64, T, "max", use_target_state_as_message_input=use_target,
+                                         mlp_hidden_layers=hidden)
+    gpu_layer = copy.deepcopy(cpu_layer).cuda()
+    x = workloads.node_states(N, H, seed=4)
+    feats = [torch.empty(a[0].shape[0], 0) for a in adj]
+    cadj = to_cuda_adj(adj)
+
+    def no_gather(*a, **k):
+        raise AssertionError("index_select on the per-edge path")
+    # inference
+    with torch.no_grad():
+        want = cpu_layer.eval()(x, adj, None, {}, {}, feats)
+    ops.clear_plan_cache()
+    before = ops.launch_counts()
+    monkeypatch.setattr(torch.Tensor, "index_select", no_gather)
+    with torch.no_grad():
+        got = gpu_layer.eval()(x.cuda(), cadj, None, {}, {}, empty_feats(cadj, "cuda"))
+    monkeypatch.undo()
+    ran = ops.launches_since(before)
+    assert "k_stream_edge" in ran or "k_edge_linear" in ran, ran
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=TOL)
+    # training: output, d x and every parameter gradient
+    xc = x.clone().requires_grad_(True)
+    yc = cpu_layer.train()(xc, adj, None, {}, {}, feats)
+    gout = torch.linspace(-1, 1, yc.numel()).view_as(yc)
+    yc.backward(gout)
+    xg = x.cuda().requires_grad_(True)
+    ops.clear_plan_cache()
+    monkeypatch.setattr(torch.Tensor, "index_select", no_gather)
+    yg = gpu_layer.train()(xg, cadj, None, {}, {}, empty_feats(cadj, "cuda"))
+    monkeypatch.undo()
+    yg.backward(gout.cuda())
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yc.detach().numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=0, atol=2e-5 * max(1.0, float(xc.grad.abs().max())))
+    for (k, pc), (_, pg) in zip(cpu_layer.named_parameters(), gpu_layer.named_parameters()):
+        np.testing.assert_allclose(pg.grad.cpu().numpy(), pc.grad.numpy(), rtol=0,
+                                   atol=2e-5 * max(1.0, float(pc.grad.abs().max())), err_msg=k)
