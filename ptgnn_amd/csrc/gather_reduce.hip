@@ -31,7 +31,6 @@
 #include <mutex>
 
 #include "dense_common.h"   // f32x16, kcol(), act_apply(): the fused node update below multiplies like the GEMM kernels
-#include "stream_gemm.h"    // num_compute_units()
 
 namespace ptgnn_amd {
 namespace {
@@ -570,9 +569,9 @@ __global__ __launch_bounds__(256) void k_long_rows(Args a) {
 // writes [N, 64] once more and costs 17-21 us per layer against an ~11 us copy floor (profiles/r04: `linear` 0.33 of the MFMA
 // peak, i.e. it is a memory pass).  Here a workgroup of 8 waves aggregates 32 destination rows exactly as k_gather_reduce
 // does (a row per 16-lane group, CSR order, the same prefetched groups of 8 slots, GELU + LayerNorm in registers), parks
-// the 32 normalised rows in LDS, and H' / 32 of its waves multiply the tile with the weight matrix -- copied into LDS at the
-// start of the workgroup, behind the first gather round trip -- on v_mfma_f32_32x32x2_f32 in the library's one K order
-// (`kcol`), add the bias, apply the activation, and the tile leaves as 256-byte rows.  Same bits as
+// the 32 normalised rows in LDS, and its eight waves multiply the tile with the weight matrix -- copied into LDS at the
+// start of the workgroup, behind the first gather round trip -- on the matrix cores in the library's one K order
+// (`kcol`), add the bias, apply the activation and store their 16 x 16 tiles.  Same bits as
 // ptgnn_amd_gather_reduce_f32 followed by ptgnn_amd_linear_f32.  The aggregate never exists in memory.
 // Every row folds serially in slot order here, whatever its length (no hub / long-row launches): the host takes this
 // kernel for minibatch-sized plans only, where a row beyond a few hundred in-edges is an oddity, not a workload.
@@ -590,27 +589,22 @@ constexpr int kUpdLd = kUpdM + 4;     // LDS row stride: 16-byte aligned rows, c
 
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
-// M16 = true: the tile product on v_mfma_f32_16x16x4_f32, one 16 x 16 output tile per wave -- all eight waves of the
-// workgroup multiply (16 MFMAs each) instead of out_dim / 32 waves with 32 MFMAs of 32x32x2 each while the others wait: the
-// tail behind the gather, during which the workgroup holds its wave slots and LDS without issuing loads, shrinks 4x.
-// The four k of an instruction are (kcol(s), kcol(s) + 4, kcol(s + 1), kcol(s + 1) + 4): the products of a row meet the
-// accumulator in the SAME order as in two 32x32x2 steps, hence the same bits (asserted on the GPU, tests/test_gpu_gather_update.py).
-// FORM 2: the product WAVE-LOCAL on v_mfma_f32_4x4x1_16b_f32 -- sixteen 4 x 4 blocks per instruction: a wave's own four rows
-// (one per 16-lane group) against output columns 4 b .. 4 b + 3 in block b, i.e. all 64 columns, one k per instruction in
-// `kcol` order (a plain fma chain: the same bits again).  No workgroup barrier behind the gather: the weights are in LDS
-// before it starts (one barrier at the top, where the eight waves are in step anyway), every wave multiplies and stores its
-// rows the moment ITS rows are aggregated and retires -- like the lane groups of k_gather_reduce.
-template <int REDUCE, int FORM>
+// The tile product runs on v_mfma_f32_16x16x4_f32, one 16 x 16 output tile per wave: all eight waves of the workgroup
+// multiply (16 MFMAs each).  The four k of an instruction are (kcol(s), kcol(s) + 4, kcol(s + 1), kcol(s + 1) + 4): the
+// products of a row meet the accumulator in the SAME order as in two 32x32x2 steps of the GEMM kernels, hence the same bits
+// (asserted on the GPU against gather_reduce + linear, tests/test_gpu_gather_update.py).  Measured alternatives (cfg4, per
+// layer; profiles/r05_notes.md 2): unfused 50.1 us; this form 42.2 us; the tile on 32x32x2 (two of the eight waves multiply,
+// rows leave through LDS) 45.8 us; wave-local products on v_mfma_f32_4x4x1 -- no barrier behind the gather -- 53.0 us, and
+// the same with persistent workgroups (weights loaded once) 56.3 us: a chain of 64 dependent 4x4x1 MFMAs per row quad costs
+// more than the barrier it avoids.
+template <int REDUCE>
 __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
-  constexpr bool M16 = FORM == 1;
   extern __shared__ __attribute__((aligned(16))) float upd_smem[];
   constexpr int LPR = 16, ROWS = 32;
   float *const Ws = upd_smem;                                   // [out_dim][kUpdLd]
   float *const As = Ws + u.out_dim * kUpdLd;                    // [32][kUpdLd]  normalised rows
-  float *const Cs = As + ROWS * kUpdLd;                         // [32][out_dim + 4] results (32x32x2 form only)
-  const int ldc = u.out_dim + 4;
-  const int64_t tile = FORM == 2 ? 0 : xcd_swizzle(blockIdx.x, gridDim.x);
-  if (FORM != 2 && tile >= a.num_tiles) return;                  // workgroup-uniform
+  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile >= a.num_tiles) return;                               // workgroup-uniform
   // the weights: issued first, they travel behind the rowptr / col / row round trips of the gather below
   // (held in registers until the gather is done: a load -> ds_write pair up front would wait for the load right here)
   const int wq = u.out_dim * (kUpdM / 4);                        // float4 pieces of W: 512 .. 2048
@@ -625,71 +619,6 @@ __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
   const int64_t row0 = a.row_begin + tile * ROWS;
   const int64_t row = row0 + grp;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if constexpr (FORM == 2) {
-    // PERSISTENT: the weights go to LDS once per workgroup, then every wave walks row quads on its own -- no barrier, no
-    // waiting for a neighbour's long row; quads of one XCD are consecutive rows (as the tiles of k_gather_reduce)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = (int)threadIdx.x + j * 512;
-      if (i < wq) *reinterpret_cast<float4 *>(Ws + (i >> 4) * kUpdLd + (i & 15) * 4) = wv[j];
-    }
-    __syncthreads();                                              // the only workgroup barrier: W is in LDS
-    const int64_t nquads = (a.num_nodes - a.row_begin + 3) >> 2;
-    const int64_t per = (nquads + kNumXcd - 1) / kNumXcd;         // quads per XCD
-    const int xcd = blockIdx.x % kNumXcd, jb = blockIdx.x / kNumXcd, nj = gridDim.x / kNumXcd;   // grid % 8 == 0
-    float *const Aw = As + wave * (4 * kUpdM);                    // this wave's 4 x 64 slab (every read is a broadcast)
-    const float *const ar = Aw + (lane & 3) * kUpdM;              // A: lane = i + 4 b holds row i of the wave, any block b
-    const int nset = (u.out_dim + 63) >> 6;                       // output columns lane + 64 cs
-    for (int64_t q = (int64_t)jb * 8 + wave; q < per; q += (int64_t)nj * 8) {
-      const int64_t quad = xcd * per + q;
-      if (quad >= nquads) break;
-      const int64_t qrow0 = a.row_begin + quad * 4;
-      const int64_t qrow = qrow0 + (lane >> 4);
-      RowOp<4, LPR, 1, REDUCE, false, false, false> op(a, g, 0);
-      if (qrow < a.num_nodes) {
-        const int beg = a.rowptr[qrow], end = a.rowptr[qrow + 1];
-        op.template reduce_pf<8>(qrow, beg, end, 1);
-        op.finish(end - beg);
-      } else {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) op.acc[0][v] = 0.f;
-      }
-      *reinterpret_cast<float4 *>(Aw + (lane >> 4) * kUpdM + g * 4) = make_float4(op.acc[0][0], op.acc[0][1], op.acc[0][2], op.acc[0][3]);
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-      for (int cs = 0; cs < nset; ++cs) {
-        const int colx = cs * 64 + lane;
-        const float *const br = Ws + (colx < u.out_dim ? colx : u.out_dim - 1) * kUpdLd;   // B: lane = j + 4 b holds column 4 b + j
-        f32x4v c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int qq = 0; qq < kUpdM / 8; ++qq) {                  // k = 8 qq + {0, 4, 1, 5, 2, 6, 3, 7}: kcol order
-          const float4 a0 = *reinterpret_cast<const float4 *>(ar + 8 * qq), a1 = *reinterpret_cast<const float4 *>(ar + 8 * qq + 4);
-          const float4 b0 = *reinterpret_cast<const float4 *>(br + 8 * qq), b1 = *reinterpret_cast<const float4 *>(br + 8 * qq + 4);
-          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b0.x, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b1.x, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b0.y, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b1.y, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b0.z, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b1.z, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b0.w, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b1.w, c, 0, 0, 0);
-        }
-        if (colx < u.out_dim) {
-          const float b = u.bias ? u.bias[colx] : 0.f;
-          // D: VGPR i = row i of the quad (the row of lane group i), this lane's column
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float v = u.bias ? c[i] + b : c[i];
-            const float o = u.act == PTGNN_AMD_ACT_TANH ? act_apply<PTGNN_AMD_ACT_TANH>(v)
-                            : (u.act == PTGNN_AMD_ACT_RELU ? act_apply<PTGNN_AMD_ACT_RELU>(v) : v);
-            if (qrow0 + i < a.num_nodes) u.out[(qrow0 + i) * u.ld_out + colx] = o;
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();                            // the slab is reused by the next quad
-    }
-    return;
-  }
   {
     RowOp<4, LPR, 1, REDUCE, false, false, false> op(a, g, 0);
     if (row < a.num_nodes) {
@@ -712,7 +641,7 @@ __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
     return u.act == PTGNN_AMD_ACT_TANH ? act_apply<PTGNN_AMD_ACT_TANH>(v)
                                        : (u.act == PTGNN_AMD_ACT_RELU ? act_apply<PTGNN_AMD_ACT_RELU>(v) : v);
   };
-  if constexpr (M16) {
+  {
     // tile t = (row half, 16-column block): waves stride over the 2 * out_dim / 16 tiles (8 at out_dim 64: one each)
     const int r16 = lane & 15, kq = lane >> 4;
     const int koff = (kq & 1) * 4 + (kq >> 1);                   // this lane's k inside an instruction: base + {0, 4, 1, 5}[kq]
@@ -739,44 +668,6 @@ __global__ __launch_bounds__(512) void k_gather_update(Args a, UpdateArgs u) {
         if (orow < a.num_nodes) u.out[orow * u.ld_out + colx] = activate(v);
       }
     }
-    return;
-  }
-  // column block n of the result on wave (n + blockIdx) % 8: consecutive workgroups put their MFMA waves on different SIMDs
-  const int nblk = u.out_dim >> 5;
-  const int n = (wave + 8 - (int)(blockIdx.x & 7)) & 7;
-  if (n < nblk) {
-    const int li = lane & 31, hi = lane >> 5;
-    f32x16 c;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = 0.f;
-    const float *al = As + li * kUpdLd + hi * 4;
-    const float *bl = Ws + (n * 32 + li) * kUpdLd + hi * 4;
-#pragma unroll
-    for (int ch = 0; ch < kUpdM / 32; ++ch)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {       // steps 4 q .. 4 q + 3 of the chunk: columns 32 ch + 8 q + 4 hi + {0..3} (kcol)
-        const float4 av = *reinterpret_cast<const float4 *>(al + ch * 32 + q * 8);
-        const float4 bv = *reinterpret_cast<const float4 *>(bl + ch * 32 + q * 8);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, c, 0, 0, 0);
-      }
-    const int colx = n * 32 + li;
-    const float b = u.bias ? u.bias[colx] : 0.f;
-    // C fragment: column li, rows (r & 3) + 8 (r >> 2) + 4 hi
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = u.bias ? c[r] + b : c[r];
-      Cs[((r & 3) + 8 * (r >> 2) + 4 * hi) * ldc + colx] = activate(v);
-    }
-  }
-  __syncthreads();
-  const int nq = u.out_dim >> 2;                                  // float4 per output row
-  for (int i = threadIdx.x; i < ROWS * nq; i += 512) {
-    const int r = i / nq, q = i - r * nq;
-    if (row0 + r < a.num_nodes)
-      *reinterpret_cast<float4 *>(u.out + (row0 + r) * u.ld_out + q * 4) = *reinterpret_cast<const float4 *>(Cs + r * ldc + q * 4);
   }
 }
 
@@ -1099,32 +990,15 @@ extern "C" int ptgnn_amd_gather_update_f32(const float *msg, int64_t ld_msg, con
   UpdateArgs u;
   u.w = w; u.bias = bias; u.out_dim = out_dim; u.act = act; u.out = out; u.ld_out = ld_out;
   // A/B + bit-identity test knob: PTGNN_AMD_GATHER_UPDATE_MFMA=32 takes the 32x32x2 form of the tile product
-  // A/B + bit-identity test knob: PTGNN_AMD_GATHER_UPDATE_MFMA = 4 (wave-local 4x4x1 products, the default), 16 (workgroup
-  // tile on 16x16x4, all eight waves), 32 (workgroup tile on 32x32x2, out_dim / 32 waves)
-  const char *mf = getenv("PTGNN_AMD_GATHER_UPDATE_MFMA");
-  const int form = mf && mf[0] == '3' ? 0 : (mf && mf[0] == '1' && mf[1] == '6' ? 1 : 2);
-  const size_t lds = ((size_t)out_dim * kUpdLd + 32 * kUpdLd + (form == 0 ? 32 * (out_dim + 4) : 0)) * sizeof(float);
+  const size_t lds = ((size_t)out_dim * kUpdLd + 32 * kUpdLd) * sizeof(float);
   const unsigned grid = (unsigned)xcd_padded_blocks(a.num_tiles);
-  // FORM 2 is persistent: four 8-wave workgroups per CU (what its 26 KB of LDS and 8 wave slots per SIMD allow), fewer on a
-  // small matrix (one quad per wave at least)
-  int64_t pgrid = (int64_t)num_compute_units() * 4;
-  const int64_t want = ((num_nodes + 3) / 4 + 7) / 8;
-  if (pgrid > want) pgrid = want;
-  pgrid = (pgrid + kNumXcd - 1) / kNumXcd * kNumXcd;
   hipStream_t st = (hipStream_t)stream_;
-#define PTGNN_GU(R)                                                          \
-  do {                                                                       \
-    if (form == 2) k_gather_update<R, 2><<<(unsigned)pgrid, 512, lds, st>>>(a, u); \
-    else if (form == 1) k_gather_update<R, 1><<<grid, 512, lds, st>>>(a, u); \
-    else k_gather_update<R, 0><<<grid, 512, lds, st>>>(a, u);                \
-  } while (0)
   switch (reduce) {
-    case PTGNN_AMD_SUM: PTGNN_GU(PTGNN_AMD_SUM); break;
-    case PTGNN_AMD_MEAN: PTGNN_GU(PTGNN_AMD_MEAN); break;
-    case PTGNN_AMD_MAX: PTGNN_GU(PTGNN_AMD_MAX); break;
-    default: PTGNN_GU(PTGNN_AMD_MIN); break;
+    case PTGNN_AMD_SUM: k_gather_update<PTGNN_AMD_SUM><<<grid, 512, lds, st>>>(a, u); break;
+    case PTGNN_AMD_MEAN: k_gather_update<PTGNN_AMD_MEAN><<<grid, 512, lds, st>>>(a, u); break;
+    case PTGNN_AMD_MAX: k_gather_update<PTGNN_AMD_MAX><<<grid, 512, lds, st>>>(a, u); break;
+    default: k_gather_update<PTGNN_AMD_MIN><<<grid, 512, lds, st>>>(a, u); break;
   }
-#undef PTGNN_GU
   PTGNN_LAUNCH_CHECK();
   count_launch(PTGNN_AMD_KERNEL_GATHER_UPDATE);
   return PTGNN_AMD_OK;
