@@ -372,7 +372,7 @@ def pmc_traffic(workload, kernel):
     cannot be read from inside a plain bench run, so the figure is the profiled one and names its source; null
     when no profile holds the kernel."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(root, f"{rnd}_{workload}_traffic.json")
         try:
             with open(path) as f:

@@ -733,6 +733,7 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
     if reduce not in REDUCE_IDS:
         raise ValueError(f"unknown aggregation function {reduce!r}")
     N = plan.num_nodes
+    caller_out = out
     if out is None:
         out = torch.empty(N, msg_dim, dtype=torch.float32, device=ysrc.device)
     elif tuple(out.shape) != (N, msg_dim) or out.dtype != torch.float32 or not out.is_contiguous():
@@ -752,6 +753,9 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
               + (N * 4.0 * msg_dim if arg is not None else 0.0))
     lo, hi = (0, N) if rows is None else (int(rows[0]), int(rows[1]))
     if rows is not None:
+        if caller_out is None or return_arg:
+            raise _lib.PtgnnAmdError("gather_reduce: a row range needs a caller-owned `out` (the other rows are not "
+                                     "written) and returns no arg")
         nbytes *= (hi - lo) / max(N, 1)
     hub_ws, hub_bytes = _hub_workspace(plan, msg_dim, arg is not None, ysrc.device)
     with _timed("gather_reduce", bytes=nbytes):

@@ -109,8 +109,11 @@ def _flatten(src: torch.Tensor, index: torch.Tensor, dim: int):
     dim = dim % src.dim() if src.dim() else 0
     moved = src.movedim(dim, 0)
     tail = tuple(moved.shape[1:])
+    width = 1
+    for d in tail:
+        width *= int(d)
     if index.dim() == 1:
-        rows = moved.reshape(moved.shape[0], -1)
+        rows = moved.reshape(moved.shape[0], width)
 
         def restore(out_rows, n):
             return out_rows.reshape((n,) + tail).movedim(0, dim)
@@ -118,7 +121,7 @@ def _flatten(src: torch.Tensor, index: torch.Tensor, dim: int):
     idx = index
     for _ in range(idx.dim(), src.dim()):
         idx = idx.unsqueeze(-1)
-    idx = idx.expand(src.shape).movedim(dim, 0).reshape(moved.shape[0], -1)       # [E, C]
+    idx = idx.expand(src.shape).movedim(dim, 0).reshape(moved.shape[0], width)    # [E, C]
     C = idx.shape[1]
     seg = (idx * C + torch.arange(C, dtype=torch.int64).unsqueeze(0)).reshape(-1)
     rows = moved.reshape(-1, 1)
