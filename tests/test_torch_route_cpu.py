@@ -145,3 +145,27 @@ def test_install_registers_the_facade_as_torch_scatter_in_a_fresh_interpreter():
         "print('INSTALL_OK', torch_scatter.__version__)\n" % ROOT)
     proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0 and "INSTALL_OK" in proc.stdout, proc.stdout + proc.stderr
+
+
+def test_host_route_edge_cases_empty_inputs_features_and_empty_edge_types():
+    from ptgnn_amd import layers as L, scatter as S
+    none = torch.zeros(0, dtype=torch.int64)
+    for red, fill in (("sum", 0.0), ("mean", 0.0), ("max", 0.0), ("min", 0.0), ("mul", 1.0)):
+        out = S.scatter(torch.zeros(0, 3), none, dim=0, dim_size=4, reduce=red)
+        assert tuple(out.shape) == (4, 3) and float(out.min()) == fill == float(out.max())
+    v, a = S.scatter_max(torch.zeros(0, 3), none, dim=0, dim_size=4)
+    assert tuple(v.shape) == (4, 3) and int(a.max()) == 0          # arg of an empty segment = src.size(dim) = 0
+    assert tuple(S.scatter(torch.zeros(0), none, dim=0).shape) == (0,)
+    assert bool(torch.isneginf(S.scatter_logsumexp(torch.zeros(0, 2), none, dim=0, dim_size=3)).all())
+    assert float(S.scatter_std(torch.zeros(0, 2), none, dim=0, dim_size=3).abs().max()) == 0.0
+    x = torch.randn(5, 3, requires_grad=True)
+    S.scatter(x[:0], none, dim=0, dim_size=2, reduce="max").sum().backward()
+    assert float(x.grad.abs().max()) == 0.0
+    # layers built with edge features, one edge type empty (graphneuralnetwork.py:162-186 hands features per type)
+    adj = [(torch.tensor([0, 1]), torch.tensor([1, 2])), (none, none), (torch.tensor([3]), torch.tensor([0]))]
+    feats = [torch.randn(2, 2), torch.zeros(0, 2), torch.randn(1, 2)]
+    g = L.GatedMessagePassingLayer(8, 12, 3, "max", edge_feature_dimension=2).eval()
+    m = L.MlpMessagePassingLayer(8, 6, 10, 3, "mean", features_dimension=2).eval()
+    with torch.no_grad():
+        assert tuple(g(torch.randn(4, 8), adj, None, {}, {}, feats).shape) == (4, 8)
+        assert tuple(m(torch.randn(4, 8), adj, None, {}, {}, feats).shape) == (4, 6)
