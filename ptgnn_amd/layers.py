@@ -45,8 +45,8 @@ import torch
 from torch import nn
 
 from ptgnn_amd import _lib, dense, ops, torch_route
-from ptgnn_amd.scatter import (edge_linear as edge_linear_autograd, gather_reduce as gather_reduce_autograd,
-                               segment_reduce)
+from ptgnn_amd.scatter import (edge_linear as edge_linear_autograd, edge_linear_feat as edge_linear_feat_autograd,
+                               gather_reduce as gather_reduce_autograd, segment_reduce)
 
 try:  # inside a ptgnn install the layers ARE ptgnn layers
     from ptgnn.neuralmodels.gnn.messagepassing.abstractmessagepassing import (  # type: ignore
@@ -176,6 +176,8 @@ def _feat_gemm_ok(node_states, edge_features, state_dim: int, out_dim: int, *par
         return False   # float64 / integer / other-device features: the general path (torch.cat promotes like the reference)
     if len({int(f.shape[-1]) for f in edge_features}) != 1:
         return False
+    if params and params[0] == "any-grad":     # shapes only: the caller has a differentiable form (scatter.edge_linear_feat)
+        return True
     return (not torch.is_grad_enabled()) or _no_grad_needed(node_states, *edge_features, *params)
 
 
@@ -382,7 +384,16 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
             agg = ops.gather_reduce(msgs, plan, M, self.__aggregation_fn, type_bits=0, col=plan.perm)
             return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
 
-        # general per-edge path (per-edge dropout / edge features in training): message order = type-major
+        if (not no_feats and p == 0.0 and self.__aggregation_fn in ops.REDUCE_IDS and _edge_training_ok(self.__state_dimension, M)
+                and _feat_gemm_ok(node_states, edge_features, self.__state_dimension, M, "any-grad")):
+            # training with edge features: the same grouped GEMM as one autograd node (scatter._EdgeLinearFeat) -- no
+            # index_select, no [E, H + F] concat; weight / feature / state gradients on the HIP kernels
+            msgs = edge_linear_feat_autograd(node_states, plan, [l.weight for l in self.__edge_message_transformation_layers],
+                                             False, edge_features)
+            agg = segment_reduce(msgs, plan, self.__aggregation_fn)
+            return dense.gru_cell(gru, agg, node_states)
+
+        # general per-edge path (per-edge dropout with edge features, odd widths): message order = type-major
         all_messages = []
         for (src, _), feats, lin in zip(adjacency_lists, edge_features,
                                         self.__edge_message_transformation_layers):
@@ -810,6 +821,26 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
 
         no_feats = self._features_dimension == 0 and not any(f is not None and f.shape[-1] != 0 for f in edge_features)
         H = self.__input_state_dim
+        if ((not no_feats) and isinstance(self.__aggregation_fn, str) and all(l.bias is None for l in first)
+                and len({tuple(l.weight.shape) for l in first}) == 1 and _edge_training_ok(H, first[0].weight.shape[0])
+                and _feat_gemm_ok(node_states, edge_features, H, first[0].weight.shape[0], "any-grad")
+                and not any(isinstance(m, nn.Dropout) and m.p > 0 and self.training for e in mlps for m in e.modules_in_order)):
+            # training with edge features: the first Linear of every edge MLP as ONE differentiable grouped GEMM that gathers
+            # [x[src] | x[dst] | features] itself (scatter._EdgeLinearFeat); the rest of each MLP on the type's rows
+            plan = ops.plan_for(adjacency_lists, num_nodes)
+            hid = edge_linear_feat_autograd(node_states, plan, [l.weight for l in first],
+                                            self.__use_target_state_as_message_input, edge_features)
+            outs, off = [], 0
+            for (src, _), edge_mlp in zip(adjacency_lists, mlps):
+                n = int(src.shape[0])
+                mods = edge_mlp.modules_in_order
+                h = hid[off:off + n]
+                for m in mods[next(i for i, m in enumerate(mods) if isinstance(m, nn.Linear)) + 1:]:
+                    h = dense.linear(h, m.weight, m.bias) if isinstance(m, nn.Linear) else m(h)
+                outs.append(h)
+                off += n
+            messages = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+            return self._update(segment_reduce(messages, plan, self.__aggregation_fn), False)
         if (no_feats and isinstance(self.__aggregation_fn, str) and node_states.dtype == torch.float32
                 and all(l.bias is None for l in first) and len({tuple(l.weight.shape) for l in first}) == 1
                 and _edge_training_ok(H, first[0].weight.shape[0])

@@ -368,6 +368,88 @@ class _EdgeLinear(torch.autograd.Function):
         return d_x, None, None, None, None, d_w
 
 
+class _EdgeLinearFeat(torch.autograd.Function):
+    """msg[off_t + e] = W_t . [x[src_t[e]] ; x[dst_t[e]] (if use_dst) ; feat_t[e]] with per-edge FEATURE rows
+    (gatedmessagepassing.py:57-61, mlpmessagepassing.py:90-98 with the features of graphneuralnetwork.py:162-186), training form.
+
+    forward : the grouped per-edge GEMM whose A rows carry the features as a third K range (ptgnn_amd_edge_linear_feat_f32):
+              the reference's [E, H (+H) + F] message input is never built;
+    backward: the weight's STATE columns and d x exactly as `_EdgeLinear` (split-edge weight-gradient GEMM; grouped GEMM over
+              an identity index + segment sums), the weight's F feature columns and d feat per edge type on the dense HIP
+              kernels (`linear_weight_grad` / `linear` over the type's [E_t, .] rows -- F is a handful of columns)."""
+
+    @staticmethod
+    def forward(ctx, x, plan, use_dst, n_types, *rest):
+        ws, feats = list(rest[:n_types]), list(rest[n_types:])
+        msg = ops.edge_linear(x, plan._adj, [w.detach() for w in ws], use_dst, edge_feats=[f.detach() for f in feats])
+        ctx.plan, ctx.use_dst, ctx.n_types = plan, use_dst, n_types
+        ctx.save_for_backward(x, *ws, *feats)
+        return msg
+
+    @staticmethod
+    def backward(ctx, grad_msg):
+        saved = ctx.saved_tensors
+        T, plan, use_dst = ctx.n_types, ctx.plan, ctx.use_dst
+        x, ws, feats = saved[0], saved[1:1 + T], saved[1 + T:]
+        adj = plan._adj
+        H = x.shape[1]
+        Ks = H * (2 if use_dst else 1)
+        gm = grad_msg.contiguous()
+        need = ctx.needs_input_grad
+        d_x = None
+        d_ws = [None] * T
+        d_fs = [None] * T
+        counts = [int(a[0].shape[0]) for a in adj]
+        if any(need[4:4 + T]):
+            d_state = ops.edge_weight_grad(x, adj, gm, use_dst)                            # [T, M, Ks]
+            off = 0
+            for t, (f, n) in enumerate(zip(feats, counts)):
+                if need[4 + t]:
+                    if n > 0:
+                        d_feat_cols = ops.linear_weight_grad(_pad_cols4(f), gm[off:off + n])[:, : f.shape[1]]
+                    else:
+                        d_feat_cols = gm.new_zeros(gm.shape[1], f.shape[1])
+                    d_ws[t] = torch.cat([d_state[t], d_feat_cols], dim=1)
+                off += n
+        if need[0]:
+            if plan.num_edges == 0:
+                d_x = torch.zeros_like(x)
+            else:
+                wt = [w.detach()[:, :Ks].t().contiguous() for w in ws]                     # [Ks, M] per type
+                g_in = ops.edge_linear(gm, [(i, i) for i in plan.identity_index()], wt, False)   # [E, Ks]
+                tp = plan.transposed_plan()
+                d_x = ops.gather_reduce(g_in[:, :H] if use_dst else g_in, tp, H, "sum", type_bits=0, col=tp.perm)
+                if d_x.shape[0] != x.shape[0]:
+                    d_x = torch.nn.functional.pad(d_x, (0, 0, 0, x.shape[0] - d_x.shape[0]))
+                if use_dst:
+                    d_dst = ops.gather_reduce(g_in[:, H:], plan, H, "sum", type_bits=0, col=plan.perm)
+                    if d_dst.shape[0] == d_x.shape[0]:
+                        d_x = d_x + d_dst
+                    else:
+                        d_x[: d_dst.shape[0]] += d_dst
+        off = 0
+        for t, (w, f, n) in enumerate(zip(ws, feats, counts)):
+            if need[4 + T + t]:
+                d_fs[t] = (ops.linear(gm[off:off + n], w.detach()[:, Ks:].t().contiguous()) if n > 0
+                           else gm.new_zeros(0, f.shape[1]))
+            off += n
+        return (d_x, None, None, None, *d_ws, *d_fs)
+
+
+def _pad_cols4(t: torch.Tensor) -> torch.Tensor:
+    extra = (-t.shape[1]) % 4
+    return t.contiguous() if extra == 0 else torch.nn.functional.pad(t, (0, extra)).contiguous()
+
+
+def edge_linear_feat(x: torch.Tensor, plan: "ops.GraphPlan", weights, use_dst: bool, edge_feats) -> torch.Tensor:
+    """Differentiable grouped per-edge Linear with per-edge feature rows (see `_EdgeLinearFeat`); `weights[t]` is the
+    type's [M, H (+H) + F] nn.Linear weight, `edge_feats[t]` its [E_t, F] fp32 feature rows on x's device."""
+    if plan._adj is None:
+        raise _lib.PtgnnAmdError("edge_linear_feat: the plan must keep its adjacency lists")
+    ws, fs = list(weights), list(edge_feats)
+    return _EdgeLinearFeat.apply(x, plan, bool(use_dst), len(ws), *ws, *fs)
+
+
 def edge_linear(x: torch.Tensor, plan: "ops.GraphPlan", weights, use_dst: bool, dropout_p: float = 0.0,
                 dropout_seed: int = 0) -> torch.Tensor:
     """Differentiable grouped per-edge Linear over the plan's adjacency lists (see `_EdgeLinear`).

@@ -138,3 +138,55 @@ def test_container_feeds_embedded_edge_features_to_the_fused_gather():
     ran = ops.launches_since(before)
     assert ran.get("k_edge_linear", 0) == 2, ran
     assert float((out.output_node_representations.cpu() - want).abs().max()) <= TOL
+
+
+@pytest.mark.parametrize("kind,use_target,hidden", [("ggnn", False, 0), ("mlp", True, 0), ("mlp", False, [32])])
+@pytest.mark.parametrize("F", [8, 5])
+def test_training_with_edge_features_runs_on_the_grouped_gemm_and_matches_the_cpu_route(kind, use_target, hidden, F, monkeypatch):
+    """Round 5: training with per-edge features is ONE autograd node around the grouped per-edge GEMM
+    (scatter._EdgeLinearFeat: no index_select, no [E, H + F] concat).  Output, d x, d features and every parameter gradient
+    against the same layer on CPU tensors (ptgnn_amd/torch_route.py = the reference's arithmetic under torch autograd)."""
+    import copy
+    import numpy as np
+    from ptgnn_amd import layers as L, ops
+    n, H, M = 900, 64, 64
+    adj, g = _graph(n, (2100, 0, 1, 777), seed=3 + F)
+    T = len(adj)
+    torch.manual_seed(5)
+    if kind == "ggnn":
+        cpu_layer = L.GatedMessagePassingLayer(H, M, T, "max", edge_feature_dimension=F)
+    else:
+        cpu_layer = L.MlpMessagePassingLayer(H, H, M, T, "sum", use_target_state_as_message_input=use_target,
+                                             mlp_hidden_layers=hidden, features_dimension=F)
+    gpu_layer = copy.deepcopy(cpu_layer).cuda()
+    x = torch.randn(n, H, generator=g)
+    feats = [torch.randn(int(a[0].shape[0]), F, generator=g) for a in adj]
+    xc = x.clone().requires_grad_(True)
+    fc = [f.clone().requires_grad_(True) for f in feats]
+    yc = cpu_layer.train()(xc, adj, None, {}, {}, fc)
+    gout = torch.linspace(-1, 1, yc.numel()).view_as(yc)
+    yc.backward(gout)
+    xg = x.cuda().requires_grad_(True)
+    fg = [f.cuda().requires_grad_(True) for f in feats]
+    cadj = to_cuda_adj(adj)
+    ops.clear_plan_cache()
+
+    def no_gather(*a, **k):
+        raise AssertionError("index_select on the per-edge path")
+    before = ops.launch_counts()
+    monkeypatch.setattr(torch.Tensor, "index_select", no_gather)
+    yg = gpu_layer.train()(xg, cadj, None, {}, {}, fg)
+    monkeypatch.undo()
+    assert ops.launches_since(before).get("k_edge_linear", 0) >= 1
+    yg.backward(gout.cuda())
+    tol = lambda t: 5e-5 * max(1.0, float(t.abs().max()))  # noqa: E731
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yc.detach().numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=0, atol=tol(xc.grad))
+    for a, b in zip(fg, fc):
+        if b.shape[0]:
+            np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=0, atol=tol(b.grad))
+    for (k, pc), (_, pg) in zip(cpu_layer.named_parameters(), gpu_layer.named_parameters()):
+        if pc.grad is None:
+            assert pg.grad is None or float(pg.grad.abs().max()) == 0.0, k
+            continue
+        np.testing.assert_allclose(pg.grad.cpu().numpy(), pc.grad.numpy(), rtol=0, atol=tol(pc.grad), err_msg=k)
