@@ -946,8 +946,9 @@ def main():
     exit_code = 0
     if rotation is not None and len(rotation) > 1:
         result["config"]["minibatches_rotated"] = len(rotation)
-        result["config"]["edges_per_step_mean"] = round(e_mine, 1)      # what `value` is computed from
-        result["config"]["nodes_per_step_mean"] = round(n_mine, 1)
+        # `value` = edges_per_gpu / (ms_per_step / layers): the MEAN over the timed steps (the per-minibatch sizes are listed below)
+        result["config"]["edges_per_gpu"] = round(e_mine, 1)
+        result["config"]["nodes_per_gpu"] = round(n_mine, 1)
         result["config"]["nodes_per_minibatch"] = [t["N"] for t in rotation]
         result["config"]["edges_per_minibatch"] = [t["E"] for t in rotation]
         try:      # the round-1..4 form of the headline (one minibatch replayed), beside the rotating one
