@@ -25,11 +25,12 @@ gradient through the same grouped GEMM + HIP segment-sum) with the GGNN layer's 
 in as a counter-based hash mask; the table form differentiates through `scatter.gather_reduce` (backward
 = the gather-reduce kernel over a backward plan); GRU / Linear blocks are `ptgnn_amd/dense.py` nodes.
 
-Edge features at inference ride the grouped per-edge GEMM as a third K range of its gathered A rows
-(`ptgnn_amd_edge_linear_feat_f32`; nothing of the reference's [E, H + F] message input exists in memory).
-Edge features in training, deeper edge MLPs and custom aggregation modules take the general per-edge path: torch only
-gathers / concatenates rows, every Linear runs on the HIP GEMM (`ptgnn_amd/dense.py`, any width) and the
-aggregation on the HIP segment-reduce seam with its autograd rule.  fp16 / bf16 node states (AMP) are up-cast
+Edge features ride the grouped per-edge GEMM as a third K range of its gathered A rows (`ptgnn_amd_edge_linear_feat_f32`;
+nothing of the reference's [E, H + F] message input exists in memory) -- inference and, as one autograd node
+(`scatter._EdgeLinearFeat`), training; deeper edge MLPs run their first Linear the same way.  Custom aggregation modules,
+per-edge dropout together with edge features, biased edge MLPs and widths that are not multiples of 32 take the general
+per-edge path: torch only gathers / concatenates rows, every Linear runs on the HIP GEMM (`ptgnn_amd/dense.py`, any width)
+and the aggregation on the HIP segment-reduce seam with its autograd rule.  fp16 / bf16 node states (AMP) are up-cast
 to fp32 on entry and the result is cast back.  No GPU path runs on a vendor BLAS or falls back to torch.
 
 Device dispatch (round 5): tensors on the CPU take `ptgnn_amd/torch_route.py` (plain torch operators, so that the
