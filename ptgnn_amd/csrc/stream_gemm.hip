@@ -1363,7 +1363,13 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   if (addend && (ld_y % 4 != 0 || !aligned16(y) || ld_add % 4 != 0 || !aligned16(addend))) return 0;
   if (k % 64 != 0 || n_out % 32 != 0 || ld_x % 4 != 0 || !aligned16(x) || !aligned16(w)) return 0;
   if (rows >= ((int64_t)1 << 31) * 32) return 0;
-  const int bn = n_out >= 128 ? 128 : n_out;
+  int bn = n_out >= 128 ? 128 : n_out;
+  // A/B knob (scripts/linear_ring_bench.py): PTGNN_AMD_LINEAR_BN=64 takes 64-column slabs, whose [64, K] weights stay resident
+  // in LDS up to K = 576, where the 128-column form needs the panel ring (the GRU backward's K = 384 input-gradient GEMMs)
+  if (const char *bn_env = getenv("PTGNN_AMD_LINEAR_BN")) {
+    const int want = atoi(bn_env);
+    if ((want == 64 || want == 96) && n_out % want == 0 && n_out > want) bn = want;
+  }
   const int nb = bn / 32;
   const char *ring_env = getenv("PTGNN_AMD_LINEAR_RING");                     // "1": force (A/B, parity tests at small K)
   const bool force_ring = ring_env && ring_env[0] == '1', no_ring = ring_env && ring_env[0] == '0';

@@ -28,12 +28,17 @@ for rows, k, n_out in [(115772, 384, 128), (115772, 256, 128), (115772, 128, 128
     x = torch.randn(rows, k, generator=g).cuda()
     w = (torch.randn(n_out, k, generator=g) / k ** 0.5).cuda()
     row = {"rows": rows, "k": k, "n_out": n_out}
-    for name, env in (("default", None), ("ring", "1"), ("no_ring", "0")):
+    for name, env in (("default", None), ("ring", "1"), ("no_ring", "0"), ("bn64_resident", "bn64")):
+        os.environ.pop("PTGNN_AMD_LINEAR_BN", None)
         if env is None:
             os.environ.pop("PTGNN_AMD_LINEAR_RING", None)
+        elif env == "bn64":      # 64-column slabs: the weights stay resident where the 128-column form needs the ring
+            os.environ.pop("PTGNN_AMD_LINEAR_RING", None)
+            os.environ["PTGNN_AMD_LINEAR_BN"] = "64"
         else:
             os.environ["PTGNN_AMD_LINEAR_RING"] = env
         ms = t_med(lambda: ops.linear(x, w))
         row[name] = {"us": round(ms * 1e3, 1), "frac": round(2.0 * rows * k * n_out / ms / 1e9 / 157.3, 3)}
+    os.environ.pop("PTGNN_AMD_LINEAR_BN", None)
     res.append(row)
     print(json.dumps(row), flush=True)
