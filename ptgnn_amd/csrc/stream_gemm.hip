@@ -1364,11 +1364,19 @@ int stream_linear(const float *x, int64_t rows, int32_t k, int64_t ld_x, const f
   if (k % 64 != 0 || n_out % 32 != 0 || ld_x % 4 != 0 || !aligned16(x) || !aligned16(w)) return 0;
   if (rows >= ((int64_t)1 << 31) * 32) return 0;
   int bn = n_out >= 128 ? 128 : n_out;
-  // A/B knob (scripts/linear_ring_bench.py): PTGNN_AMD_LINEAR_BN=64 takes 64-column slabs, whose [64, K] weights stay resident
-  // in LDS up to K = 576, where the 128-column form needs the panel ring (the GRU backward's K = 384 input-gradient GEMMs)
-  if (const char *bn_env = getenv("PTGNN_AMD_LINEAR_BN")) {
-    const int want = atoi(bn_env);
-    if ((want == 64 || want == 96) && n_out % want == 0 && n_out > want) bn = want;
+  // 64-column slabs where the [128, K] slab does not fit LDS but the [64, K] one does (300 < K <= 576: the GRU backward's
+  // K = 3 H input-gradient GEMMs): the weights stay RESIDENT and A is read once per 64-column slab, against the panel ring's
+  // refill barriers every 64 k.  Measured (scripts/linear_ring_bench.py, profiles/r05_notes.md 7): 116 k x 384 -> 128
+  // 127.6 -> 113.0 us (0.57 -> 0.64 of the MFMA peak), 1.25 M x 512 -> 256 2657 -> 2443 us (0.78 -> 0.85); same bits (one K
+  // order).  PTGNN_AMD_LINEAR_BN = 128 | 64 forces either form where it fits (A/B).
+  {
+    const bool fits128 = Slab::bytes(k, 128) + kEpiBytes <= (size_t)kLdsBudget;
+    const bool fits64 = Slab::bytes(k, 64) + kEpiBytes <= (size_t)kLdsBudget;
+    const char *bn_env = getenv("PTGNN_AMD_LINEAR_BN");
+    const int want = bn_env ? atoi(bn_env) : 0;
+    const char *ring_force = getenv("PTGNN_AMD_LINEAR_RING");          // "1" forces the ring, whose slabs are 128 columns
+    const bool ring_forced = ring_force && ring_force[0] == '1';
+    if (!ring_forced && n_out % 128 == 0 && n_out <= 256 && fits64 && (want == 64 || (want != 128 && !fits128))) bn = 64;
   }
   const int nb = bn / 32;
   const char *ring_env = getenv("PTGNN_AMD_LINEAR_RING");                     // "1": force (A/B, parity tests at small K)

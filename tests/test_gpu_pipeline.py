@@ -74,7 +74,8 @@ def test_pipelined_aggregate_gru_equals_the_unsplit_pair_bit_for_bit(form, piece
 @pytest.mark.parametrize("rows,k,n_out,act,expect", [
     (250_000, 128, 128, None, "k_stream_linear"),        # resident slab (>= 3 units per wave: the streaming dispatch)
     (116_000, 128, 128, None, None),                     # below that the tile kernel runs: GEMM + torch add
-    (116_000, 384, 128, None, "k_stream_linear_ring"),   # the GRU backward's d_gh W_hh (K = 3 H): panel ring
+    (116_000, 384, 128, None, "k_stream_linear"),        # the GRU backward's d_gh W_hh (K = 3 H): 64-column resident slabs
+    (116_000, 768, 128, None, "k_stream_linear_ring"),   # K = 3 x 256 (the Typilus stack's last layer): panel ring
     (116_000, 128, 256, "tanh", "k_stream_linear"),
     (5_000, 100, 36, "relu", None),                      # not a streaming shape: GEMM + torch add
     (33, 64, 32, None, None)])
