@@ -166,7 +166,7 @@ def _edge_messages(table: torch.Tensor, adjacency_lists, plan, weights):
     return ops.edge_linear(table, adjacency_lists, weights, False), plan.perm
 
 
-def _feat_gemm_ok(node_states, edge_features, state_dim: int, out_dim: int, *params) -> bool:
+def _feat_gemm_ok(node_states, edge_features, state_dim: int, out_dim: int, *params, shapes_only: bool = False) -> bool:
     """Inference with per-edge features (graphneuralnetwork.py:162-186 -> gatedmessagepassing.py:57-61 /
     mlpmessagepassing.py:96-98): the grouped per-edge GEMM reads the feature rows as a third K range of its A operand
     (ptgnn_amd_edge_linear_feat_f32), so the reference's [E, H (+H) + F] input matrix is never built."""
@@ -177,7 +177,7 @@ def _feat_gemm_ok(node_states, edge_features, state_dim: int, out_dim: int, *par
         return False   # float64 / integer / other-device features: the general path (torch.cat promotes like the reference)
     if len({int(f.shape[-1]) for f in edge_features}) != 1:
         return False
-    if params and params[0] == "any-grad":     # shapes only: the caller has a differentiable form (scatter.edge_linear_feat)
+    if shapes_only:     # the caller has a differentiable form (scatter.edge_linear_feat): gradients are no obstacle
         return True
     return (not torch.is_grad_enabled()) or _no_grad_needed(node_states, *edge_features, *params)
 
@@ -386,7 +386,7 @@ class GatedMessagePassingLayer(AbstractMessagePassingLayer):
             return ops.gru_cell(agg, node_states, gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
 
         if (not no_feats and p == 0.0 and self.__aggregation_fn in ops.REDUCE_IDS and _edge_training_ok(self.__state_dimension, M)
-                and _feat_gemm_ok(node_states, edge_features, self.__state_dimension, M, "any-grad")):
+                and _feat_gemm_ok(node_states, edge_features, self.__state_dimension, M, shapes_only=True)):
             # training with edge features: the same grouped GEMM as one autograd node (scatter._EdgeLinearFeat) -- no
             # index_select, no [E, H + F] concat; weight / feature / state gradients on the HIP kernels
             msgs = edge_linear_feat_autograd(node_states, plan, [l.weight for l in self.__edge_message_transformation_layers],
@@ -824,7 +824,7 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
         H = self.__input_state_dim
         if ((not no_feats) and isinstance(self.__aggregation_fn, str) and all(l.bias is None for l in first)
                 and len({tuple(l.weight.shape) for l in first}) == 1 and _edge_training_ok(H, first[0].weight.shape[0])
-                and _feat_gemm_ok(node_states, edge_features, H, first[0].weight.shape[0], "any-grad")
+                and _feat_gemm_ok(node_states, edge_features, H, first[0].weight.shape[0], shapes_only=True)
                 and not any(isinstance(m, nn.Dropout) and m.p > 0 and self.training for e in mlps for m in e.modules_in_order)):
             # training with edge features: the first Linear of every edge MLP as ONE differentiable grouped GEMM that gathers
             # [x[src] | x[dst] | features] itself (scatter._EdgeLinearFeat); the rest of each MLP on the type's rows
