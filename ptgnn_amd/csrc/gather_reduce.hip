@@ -574,7 +574,11 @@ __global__ __launch_bounds__(256) void k_long_rows(Args a) {
 // (`kcol`), add the bias, apply the activation and store their 16 x 16 tiles.  Same bits as
 // ptgnn_amd_gather_reduce_f32 followed by ptgnn_amd_linear_f32.  The aggregate never exists in memory.
 // Every row folds serially in slot order here, whatever its length (no hub / long-row launches): the host takes this
-// kernel for minibatch-sized plans only, where a row beyond a few hundred in-edges is an oddity, not a workload.
+// kernel for minibatch-sized plans only, where a row beyond a few hundred in-edges is an oddity, not a workload -- and
+// stops taking it for a while when a plan reports hub rows (ptgnn_amd.ops.gather_update_supported reads the plan's hub
+// count back asynchronously).  A workgroup-cooperative fold of such rows inside this kernel was built and dropped: its
+// second fold loop raised the allocation from 62-72 to 76-96 VGPRs, i.e. from four resident workgroups per CU to two,
+// on the path that has no hub rows.
 struct UpdateArgs {
   const float *w;      // [out_dim, M] row-major (nn.Linear layout)
   const float *bias;   // nullable

@@ -144,7 +144,7 @@ class GraphPlan:
 
     __slots__ = ("rowptr", "col", "perm", "type_bits", "num_nodes", "num_edges", "num_types",
                  "num_src_rows", "_backward", "_adj", "_adj_refs", "_inv_perm", "_ready", "_waited",
-                 "_hub_tickets", "hub_entries", "hub_count", "_slot_rows", "_ident", "_transposed", "_uniq",
+                 "_hub_tickets", "hub_entries", "hub_count", "_slot_rows", "_ident", "_transposed", "_uniq", "_hub_posted",
                  "__weakref__")
 
     def __init__(self, rowptr, col, perm, type_bits, num_nodes, num_edges, num_types):
@@ -162,6 +162,7 @@ class GraphPlan:
         self.hub_entries = self.hub_count = None   # (chunk, row) pairs of rows > HUB_THRESHOLD
         self._slot_rows = self._ident = self._transposed = None
         self._uniq = None      # UniqueMessages | pending read-back | False (not worth it / not applicable)
+        self._hub_posted = False   # the hub count's asynchronous read-back has been posted (ops.gather_update_supported)
 
     def may_have_hubs(self) -> bool:
         """Only plans with more edges than the threshold can contain a hub row (whether they do is
@@ -780,9 +781,47 @@ GATHER_UPDATE = os.environ.get("PTGNN_AMD_GATHER_UPDATE", "1") not in ("", "0")
 GATHER_UPDATE_MAX_EDGES = 1 << 21
 
 
+# ... and plans without hub rows: the fused kernel folds every row serially, so a row of > HUB_THRESHOLD in-edges (which the
+# unfused aggregation splits over chunk workgroups) would set its duration.  Whether a plan has such rows is known on the
+# device only (`plan.hub_count`); it is read back asynchronously once per plan, and a non-zero count sends the next
+# GATHER_UPDATE_BACKOFF calls to the unfused pair (both forms are exact: this is a speed decision, never a correctness one).
+GATHER_UPDATE_BACKOFF = 64
+_HUB_PENDING: List[Tuple["torch.cuda.Event", torch.Tensor]] = []
+_HUB_SKIP = [0]
+
+
+def _poll_hub_counts() -> None:
+    for item in list(_HUB_PENDING):
+        ev, host = item
+        if ev.query():
+            _HUB_PENDING.remove(item)
+            if int(host[0]) > 0:
+                _HUB_SKIP[0] = GATHER_UPDATE_BACKOFF
+            _PINNED_FREE.setdefault(1, []).append(host)
+    del _HUB_PENDING[:-16]
+
+
 def gather_update_supported(msg_dim: int, out_dim: int, plan: "GraphPlan") -> bool:
-    return (GATHER_UPDATE and plan.num_edges < GATHER_UPDATE_MAX_EDGES
-            and bool(_lib.load().ptgnn_amd_gather_update_supported(int(msg_dim), int(out_dim))))
+    if not (GATHER_UPDATE and plan.num_edges < GATHER_UPDATE_MAX_EDGES
+            and bool(_lib.load().ptgnn_amd_gather_update_supported(int(msg_dim), int(out_dim)))):
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        return _HUB_SKIP[0] == 0
+    _poll_hub_counts()
+    if plan.hub_count is not None and not plan._hub_posted:
+        plan._hub_posted = True
+        plan.wait()
+        dev = plan.hub_count.device
+        host = _pinned_words(1)
+        with torch.cuda.device(dev):
+            host.copy_(plan.hub_count.to(torch.int64), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        _HUB_PENDING.append((ev, host))
+    if _HUB_SKIP[0] > 0:
+        _HUB_SKIP[0] -= 1
+        return False
+    return True
 
 
 def gather_update(msgs: torch.Tensor, plan: GraphPlan, reduce: str, col: torch.Tensor, type_bits: int, epilogue: int,

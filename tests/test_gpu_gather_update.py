@@ -88,6 +88,7 @@ def test_mlp_layer_hidden_64_takes_the_fused_kernel_and_matches_the_oracle(agg, 
     layer = layer.cuda()
     cadj = to_cuda_adj(adj)
     outs = {}
+    monkeypatch.setattr(ops, "_HUB_SKIP", [0])       # an earlier test's hub plan must not send this one to the unfused pair
     for fused in (True, False):
         monkeypatch.setattr(ops, "GATHER_UPDATE", fused)
         ops.clear_plan_cache()
@@ -153,3 +154,27 @@ def test_deeper_edge_mlps_run_their_first_linear_on_the_grouped_gemm(hidden, use
         # (5e-5: column sums over ~4 000 rows in two different fp32 orders -- the LayerNorm bias gradient sat at 2.1e-5)
         np.testing.assert_allclose(pg.grad.cpu().numpy(), pc.grad.numpy(), rtol=0,
                                    atol=5e-5 * max(1.0, float(pc.grad.abs().max())), err_msg=k)
+
+
+def test_a_plan_with_hub_rows_sends_the_following_calls_to_the_unfused_pair(monkeypatch):
+    """The fused kernel folds every row serially; a plan that reports hub rows (count read back asynchronously, no host
+    synchronisation on the hot path) switches the next GATHER_UPDATE_BACKOFF decisions to gather_reduce + linear."""
+    from ptgnn_amd import ops
+    monkeypatch.setattr(ops, "_HUB_SKIP", [0])
+    monkeypatch.setattr(ops, "_HUB_PENDING", [])
+    g = torch.Generator().manual_seed(2)
+    N, E = 20_000, 60_000
+    src, dst = torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)
+    plain = ops.build_plan(to_cuda_adj([(src, dst)]), N)
+    assert ops.gather_update_supported(64, 64, plain)
+    torch.cuda.synchronize()
+    assert ops.gather_update_supported(64, 64, plain) and ops._HUB_SKIP[0] == 0
+    dst2 = dst.clone()
+    dst2[: ops.HUB_THRESHOLD + 500] = 7                       # one hub row
+    hubby = ops.build_plan(to_cuda_adj([(src, dst2)]), N)
+    assert ops.gather_update_supported(64, 64, hubby)        # the count is not back yet: still fused (exact either way)
+    torch.cuda.synchronize()
+    assert not ops.gather_update_supported(64, 64, plain)    # the read-back has arrived: back off
+    assert ops._HUB_SKIP[0] == ops.GATHER_UPDATE_BACKOFF - 1
+    monkeypatch.setattr(ops, "_HUB_SKIP", [1])
+    assert not ops.gather_update_supported(64, 64, plain) and ops.gather_update_supported(64, 64, plain)
