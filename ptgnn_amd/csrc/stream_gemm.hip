@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
   const int li = lane & 31, hi = lane >> 5;
   const int lofs = hi * 4;
   const int srow = lane >> 3, scol = (lane & 7) * 4;          // this lane's row / column in the store layout
-  float *const sink = reinterpret_cast<float *>(ptgnn_amd_edge_store_sink) + lane * 4;
+  [[maybe_unused]] float *const sink = reinterpret_cast<float *>(ptgnn_amd_edge_store_sink) + lane * 4;
   const float *const bl = smem + li * sl.ld + hi * 4;
   const int cbs = 32 * sl.ld;
 
