@@ -56,7 +56,7 @@ def _index_plan(index: torch.Tensor, num_samples: int) -> "ops.GraphPlan":
 
 def _pool(values: torch.Tensor, index: torch.Tensor, num_samples, reduce: str) -> torch.Tensor:
     if not values.is_cuda:    # device dispatch: CPU tensors take the plain-torch route (ptgnn_amd/torch_route.py)
-        return torch_route.aggregate(values, index, int(num_samples), reduce)
+        return torch_route.segment(values, index, int(num_samples), reduce)    # varsizedsummary.py:35-41: no dtype cast
     plan = _index_plan(index, int(num_samples))
     dt = values.dtype
     return segment_reduce(values.to(torch.float32).contiguous(), plan, reduce).to(dt)
