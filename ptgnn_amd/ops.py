@@ -112,7 +112,8 @@ class _timed:
 def _require_cuda_f32(name: str, t: torch.Tensor, dims: int = 2):
     if not t.is_cuda:
         raise _lib.PtgnnAmdError(
-            f"{name} must live on the GPU: ptgnn_amd has no CPU path (got device {t.device})")
+            f"{name} must live on the GPU: the C-ABI wrappers have no CPU path (got device {t.device}; CPU tensors are served "
+            "one level up, by the layers' and the facade's plain-torch route)")
     if t.dtype != torch.float32:
         raise _lib.PtgnnAmdError(f"{name} must be float32 (got {t.dtype})")
     if t.dim() != dims:
