@@ -2,35 +2,44 @@
 """bench.py -- edges/s (and nodes/s) per message-passing layer on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one minibatch whose inputs are already resident in
-HBM: build the graph plan (dst-sorted CSR) for that minibatch + every message-passing layer of the
-workload.  Nothing is cached across steps (the plan cache is cleared each step).
+`--gpus N` with N > 1 may be started either way: under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...
+bench.py --gpus N ...` (what the driver does; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or
+plainly as `python bench.py --gpus N`, which re-executes itself under torch.distributed.run on 127.0.0.1 (the reference's
+multi-GPU entry spawns its ranks from one process too: distributedtrainer.py:250-265).
 
-Primary workload: the batch BASELINE.json quotes its metric on -- the Graph2Class-style batch of
-configs[2] (48 graphs, ~116k nodes, 8 raw -> 17 edge types, Typilus GGNN stack: 8 GGNN layers,
-hidden 128, max aggregation, fp32, forward).  `value` = E / t_layer (edges per second per message-passing
-layer, E counted after reverse + self augmentation).  At N=1 the same run also reports configs[1]
-(synthetic 200k-node / 1.1M-edge graph, one MLP-MP layer) under "config2", configs[3] (VarMisuse batch, T = 21,
-8 MLP-MP layers hidden 64) on one GPU under "config4", the per-GPU shard of configs[4]
-(power-law, 1.25M nodes / 12.5M edges, H=256; every row checked against the chunked CPU oracle) under "config5_shard",
-the training step of the Graph2Class stack under "graph2class_train", the README's own architecture under
-"readme_default_arch", and the CPU restatement under "cpu_baseline".  The GPU output of the primary workload and
-of config 2 is compared with the CPU oracle's at FULL size ("parity"); a miss fails the run (exit code 3).
+One "step" = one pass of the hot path over one minibatch whose inputs are already resident in HBM: build the graph plan
+(dst-sorted CSR) for that minibatch + every message-passing layer of the workload.  Nothing is cached across steps (the
+plan cache is cleared each step).
 
-N>1: the path partitions over whole graphs (a minibatch is a disjoint union; the reference's own
-multi-GPU mode hands whole graphs to ranks), so every rank runs the single-GPU step on ITS OWN
-Graph2Class batch: no data-path collective, weak scaling.  After it, by default, the dst-range-sharded cut-edge
-workloads run (ptgnn_amd.sharded: halo all-to-all over RCCL; "cut_edges_variant": the cfg5 shard and the cfg4 stack).
+Primary workload: the batch BASELINE.json quotes its metric on -- the Graph2Class-style batch of configs[2] (48 graphs,
+~116k nodes, 8 raw -> 17 edge types, Typilus GGNN stack: 8 GGNN layers, hidden 128, max aggregation, fp32, forward).
+`value` = E / t_layer (edges per second per message-passing layer, E counted after reverse + self augmentation).  At N=1
+the same run also reports, each with its own full-size parity against the CPU oracle (benchmarks/*.py):
+  config1            configs[0] as the reference batches it (3 000-node cap): GGNN-64 layer and the shipped PPI stack
+  config2            configs[1]: synthetic 200k / 1.1M graph, one MLP-MP layer
+  config3_sum        configs[2] with sum aggregation
+  config4, config4_ggnn   configs[3] on one GPU: the shipped MLP-MP stack and the GGNN variant with global exchange
+  config5_shard      the per-GPU shard of configs[4], every row checked; sharded_cfg5: the same shard through the dst-range
+                     code path (process group, halo all-to-all) with its one-GPU counterpart beside it
+  graph2class_train, readme_default_arch    training steps (the README's own quantity)
+  cpu_baseline       the CPU restatement timed on this box's host cores
+`parity` (top level) rolls every config up: `strict_1e-5` and `configs_on_relaxed_bar`.  A parity miss fails the run (exit
+code 3).
+
+N>1: the path partitions over whole graphs (a minibatch is a disjoint union; the reference's own multi-GPU mode hands
+whole graphs to ranks), so every rank runs the single-GPU step on ITS OWN Graph2Class batch: no data-path collective,
+weak scaling.  After it, by default, the dst-range-sharded cut-edge workloads run (ptgnn_amd.sharded: halo all-to-all over
+RCCL): `sharded_cfg5` (top level) and `cut_edges_variant`.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
-import time
 
 import torch
 
@@ -38,18 +47,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-_T0 = time.perf_counter()
-
-
-def _log(msg):
-    """Progress on stderr (stdout carries exactly one JSON line)."""
-    if int(os.environ.get("RANK", "0")) == 0:
-        sys.stderr.write(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}\n")
-        sys.stderr.flush()
-
-
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+from benchmarks import common as C  # noqa: E402
+from benchmarks.common import _log  # noqa: E402
 
 
 def parse():
@@ -78,809 +77,52 @@ def parse():
                    help="N>1: the per-rank graphs as ONE disjoint-union batch with global node ids, split by "
                         "ptgnn_amd.sharded (no-cut detection = one all-reduce per minibatch)")
     p.add_argument("--no-sharded-variants", action="store_true",
-                   help="N>1: skip the dst-range-sharded cut-edge workloads (cfg5 shard, cfg4 stack) that run after "
-                        "the primary measurement by default")
+                   help="skip the dst-range-sharded cut-edge workloads (cfg5 shard; at N>1 also the cfg4 stack) that run "
+                        "after the primary measurement by default")
     a = p.parse_args()
     a.force_sharded = a.force_sharded or a.global_ids or a.cut_edges   # all three need the process group
     return a
 
 
-def dist_setup(args):
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # Validation hook for 1-GPU boxes: PTGNN_AMD_BENCH_BACKEND=gloo PTGNN_AMD_BENCH_SHARE_GPU=1 runs the N > 1 code
-    # (sharding, all-to-all, rank reductions) with every rank on cuda:0 -- RCCL refuses two ranks per device.  The
-    # numbers of such a run mean nothing; the default (one GPU per rank over RCCL) is what the driver launches.
-    backend = os.environ.get("PTGNN_AMD_BENCH_BACKEND", "nccl")
-    if os.environ.get("PTGNN_AMD_BENCH_SHARE_GPU", "0") not in ("", "0"):
-        local = 0
-        # two PROCESSES time-slicing one GPU turn every cross-stream event wait into a scheduling quantum (measured:
-        # 42 -> 345 ms per cfg5 step with the aggregation's side streams engaged): keep the library on one stream here
-        os.environ.setdefault("PTGNN_AMD_HUB_STREAM", "0")
-    if world > 1 or args.force_sharded or args.sharded_variants:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(0)
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    return rank, world, torch.device("cuda", local if world > 1 else 0)
-
-
-def barrier_sync(world):
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
-
-
-def sum_over_ranks(value, world, dev):
-    if world == 1:
-        return value
-    import torch.distributed as dist
-    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item())
-
-
-def max_over_ranks(seconds, world, dev):
-    if world == 1:
-        return seconds
-    import torch.distributed as dist
-    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
-
-
-# ------------------------------------------------------------------------------------------------
-# workloads
-# ------------------------------------------------------------------------------------------------
-def make_cfg2(dev, rank, world, force_sharded=False, cut_edges=False):
-    """configs[1].  world > 1, default: the path partitions over whole graphs (a minibatch is a disjoint
-    union, graphneuralnetwork.py:418-423; the reference's own multi-GPU mode hands whole graphs to
-    ranks, distributedtrainer.py:250-297), so every rank runs the single-GPU step on ITS OWN 200k-node
-    graph with rank-local node ids: no data-path collective (weak scaling).  `force_sharded` /
-    `cut_edges` go through ptgnn_amd.sharded with global ids instead."""
-    from ptgnn_amd import layers as L, workloads
-    N, E, H = 200_000, 1_100_000, 128
-    torch.manual_seed(1234)
-    layer = L.MlpMessagePassingLayer(H, H, H, 1, "sum").to(dev).eval()
-    if not force_sharded and not cut_edges:
-        adj = workloads.random_graph(N, E, seed=1234 + rank)
-        x = workloads.node_states(N, H, seed=1234 + rank)
-        state = {"adj": [(s.to(dev), d.to(dev)) for s, d in adj], "x": x.to(dev), "cpu_adj": adj, "cpu_x": x}
-    else:
-        from ptgnn_amd import sharded
-        state = sharded.make_weak_scaling_shard(N, E, H, rank, world, dev, seed=1234, cut_edges=cut_edges)
-        state["cut_edges"] = cut_edges
-    desc = "cfg2: synthetic random graph N=200k E=1.1M, 1 MLP-MP layer H=M=128, T=1, sum"
-    if "adj" not in state:
-        desc += (f" per GPU; one graph of {world} x 200k nodes, sources uniform over all ranks "
-                 f"({world - 1}/{world} of the edges cut)" if cut_edges else
-                 f" per GPU; disjoint union of {world} such graphs with global ids, dst-range partition on "
-                 "graph boundaries found by ptgnn_amd.sharded")
-    elif world > 1:
-        desc += f" per GPU; {world} independent graphs, one per GPU (partition over whole graphs)"
-    state.update(layer=layer, N=N, E=E, H=H, layers_per_step=1, desc=desc)
-    return state
-
-
-def step_cfg2(st, world):
-    from ptgnn_amd import ops
-    ops.clear_plan_cache()
-    with torch.no_grad():
-        if "adj" in st:
-            adj = st["adj"]
-            feats = [None]
-            return st["layer"](st["x"], adj, None, {}, {}, feats)
-        from ptgnn_amd import sharded
-        return sharded.layer_forward(st["layer"], st)
-
-
-def make_cfg3(dev, rank=0):
-    """configs[2]; every rank builds its own batch of 48 graphs (seed + rank)."""
-    from ptgnn_amd import layers as L, workloads
-    from ptgnn_amd.gnn import GraphNeuralNetwork
-    H = 128
-    mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234 + rank)
-    T = 17
-    torch.manual_seed(1234)
-    ggnn = L.GatedMessagePassingLayer(H, H, T, "max")
-    r1 = L.ConcatResidualLayer(H)
-    last = L.GatedMessagePassingLayer(2 * H, H, T, "max")
-    mods = [r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last]
-    specs = ([{"kind": "residual_origin", "name": "r1"}] + [ggnn.export_weights()] * 7
-             + [{"kind": "residual_concat", "name": "r1"}, last.export_weights()])
-    net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).to(dev).eval()
-    N = mb["num_nodes"]
-    E_raw = sum(int(a[0].shape[0]) for a in mb["adjacency_lists"])
-    x_cpu = workloads.node_states(N, H, seed=5 + rank)
-    return {"net": net, "x": x_cpu.to(dev), "cpu_x": x_cpu, "cpu_adj": mb["adjacency_lists"], "specs": specs,
-            "adj": [(s.to(dev), d.to(dev)) for s, d in mb["adjacency_lists"]],
-            "n2g": mb["node_to_graph_idx"].to(dev),
-            "refs": {k: v.to(dev) for k, v in mb["reference_node_ids"].items()},
-            "refg": {k: v.to(dev) for k, v in mb["reference_node_graph_idx"].items()},
-            "G": mb["num_graphs"], "N": N, "E": 2 * E_raw + N, "H": H, "layers_per_step": 8,
-            "desc": f"cfg3: Graph2Class-style batch, 48 graphs N={N}, T0=8->T=17, E={2 * E_raw + N} "
-                    "(incl. reverse+self), Typilus GGNN arch: 8 GGNN layers H=128 (+concat residual), max"}
-
-
-def typilus_stack(arch, H, T, dropout, agg=os.environ.get("TRAIN_AGG", "max")):
-    """The two architectures of ptgnn/implementations/typilus/train.py: "ggnn" = create_ggnn_mp_layers
-    (:37-64, the shape BASELINE configs[2] names, at the hidden size given) and "mlp" = create_mlp_mp_layers
-    (:66-99), the DEFAULT the README's V100 numbers were measured on (hidden 64)."""
-    from ptgnn_amd import layers as L
-    if arch == "ggnn":
-        ggnn = L.GatedMessagePassingLayer(H, H, T, agg, dropout_rate=dropout)
-        r1 = L.ConcatResidualLayer(H)
-        last = L.GatedMessagePassingLayer(2 * H, H, T, agg, dropout_rate=dropout)
-        return [r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last]
-    mk = lambda: L.MlpMessagePassingLayer(H, H, H, T, agg, dropout_rate=dropout)          # noqa: E731
-    mk2 = lambda: L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, agg, dropout_rate=dropout)  # noqa: E731
-    r1, r2 = L.ConcatResidualLayer(H), L.ConcatResidualLayer(H)
-    return [r1.pass_through_dummy_layer(), mk(), mk(), mk(), r1, mk2(),
-            r2.pass_through_dummy_layer(), mk(), mk(), mk(), r2, mk2()]
-
-
-def train_cfg3(dev, dropout, steps=8, warmup=4, arch="ggnn", H=128, forward_too=False):
-    """Training step (forward + backward + Adam) of a Typilus stack on the Graph2Class-style batch with a
-    linear classification head on the `supernodes` references -- the quantity README.md:15-17 quotes
-    (1.13 M edges/s on a V100, for the default MLP-MP architecture at hidden 64).  `dropout` is the layers'
-    dropout rate (GGNN: per-edge input dropout; MLP-MP: on the node update)."""
-    from ptgnn_amd import ops, workloads
-    from ptgnn_amd.gnn import GraphNeuralNetwork
-    T = 17
-    mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234)
-    torch.manual_seed(1234)
-    mods = typilus_stack(arch, H, T, dropout)
-    net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).to(dev).train()
-    N = mb["num_nodes"]
-    E = 2 * sum(int(a[0].shape[0]) for a in mb["adjacency_lists"]) + N
-    x = workloads.node_states(N, H, seed=5).to(dev)
-    adj = [(s.to(dev), d.to(dev)) for s, d in mb["adjacency_lists"]]
-    n2g = mb["node_to_graph_idx"].to(dev)
-    refs = {k: v.to(dev) for k, v in mb["reference_node_ids"].items()}
-    refg = {k: v.to(dev) for k, v in mb["reference_node_graph_idx"].items()}
-    head = torch.nn.Linear(net.output_node_state_dim, 100).to(dev)
-    opt = torch.optim.Adam(list(net.parameters()) + list(head.parameters()), lr=1e-4)
-    target = torch.randint(0, 100, (refs["supernodes"].shape[0],), device=dev)
-
-    def forward():
-        ops.clear_plan_cache()
-        return net(node_data={"input": x}, adjacency_lists=adj, edge_feature_data=[], node_to_graph_idx=n2g,
-                   reference_node_ids=refs, reference_node_graph_idx=refg, num_graphs=mb["num_graphs"])
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        out = forward()
-        logits = head(out.output_node_representations[out.node_idx_references["supernodes"]])
-        torch.nn.functional.cross_entropy(logits, target).backward()
-        opt.step()
-
-    def clock(fn, n, w):
-        for _ in range(w):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
-
-    _log(f"  train {arch} dropout {dropout}: inputs built")
-    # median of three blocks of `steps` steps: the README architecture's step is ~90 small launches, and one host hiccup
-    # inside a single 8-step block moved its figure from 7.6-7.8 to 9.8 ms between two runs of the same tree (round 5)
-    blocks = [clock(step, steps, warmup if i == 0 else 0) for i in range(3)]
-    dt = sorted(blocks)[1]
-    _log(f"  train {arch} dropout {dropout}: {dt * 1e3:.2f} ms/step (blocks {[round(b * 1e3, 2) for b in blocks]})")
-    timer = ops.KernelTimer()          # a second pass over the same steps with a HIP-event bracket per C-ABI launch
-    ops.set_kernel_timer(timer)
-    for _ in range(4):
-        step()
-    ops.set_kernel_timer(None)
-    ktab = {k: {kk: v[kk] for kk in ("calls", "avg_ms", "bound", "achieved", "unit", "frac", "total_ms")}
-            for k, v in kernel_table(timer.summary()).items()}
-    res = {"arch": arch, "hidden": H, "dropout": dropout, "ms_per_train_step": round(dt * 1e3, 3),
-           "ms_per_train_step_is": f"median of 3 blocks of {steps} steps",
-           "ms_per_train_step_blocks": [round(b * 1e3, 3) for b in blocks],
-           "kernels_over_4_steps": ktab,
-           "edges_per_sec_readme_convention": round(E / dt, 1), "graphs_per_sec": round(mb["num_graphs"] / dt, 1),
-           "vs_readme_v100_training_1129k": round(E / dt / 1.129e6, 2)}
-    if forward_too:
-        net.eval()
-        with torch.no_grad():
-            df = clock(forward, 3 * steps, warmup)
-        res.update(ms_per_forward=round(df * 1e3, 3), inference_edges_per_sec_readme_convention=round(E / df, 1),
-                   vs_readme_v100_inference_2527k=round(E / df / 2.527e6, 2))
-    return res
-
-
-ROTATE_MINIBATCHES = 4
-
-
-def step_cfg3(st):
-    from ptgnn_amd import ops
-    ops.clear_plan_cache()
-    with torch.no_grad():
-        return st["net"](node_data={"input": st["x"]}, adjacency_lists=st["adj"], edge_feature_data=[],
-                         node_to_graph_idx=st["n2g"], reference_node_ids=st["refs"],
-                         reference_node_graph_idx=st["refg"], num_graphs=st["G"])
-
-
-# ------------------------------------------------------------------------------------------------
-def timed_region(step_fn, steps, warmup, world, dev):
-    """The contract's timed region: W untimed warm-up steps, then EXACTLY K steps bracketed by
-    barrier + synchronize on both sides, max over ranks.  No per-kernel instrumentation runs here:
-    a HIP event pair around every launch costs ~0.1 ms of queue serialisation per kernel on this
-    stack and would be charged to `value`.  The per-kernel HIP-event pass runs right after, over the
-    same K steps of the same inputs (`kernel_pass`)."""
-    for _ in range(warmup):
-        step_fn()
-    barrier_sync(world)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step_fn()
-    barrier_sync(world)
-    dt = time.perf_counter() - t0
-    return max_over_ranks(dt, world, dev), kernel_pass(step_fn, steps, world)
-
-
-def kernel_pass(step_fn, steps, world):
-    """K more steps with a HIP-event bracket around every C-ABI launch (events are recorded on the
-    stream the kernels are launched on); feeds `roofline` and `kernels`."""
-    from ptgnn_amd import ops
-    timer = ops.KernelTimer()
-    barrier_sync(world)
-    ops.set_kernel_timer(timer)
-    for _ in range(steps):
-        step_fn()
-    barrier_sync(world)
-    ops.set_kernel_timer(None)
-    return timer.summary()
-
-
-def kernel_table(summary):
-    table = {}
-    for name, d in summary.items():
-        ms = d["ms"] / d["calls"]
-        row = {"calls": d["calls"], "avg_ms": round(ms, 5)}
-        if name in ("linear", "gru_cell", "edge_linear", "edge_linear_shared", "edge_weight_grad", "linear_weight_grad"):
-            tf = d["flops"] / d["calls"] / (ms * 1e-3) / 1e12
-            row.update(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                       frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
-        else:
-            gbs = d["bytes"] / d["calls"] / (ms * 1e-3) / 1e9
-            row.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                       frac=round(gbs / HBM_PEAK_GBS, 4))
-        row["algorithmic_bytes_per_launch"] = round(d["bytes"] / d["calls"])
-        row["total_ms"] = round(d["ms"], 4)
-        table[name] = row
-    return table
-
-
-# bench kernel bracket -> device kernel names it may resolve to (streaming core first, round-1 tile kernels second)
-PMC_KERNEL = {"linear": ("k_stream_linear", "k_linear_tlp"), "gather_reduce": ("k_gather_reduce",),
-              "gru_cell": ("k_stream_gru", "k_gru"), "edge_linear": ("k_stream_edge", "k_edge_linear")}
-
-
-def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r0N_<workload>_traffic.json, written by scripts/gpu_profile.sh + summarize_prof.py:
-    FETCH_SIZE x2 wide-read correction + WRITE_SIZE, separate --pmc runs; newest round first).  PMC counters
-    cannot be read from inside a plain bench run, so the figure is the profiled one and names its source; null
-    when no profile holds the kernel."""
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
-        path = os.path.join(root, f"{rnd}_{workload}_traffic.json")
-        try:
-            with open(path) as f:
-                prof = json.load(f)
-        except (OSError, ValueError):
-            continue
-        for name in PMC_KERNEL.get(kernel, ()):
-            row = prof.get("kernels", {}).get(name)
-            if row:
-                return {"traffic": row["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch", "traffic_kernel": name,
-                        "traffic_source": f"profiles/{rnd}_{workload}_traffic.json ({prof['source']})"}
-    return {"traffic": None}
-
-
-# wall-clock budget of the sharded cut-edge variants at N > 1 (env override: the watchdog test uses a short one)
-VARIANT_DEADLINE_S = float(os.environ.get("PTGNN_AMD_BENCH_VARIANT_DEADLINE", "240"))
-PARITY_TOL = 1e-5   # BASELINE.json north_star: fp32 node states within 1e-5 of the reference CPU path
-
-
-CPU_FORWARD_BUDGET_S = 6.0    # per thread count: a warm-up slower than this is reported as is (no timed repeats)
-
-
-def _timed_forwards(fn, n_timed=3, budget=None):
-    """1 warm-up + n timed forwards, median (SURVEY.md 8d / BASELINE.md 3).  Time-boxed: when the warm-up alone
-    exceeds the budget (e.g. 256 threads on a cgroup-limited host: 105 s per forward) its time is the figure and
-    the repeats are skipped, so the default bench run stays within minutes.  Returns (seconds, output, n_timed)."""
-    t0 = time.perf_counter()
-    out = fn()
-    warm = time.perf_counter() - t0
-    if warm > (CPU_FORWARD_BUDGET_S if budget is None else budget):
-        return warm, out, 0
-    ts = []
-    for _ in range(n_timed):
-        t0 = time.perf_counter()
-        out = fn()
-        ts.append(time.perf_counter() - t0)
-    ts.sort()
-    return ts[len(ts) // 2], out, n_timed
-
-
-def _thread_counts():
-    """{1, 8, 32, all}, `all` capped at the cores this process may actually use."""
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except AttributeError:
-        usable = os.cpu_count() or 1
-    try:   # cgroup v2 CPU quota of the container, if any
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            usable = max(1, min(usable, -(-int(quota) // int(period))))
-    except (OSError, ValueError):
-        pass
-    return sorted({c for c in (1, 8, 32, usable) if c <= usable})
-
-
-def _sweep(fn):
-    """seconds per forward by thread count.  Counts are tried in increasing order; once doubling-plus the threads
-    no longer buys 20 % (the oracle is bandwidth / framework bound well before 256 threads) larger counts are
-    skipped -- oversubscribed runs cost minutes and are never the baseline."""
-    sweep, out, prev = {}, None, None
-    for c in _thread_counts():
-        if prev is not None and c > 32 and sweep[str(prev[0])] > 0.8 * prev[1]:
-            sweep[str(c)] = None
-            continue
-        torch.set_num_threads(c)
-        sec, out, _ = _timed_forwards(fn)
-        if sweep:
-            prev = (c, min(v for v in sweep.values() if v is not None))
-        sweep[str(c)] = round(sec, 4)
-    return sweep, out
-
-
-def cpu_baseline_cfg2(st, gpu_out):
-    """The CPU restatement of the reference path (kind "port": the reference's own modules live in
-    /root/reference, which does not exist on the GPU box) on this box's host cores, on the SAME config-2 inputs:
-    thread sweep {1, 8, 32, all}, 1 warm-up + 3 timed forwards each, median; parity of the GPU output against
-    the oracle output at full size."""
-    from oracle import mp_oracle as O
-    spec = st["layer"].export_weights()
-    x, adj = st["cpu_x"], st["cpu_adj"]
-    feats = [torch.empty(st["E"], 0)]
-    with torch.no_grad():
-        sweep, want = _sweep(lambda: O.mlp_mp_layer(x, adj, feats, spec))
-    best = min((k for k in sweep if sweep[k] is not None), key=lambda k: sweep[k])
-    parity = {"max_abs": float((gpu_out.cpu() - want).abs().max()), "tol": PARITY_TOL, "n": st["N"],
-              "against": "oracle/mp_oracle.py at full size (N=200k, E=1.1M)"}
-    return {"value": round(st["E"] / sweep[best], 1), "unit": "edges/s", "cores": int(best), "kind": "port",
-            "host_cpus": os.cpu_count(), "seconds_by_threads": sweep,
-            "value_1_thread": round(st["E"] / sweep["1"], 1),
-            "sample": "cfg2 full size (N=200k, E=1.1M), 1 MLP-MP layer forward; per thread count 1 warm-up + 3 timed, "
-                      "median; best thread count reported in `cores`. torch-CPU fp32 restatement of the reference "
-                      "layer (oracle/mp_oracle.py): the reference's own modules cannot be imported on the GPU box "
-                      "(no /root/reference there); their timing in the authoring container is in BASELINE.md"}, parity
-
-
-def cpu_baseline_cfg3(st, gpu_out):
-    """CPU restatement (kind "port") of the 8-layer GGNN stack on this box's host cores.
-    Thread sweep on a BOUNDED sample (the first 8 of the 48 graphs, same weights: 1 warm-up + 3 timed forwards per
-    thread count, median), then ONE forward of the full batch at the best thread count -- timed, and kept as the
-    full-size parity reference for the GPU output."""
-    from oracle import mp_oracle as O
-    from ptgnn_amd import workloads
-    small = workloads.batched_graphs(8, 2500, 8, 2.2, seed=1234)
-    xs = workloads.node_states(small["num_nodes"], st["H"], seed=5)
-    e_small = 2 * sum(int(a[0].shape[0]) for a in small["adjacency_lists"]) + small["num_nodes"]
-    with torch.no_grad():
-        sweep, _ = _sweep(lambda: O.gnn_forward(xs, small["adjacency_lists"], st["specs"], True, True))
-        ranked = sorted((k for k in sweep if sweep[k] is not None), key=lambda k: sweep[k])
-        # the FULL batch (the inputs the GPU line is measured on) at the TWO best thread counts of the sample sweep (an
-        # 8-graph sample can rank them wrongly for the 48-graph batch: VERDICT r03 weak #14), 1 warm-up + 3 timed
-        # forwards each, median (SURVEY.md 8d); the better one is `value`
-        full_by_threads, full, best = {}, None, ranked[0]
-        for cand in ranked[:2]:
-            torch.set_num_threads(int(cand))
-            sec, (want_c, n_edges_c), n_timed_c = _timed_forwards(
-                lambda: O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True), budget=9.0)
-            full_by_threads[cand] = round(sec, 3)
-            if full is None or sec < full:
-                full, best, want, n_edges, n_timed = sec, cand, want_c, n_edges_c, n_timed_c
-    layers = st["layers_per_step"]
-    parity = {"max_abs": float((gpu_out.cpu() - want).abs().max()), "tol": PARITY_TOL, "n": st["N"],
-              "edges_counted_match": bool(n_edges == st["E"]),
-              "against": f"oracle/mp_oracle.py at full size (N={st['N']}, E={st['E']}, 8 GGNN layers)"}
-    return {"value": round(st["E"] / (full / layers), 1), "unit": "edges/s", "cores": int(best),
-            "kind": "port", "host_cpus": os.cpu_count(), "seconds_by_threads_8_graph_sample": sweep,
-            "full_batch_seconds": round(full, 3), "full_batch_timed_forwards": n_timed,
-            "full_batch_seconds_by_threads": full_by_threads,
-            "sample_value": round(e_small / (sweep[best] / layers), 1),
-            "sample_value_1_thread": round(e_small / (sweep["1"] / layers), 1),
-            "sample": f"`value` = E / t_layer of the FULL Graph2Class batch (the GPU line's own inputs: N={st['N']}, "
-                      f"E={st['E']}, {layers}-layer GGNN stack forward) at the best thread count (`cores`), 1 warm-up + "
-                      "3 timed forwards, median -- also the parity reference; the thread count is the better of the two "
-                      f"best of a sweep {{1, 8, 32, all}} on the first 8 of the 48 graphs (N={small['num_nodes']}, E={e_small}; "
-                      "`sample_value*`). torch-CPU fp32 restatement of the reference layers "
-                      "(oracle/mp_oracle.py): the reference's own modules cannot be imported on the GPU box (no "
-                      "/root/reference there); their timing in the authoring container is in BASELINE.md"}, parity
-
-
-def repeat_stats(step_fn, steps, blocks=5):
-    """min / median ms per step over repeated K-step blocks (robust to DVFS and first-touch effects); the
-    contract's `ms_per_step` stays the single timed region."""
-    per = []
-    for _ in range(blocks):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step_fn()
-        torch.cuda.synchronize()
-        per.append((time.perf_counter() - t0) / steps * 1e3)
-    per.sort()
-    return {"blocks": blocks, "steps_per_block": steps, "ms_per_step_min": round(per[0], 4),
-            "ms_per_step_median": round(per[len(per) // 2], 4), "ms_per_step_max": round(per[-1], 4)}
-
-
-def sustained_stats(dev, seconds=10.0, batches=4, block=40):
-    """>= `seconds` of the primary step back to back, ROTATING over `batches` minibatches of different seeds (the timed
-    region replays one minibatch for 80 ms: weights and states stay cache-warm and the clocks never settle; VERDICT r03
-    weak #12).  Blocks of `block` steps are timed with one synchronisation each; reports min / median / max ms per step
-    over the blocks and the first second against the last (DVFS steady state)."""
-    states = [make_cfg3(dev, r) for r in range(batches)]
-    for st in states:                     # warm every batch once (plan caches are cleared per step anyway)
-        step_cfg3(st)
-    torch.cuda.synchronize()
-    per, stamps, i = [], [], 0
-    t_start = time.perf_counter()
-    while time.perf_counter() - t_start < seconds:
-        t0 = time.perf_counter()
-        for _ in range(block):
-            step_cfg3(states[i % batches])
-            i += 1
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        per.append((t1 - t0) / block * 1e3)
-        stamps.append(t1 - t_start)
-    total = time.perf_counter() - t_start
-    first = [p_ for p_, t_ in zip(per, stamps) if t_ <= 1.0] or per[:1]
-    last = [p_ for p_, t_ in zip(per, stamps) if t_ >= total - 1.0] or per[-1:]
-    srt = sorted(per)
-    edges = sum(st["E"] for st in states) / batches
-    med = srt[len(srt) // 2]
-    return {"seconds": round(total, 2), "steps": i, "minibatches_rotated": batches,
-            "nodes_per_minibatch": [st["N"] for st in states], "steps_per_block": block, "blocks": len(per),
-            "ms_per_step_min": round(srt[0], 4), "ms_per_step_median": round(med, 4), "ms_per_step_max": round(srt[-1], 4),
-            "ms_per_step_first_second": round(sum(first) / len(first), 4),
-            "ms_per_step_last_second": round(sum(last) / len(last), 4),
-            "edges_per_sec_per_layer_median": round(edges / (med / 1e3 / 8), 1)}
-
-
-def config5_shard(dev, parity=True):
-    """configs[4] at its per-GPU size (an 8-way dst-range shard of N=10M / E=100M: 1.25M rows, 12.5M in-edges with
-    Zipf-0.8 destinations, H=256): the only BASELINE shape whose node table (1.28 GB) exceeds the 256 MiB
-    Infinity Cache.  One GGNN layer AND one MLP-MP layer (sum; SURVEY.md 8d "1 layer (GGNN and MLP-MP)") through the
-    layer API, the plan build and the aggregation kernel on their own, and oracle parity on EVERY row (oracle/fullrow.py:
-    the chunked CPU oracle, fp32 + float64 attribution of the rows fp32 itself cannot hold to 1e-5)."""
-    from ptgnn_amd import layers as L, ops, workloads
-    N, E, H = 1_250_000, 12_500_000, 256
-    adj = workloads.power_law_graph(N, E, alpha=0.8, seed=1234)
-    cadj = [(adj[0][0].to(dev), adj[0][1].to(dev))]
-    x_cpu = workloads.node_states(N, H, seed=2)
-    x = x_cpu.to(dev)
-    deg = torch.bincount(adj[0][1], minlength=N)
-
-    def clock(fn, k=3, w=2, blocks=3):
-        """Median of `blocks` blocks of k steps (a layer step allocates ~4 GB of fresh outputs; one allocator round trip
-        inside a single 5-step block moved the round-4 figure from 12.2 to 15.6 ms between two runs of the same tree)."""
-        for _ in range(w):
-            fn()
-        times = []
-        for _ in range(blocks):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(k):
-                out = fn()
-            torch.cuda.synchronize()
-            times.append((time.perf_counter() - t0) / k)
-        return sorted(times)[blocks // 2], out
-
-    def events(fn, reps=7):
-        evs = []
-        for _ in range(reps):
-            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s_.record(); fn(); e_.record()
-            evs.append((s_, e_))
-        torch.cuda.synchronize()
-        return sorted(a.elapsed_time(b) for a, b in evs)[reps // 2]
-
-    res = {"workload": "cfg5 per-GPU shard: power-law (Zipf 0.8 destinations) N=1.25M E=12.5M, 1 layer H=M=256, sum"}
-    ok = True
-    for kind in ("ggnn", "mlp"):
-        torch.manual_seed(5)
-        layer = (L.GatedMessagePassingLayer(H, H, 1, "sum") if kind == "ggnn"
-                 else L.MlpMessagePassingLayer(H, H, H, 1, "sum")).eval()
-        spec = layer.export_weights()
-        layer = layer.to(dev)
-
-        def step():
-            ops.clear_plan_cache()
-            with torch.no_grad():
-                return layer(x, cadj, None, {}, {}, [None])
-        dt, out = clock(step)
-        timer = ops.KernelTimer()       # per-kernel HIP-event pass over 3 more steps
-        ops.set_kernel_timer(timer)
-        for _ in range(3):
-            step()
-        ops.set_kernel_timer(None)
-        ktab = {k: {kk: v[kk] for kk in ("calls", "avg_ms", "bound", "achieved", "unit", "frac")}
-                for k, v in kernel_table(timer.summary()).items()}
-        entry = {"ms_per_layer_step": round(dt * 1e3, 3), "timing": "median of 3 blocks of 3 steps",
-                 "edges_per_sec_per_layer": round(E / dt, 1),
-                 "nodes_per_sec_per_layer": round(N / dt, 1), "kernels": ktab}
-        if parity:
-            # EVERY row of the shard against the chunked CPU oracle (round 5; rounds 2-4: a 4 104-row sample)
-            from oracle import fullrow
-            got_cpu = out.cpu()
-            del out
-            torch.cuda.empty_cache()
-            entry["parity"] = fullrow.full_row_parity(spec, adj, x_cpu, got_cpu)
-            _log(f"cfg5 {kind} full-row parity: {entry['parity']}")
-            ok = ok and entry["parity"]["ok"]
-            out = None
-        res["ggnn_layer" if kind == "ggnn" else "mlp_mp_layer"] = entry
-        del layer, out
-    # headline fields = the GGNN layer (the figure rounds 1-2 reported under these keys)
-    res.update({k: res["ggnn_layer"][k] for k in ("ms_per_layer_step", "edges_per_sec_per_layer", "nodes_per_sec_per_layer")})
-    if parity:
-        res["parity"] = {"ok": ok, "ggnn": res["ggnn_layer"]["parity"], "mlp_mp": res["mlp_mp_layer"]["parity"]}
-    plan = ops.plan_for(cadj, N)
-    y = torch.randn(N, H, device=dev)
-    ms = events(lambda: ops.gather_reduce(y, plan, H, "sum"))
-    nbytes = E * (4.0 * H + 4) + N * (4.0 * H + 4)
-    res["gather_reduce"] = {"avg_ms": round(ms, 4), "algorithmic_bytes_per_launch": round(nbytes),
-                            "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "bound": "hbm"}
-    ms_plan = events(lambda: ops.build_plan(cadj, N))
-    pbytes = E * 24.0 + 4.0 * (N + 1)
-    res["plan_build"] = {"avg_ms": round(ms_plan, 4), "algorithmic_bytes_per_launch": round(pbytes),
-                         "achieved": round(pbytes / ms_plan / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(pbytes / ms_plan / 1e6 / HBM_PEAK_GBS, 4), "bound": "hbm",
-                         "note": "hand-written LSD radix passes (ptgnn_amd/csrc/csr_build.hip), HIP events around "
-                                 "ptgnn_amd_csr_build"}
-    return res
-
-
-# ------------------------------------------------------------------------------------------------
-# dst-range-sharded cut-edge workloads (north star: "destination-node sharding ... RCCL all-to-all of cut-edge
-# messages over xGMI"): every layer exchanges halo rows over RCCL.  Secondary entries at N > 1.
-# ------------------------------------------------------------------------------------------------
-def _clock_collective(fn, k, w, world, dev):
-    for _ in range(w):
-        fn()
-    barrier_sync(world)
-    t0 = time.perf_counter()
-    for _ in range(k):
-        fn()
-    barrier_sync(world)
-    return max_over_ranks(time.perf_counter() - t0, world, dev) / k
-
-
-def sharded_cfg5(dev, rank, world, k=5):
-    """configs[4] as a weak-scaling dst-range shard: rank p owns 1.25M nodes of ONE power-law graph of
-    world x 1.25M nodes and the 12.5M in-edges of its nodes (Zipf-0.8 destinations inside the range, sources
-    uniform over ALL ranks' nodes => (world-1)/world of the edges are cut); one GGNN layer, H = M = 256, sum.
-    Per step: halo bookkeeping + plan build + halo all-to-all (RCCL) + edge-free table form."""
-    from ptgnn_amd import layers as L, sharded, workloads
-    N, E, H = 1_250_000, 12_500_000, 256
-    if (os.environ.get("PTGNN_AMD_BENCH_SHARE_GPU", "0") not in ("", "0")
-            and os.environ.get("PTGNN_AMD_BENCH_FULL_VARIANTS", "0") in ("", "0")):
-        # validation mode (every rank on cuda:0 over gloo, whose all-to-all stages 1.3 GB per rank through the host):
-        # the same code on a tenth of the shard -- the numbers of such a run mean nothing anyway
-        N, E = N // 10, E // 10
-    lo = rank * N
-    adj = workloads.power_law_graph(N, E, alpha=0.8, seed=1234 + rank)
-    g = torch.Generator().manual_seed(99 + rank)
-    src = torch.randint(0, world * N, (E,), generator=g, dtype=torch.int64)
-    state = {"adj_global": [(src.to(dev), (adj[0][1] + lo).to(dev))], "range": (lo, lo + N),
-             "x": workloads.node_states(N, H, seed=7 + rank).to(dev),
-             "all_ranges": [(p * N, (p + 1) * N) for p in range(world)]}
-    torch.manual_seed(5)
-    layer = L.GatedMessagePassingLayer(H, H, 1, "sum").to(dev).eval()
-
-    def step():
-        from ptgnn_amd import ops
-        ops.clear_plan_cache()
-        with torch.no_grad():
-            return sharded.layer_forward(layer, state)
-    _log("  cfg5 shard: inputs built")
-    dt = _clock_collective(step, k, 2, world, dev)
-    _log(f"  cfg5 shard: {dt * 1e3:.2f} ms/step (single block)")
-    state["overlap"] = True      # two-block mode: own-source block aggregated under the halo all-to-all
-    dt2 = _clock_collective(step, k, 2, world, dev)
-    _log(f"  cfg5 shard: {dt2 * 1e3:.2f} ms/step (two blocks, overlapped)")
-    state["overlap"] = False
-    shard = sharded.ShardedGraph.build(state["adj_global"], state["range"], all_ranges=state["all_ranges"])
-    y = torch.empty(N, H, device=dev)
-    t_x = 0.0 if shard.no_cut else _clock_collective(lambda: shard.exchange(y), k, 2, world, dev)
-    halo = sum_over_ranks(shard.n_halo, world, dev)
-    return {"workload": f"cfg5 shard x{world}: one power-law graph of {world} x {N / 1e6:.3g}M nodes, {E / 1e6:.3g}M in-edges per GPU, "
-                        f"sources uniform over all GPUs ({world - 1}/{world} of the edges cut), 1 GGNN layer H=M=256, sum",
-            "ms_per_step": round(dt * 1e3, 3), "edges_per_sec_per_layer": round(E * world / dt, 1),
-            "ms_per_step_two_block_overlap": round(dt2 * 1e3, 3),
-            "halo_rows_all_ranks": int(halo), "halo_bytes_per_layer_all_ranks": int(halo) * H * 4,
-            "all_to_all_ms": round(t_x * 1e3, 3), "no_cut": bool(shard.no_cut)}
-
-
-def cfg4_batch():
-    """configs[3]: the VarMisuse batch (40 graphs x ~2000 nodes, T0 = 10) with reverse and self edges: T = 21."""
-    from ptgnn_amd import workloads
-    mb = workloads.batched_graphs(40, 2000, 10, 2.4, seed=21)
-    n, n2g = mb["num_nodes"], mb["node_to_graph_idx"]
-    adj = list(mb["adjacency_lists"])
-    adj = adj + [(d_, s_) for s_, d_ in adj]
-    ar = torch.arange(n, dtype=torch.int64)
-    adj.append((ar, ar))
-    return mb, adj, n, n2g
-
-
-def cfg4_modules(dev, H=64, T=21, with_specs=False):
-    """The 8-layer MLP-MP stack of varmisuse/train.py:42-74 (hidden 64, max, dropout 0.1, concat / mean residuals);
-    `with_specs`: also the oracle's layer-spec list of the same stack (oracle/mp_oracle.py run_layer_stack)."""
-    from ptgnn_amd import layers as L
-    torch.manual_seed(4)
-    mk = lambda: L.MlpMessagePassingLayer(H, H, H, T, "max", dropout_rate=0.1)          # noqa: E731
-    mk2 = lambda: L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, "max", dropout_rate=0.1)  # noqa: E731
-    r1, r2, r3 = L.ConcatResidualLayer(H), L.MeanResidualLayer(H), L.ConcatResidualLayer(H)
-    mods = [r1.pass_through_dummy_layer(), mk(), mk(), mk(), r1, mk2(), r2.pass_through_dummy_layer(), mk(), mk(), r2,
-            r3.pass_through_dummy_layer(), mk(), r3, mk2()]
-    marks = [("residual_origin", "r1"), None, None, None, ("residual_concat", "r1"), None, ("residual_origin", "r2"),
-             None, None, ("residual_mean", "r2"), ("residual_origin", "r3"), None, ("residual_concat", "r3"), None]
-    specs = [m.export_weights() if mk_ is None else {"kind": mk_[0], "name": mk_[1]} for m, mk_ in zip(mods, marks)]
-    mods = [m.to(dev).eval() for m in mods]
-    return (mods, specs) if with_specs else mods
-
-
-def config4(dev, k=20, parity=True):
-    """configs[3] on ONE GPU, unsharded: the stack above over the whole batch through the layers' ordinary forward
-    (the 4-GPU dst-range-sharded form is `cut_edges_variant.cfg4_stack` at N > 1).  Parity, at the full benchmarked
-    size: every MLP-MP layer fed the ORACLE's input of that layer (the stated 1e-5 bar), and the whole stack
-    attributed against a float64 evaluation (8 stacked LayerNorms amplify fp32 rounding: the reference's own fp32
-    arithmetic sits ~7e-5 from float64 end to end, so "within 1e-5 of the reference" is not a property any fp32
-    implementation of this stack can have; the HIP path must be no further from float64 than 2 x the oracle is)."""
-    from ptgnn_amd import layers as L, ops, workloads
-    mb, adj_cpu, n, n2g = cfg4_batch()
-    adj = [(s_.to(dev), d_.to(dev)) for s_, d_ in adj_cpu]
-    n2g = n2g.to(dev)
-    mods, specs = cfg4_modules(dev, with_specs=True)
-    x_cpu = workloads.node_states(n, 64, seed=6)
-    x0 = x_cpu.to(dev)
-    feats = [None] * len(adj)
-    # the layer loop of the container (graphneuralnetwork.py:122-131), as ptgnn runs a stack
-    from ptgnn_amd.gnn import GraphNeuralNetwork
-    net = GraphNeuralNetwork(mods, torch.nn.Identity(), False, False).to(dev).eval()
-
-    def step():
-        ops.clear_plan_cache()
-        with torch.no_grad():
-            return net.gnn(x0, adj, feats, n2g, {}, {})
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(k):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / k
-    e = sum(int(a[0].shape[0]) for a in adj)
-    res = {"workload": f"cfg4: VarMisuse batch N={n}, T=21, E={e} (incl. reverse+self), 8 MLP-MP layers hidden 64 "
-                       "(+ concat / mean residuals), max, one GPU, unsharded",
-           "ms_per_forward": round(dt * 1e3, 4), "edges_per_sec_per_layer": round(e / (dt / 8), 1),
-           "nodes_per_sec_per_layer": round(n / (dt / 8), 1), "edges_per_sec_readme_convention": round(e / dt, 1)}
-    if parity:
-        from oracle import mp_oracle as O
-        with torch.no_grad():
-            trace = []
-            want = O.run_layer_stack(x_cpu, adj_cpu, specs, trace=trace)
-            exact = O.run_layer_stack(x_cpu.double(), adj_cpu, [O.cast_spec(sp, torch.float64) for sp in specs])
-            worst = 0.0
-            for mod, spec, (x_in, x_out) in zip(mods, specs, trace):
-                if spec["kind"] != "mlp":
-                    continue
-                ops.clear_plan_cache()
-                got = mod(x_in.to(dev), adj, None, {}, {}, feats).cpu()
-                worst = max(worst, float((got - x_out).abs().max()))
-            got = step().cpu()
-        ours64, ref64 = float((got.double() - exact).abs().max()), float((want.double() - exact).abs().max())
-        res["parity"] = {"per_layer_max": worst, "tol": PARITY_TOL, "end_to_end": float((got - want).abs().max()),
-                         "ours_vs_fp64": ours64, "oracle_vs_fp64": ref64, "n": n,
-                         "ok": bool(worst <= PARITY_TOL and ours64 <= max(PARITY_TOL, 2.0 * ref64)),
-                         # the literal bar end to end, next to the float64-attributed `ok` (ADVICE r03)
-                         "strict_1e-5": bool(float((got - want).abs().max()) <= PARITY_TOL),
-                         "against": "oracle/mp_oracle.py at full size: per layer (each MLP-MP layer fed the oracle's input "
-                                    "of that layer) and end to end, attributed against a float64 evaluation of the stack"}
-    return res
-
-
-def sharded_cfg4(dev, rank, world, k=5):
-    """configs[3]: the VarMisuse batch (40 graphs x ~2000 nodes, T0 = 10 -> T = 21) through the 8-layer MLP-MP
-    stack of varmisuse/train.py:42-74 (hidden 64, max) over `world` GPUs, in BOTH partitions SURVEY.md 8e names:
-      * "graph_boundaries": cuts snapped to graph starts (sharded.ranges_on_graph_boundaries) -- a disjoint-union
-        batch then has no cut edge, so there is no halo exchange and no bookkeeping: the single-GPU stack on the
-        rank's own graphs (what ptgnn's batches allow, and the configuration meant to scale);
-      * "through_graphs": ranges balanced by in-edge mass alone, cuts go through graphs -- every layer exchanges halo
-        rows over one RCCL all-to-all (`forward_sharded`, edge form over the [own | halo] table), plain and
-        two-block (overlapped) mode: the worst case for this batch, kept to measure the exchange path."""
-    from ptgnn_amd import ops, sharded, workloads
-    H = 64
-    mb, adj, n, n2g = cfg4_batch()
-    indeg = torch.zeros(n, dtype=torch.int64)
-    for _, d_ in adj:
-        indeg += torch.bincount(d_, minlength=n)
-    mods = cfg4_modules(dev)
-    x_all = workloads.node_states(n, H, seed=6)
-    out = {}
-    for name, ranges, no_cut in (("graph_boundaries", sharded.ranges_on_graph_boundaries(n2g, indeg, world), True),
-                                 ("through_graphs", sharded.balanced_node_ranges(indeg, world), False)):
-        lo, hi = ranges[rank]
-        mine = [(s_[(d_ >= lo) & (d_ < hi)].to(dev), d_[(d_ >= lo) & (d_ < hi)].to(dev)) for s_, d_ in adj]
-        e_mine = sum(int(a[0].shape[0]) for a in mine)
-        x = x_all[lo:hi].contiguous().to(dev)
-        n2g_local = n2g[lo:hi].contiguous().to(dev)
-        holder = {}
-
-        def step():
-            ops.clear_plan_cache()
-            with torch.no_grad():
-                shard = sharded.ShardedGraph.build(mine, (lo, hi), all_ranges=ranges, overlap=holder.get("overlap", False),
-                                                   assume_no_cut=no_cut)
-                shard.attach_graph_index(n2g_local, mb["num_graphs"])
-                holder["shard"] = shard
-                return sharded.run_stack(mods, x, shard)
-        dts = [_clock_collective(step, k, 2, world, dev) for _ in range(3)]   # the first block also pays one-time set-up
-        dt = sorted(dts)[1]                                                    # of the collectives: median, like the other lines
-        edges = sum_over_ranks(e_mine, world, dev)
-        entry = {"ms_per_forward": round(dt * 1e3, 3), "ms_per_forward_is": "median of 3 blocks",
-                 "ms_per_forward_blocks": [round(t * 1e3, 3) for t in dts],
-                 "edges_per_sec_per_layer": round(edges / (dt / 8), 1),
-                 "edges_per_sec_readme_convention": round(edges / dt, 1),
-                 "nodes_per_rank_min_max": [int(min(b_ - a_ for a_, b_ in ranges)), int(max(b_ - a_ for a_, b_ in ranges))]}
-        if not no_cut:
-            holder["overlap"] = True
-            entry["ms_per_forward_two_block_overlap"] = round(_clock_collective(step, k, 2, world, dev) * 1e3, 3)
-            holder["overlap"] = False
-            step()
-            shard = holder["shard"]
-            halo = sum_over_ranks(shard.n_halo, world, dev)
-            y = torch.empty(hi - lo, H, device=dev)
-            t_x = 0.0 if shard.no_cut else _clock_collective(lambda: shard.exchange(y), k, 2, world, dev)
-            entry.update(halo_rows_all_ranks=int(halo), halo_bytes_per_layer_all_ranks=int(halo) * H * 4,
-                         all_to_all_ms_per_layer=round(t_x * 1e3, 3), no_cut=bool(shard.no_cut))
-        out[name] = entry
-    out["workload"] = (f"cfg4 sharded x{world}: VarMisuse batch N={n}, T=21, 8 MLP-MP layers hidden 64 (+ residuals), "
-                       "per-minibatch shard build + plan build + 8 layers per forward")
-    return out
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU over RCCL on 127.0.0.1
+    (LOCAL_RANK -> device, bound in benchmarks.common.dist_setup).  Rank 0's single JSON line passes through this
+    process's stdout; the exit code is the ranks'."""
+    shared = os.environ.get("PTGNN_AMD_BENCH_SHARE_GPU", "0") not in ("", "0")
+    have = torch.cuda.device_count()
+    if have < args.gpus and not shared:
+        raise SystemExit(f"--gpus {args.gpus}: this node shows {have} GPU(s) (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    _log(f"no WORLD_SIZE in the environment: launching {args.gpus} ranks under torch.distributed.run")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
-    rank, world, dev = dist_setup(args)
+    rank, world, dev = C.dist_setup(args)
+    # N = 1: the cfg5 shard also runs through the dst-range code path (world-1 process group, nothing cut) unless skipped
+    sharded_leg = (not args.no_sharded_variants and not args.no_secondary) or args.sharded_variants or args.force_sharded
+    from benchmarks import cpu_baseline as CPU, graph2class as G2C, synthetic as SYN
     # CPU legs before the final thread sweep (the cfg4 / cfg5 oracle parity) run on a bounded pool: a 256-thread
     # OpenMP pool on a quota-limited container oversubscribes, and its spinning workers then slow every later
     # host-side step of this process (measured: 29 s to build a batch that takes 1 s)
-    torch.set_num_threads(max(1, min(16, _thread_counts()[-1])))
+    torch.set_num_threads(max(1, min(16, CPU._thread_counts()[-1])))
     from ptgnn_amd import _lib, ops
     _lib.load()
     ops.set_gemm_mode(args.gemm or "stream")
@@ -888,26 +130,24 @@ def main():
 
     rotation = None
     if args.workload == "cfg2":
-        st = make_cfg2(dev, rank, world, args.force_sharded or args.global_ids, args.cut_edges)
-        step = lambda: step_cfg2(st, world)  # noqa: E731
+        st = SYN.make_cfg2(dev, rank, world, args.force_sharded or args.global_ids, args.cut_edges)
+        step = lambda: SYN.step_cfg2(st, world)  # noqa: E731
     else:
-        if args.force_sharded:
-            raise SystemExit("the sharded variants are cfg2 runs: add --workload cfg2")
         # The timed K steps ROTATE over four minibatches of different seeds (round 5): replaying one minibatch keeps its
         # states, messages and weights warm in the 256 MiB Infinity Cache and flattered the round-4 headline by ~2 %
         # (3.84 vs 3.92 ms sustained).  Rank r draws minibatches r, r + world, r + 2 world, ...; parity and the CPU
         # baseline use the first one; the single-minibatch replay figure is reported beside the headline.
-        rotation = [make_cfg3(dev, rank + world * i) for i in range(1 if args.no_rotation else ROTATE_MINIBATCHES)]
+        rotation = [G2C.make_cfg3(dev, rank + world * i) for i in range(1 if args.no_rotation else G2C.ROTATE_MINIBATCHES)]
         st = rotation[0]
         turn = {"i": 0}
 
         def step():
             cur = rotation[turn["i"] % len(rotation)]
             turn["i"] += 1
-            return step_cfg3(cur)
+            return G2C.step_cfg3(cur)
 
     _log(f"workload {args.workload} built; timing the primary region")
-    seconds, summary = timed_region(step, args.steps, args.warmup, world, dev)
+    seconds, summary = C.timed_region(step, args.steps, args.warmup, world, dev)
     ms_per_step = seconds / args.steps * 1e3
     _log(f"primary: {ms_per_step:.3f} ms/step")
     layers = st["layers_per_step"]
@@ -916,15 +156,15 @@ def main():
         e_mine, n_mine = sum(t["E"] for t in timed) / args.steps, sum(t["N"] for t in timed) / args.steps
     else:
         e_mine, n_mine = st["E"], st["N"]
-    edges_all_ranks = sum_over_ranks(e_mine, world, dev)       # per-rank batches differ in size
-    nodes_all_ranks = sum_over_ranks(n_mine, world, dev)
+    edges_all_ranks = C.sum_over_ranks(e_mine, world, dev)       # per-rank batches differ in size
+    nodes_all_ranks = C.sum_over_ranks(n_mine, world, dev)
     value = edges_all_ranks / (seconds / args.steps / layers)
-    ktab = kernel_table(summary)
+    ktab = C.kernel_table(summary)
     dominant = max(ktab, key=lambda k: ktab[k]["total_ms"])
     roof = {k: ktab[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac",
                                            "algorithmic_bytes_per_launch")}
     roof.update(kernel=dominant, avg_ms=ktab[dominant]["avg_ms"])
-    roof.update(pmc_traffic(args.workload, dominant))
+    roof.update(C.pmc_traffic(args.workload, dominant))
 
     result = {
         "metric": "edges/sec per MP layer", "value": round(value, 1), "unit": "edges/s",
@@ -949,6 +189,7 @@ def main():
         "roofline": roof, "kernels": ktab,
     }
     exit_code = 0
+    parities = {}
     if rotation is not None and len(rotation) > 1:
         result["config"]["minibatches_rotated"] = len(rotation)
         # `value` = edges_per_gpu / (ms_per_step / layers): the MEAN over the timed steps (the per-minibatch sizes are listed below)
@@ -957,10 +198,10 @@ def main():
         result["config"]["nodes_per_minibatch"] = [t["N"] for t in rotation]
         result["config"]["edges_per_minibatch"] = [t["E"] for t in rotation]
         try:      # the round-1..4 form of the headline (one minibatch replayed), beside the rotating one
-            sec1, _ = timed_region(lambda: step_cfg3(st), args.steps, 2, world, dev)
+            sec1, _ = C.timed_region(lambda: G2C.step_cfg3(st), args.steps, 2, world, dev)
             result["single_minibatch_replay"] = {
                 "ms_per_step": round(sec1 / args.steps * 1e3, 4),
-                "value": round(sum_over_ranks(st["E"], world, dev) / (sec1 / args.steps / layers), 1),
+                "value": round(C.sum_over_ranks(st["E"], world, dev) / (sec1 / args.steps / layers), 1),
                 "note": "one minibatch replayed K times (the rounds 1-4 headline form): its working set stays cache-warm"}
         except Exception as exc:  # noqa: BLE001
             result["single_minibatch_replay"] = {"error": f"{type(exc).__name__}: {exc}"}
@@ -973,152 +214,82 @@ def main():
         k2 = max(5, args.steps // 2)
         for key, cut in (("global_ids_variant", False), ("cut_edges_variant", True)):
             try:   # secondary numbers must never cost the primary line
-                st2 = make_cfg2(dev, rank, world, True, cut)
-                sec2, _ = timed_region(lambda: step_cfg2(st2, world), k2, 2, world, dev)
+                st2 = SYN.make_cfg2(dev, rank, world, True, cut)
+                sec2, _ = C.timed_region(lambda: SYN.step_cfg2(st2, world), k2, 2, world, dev)
                 result[key] = {"workload": st2["desc"], "ms_per_step": round(sec2 / k2 * 1e3, 4),
                                "edges_per_sec_per_layer": round(st2["E"] * world / (sec2 / k2), 1)}
                 del st2
             except Exception as exc:  # noqa: BLE001
                 result[key] = {"error": f"{type(exc).__name__}: {exc}"}
                 break              # ranks may have diverged: do not enter another collective section
-    if (world > 1 and not args.no_sharded_variants) or args.sharded_variants:
-        # the north-star split: every rank enters these together; neither a failure nor a hang can cost the
-        # primary line (an exception on one rank leaves its peers inside a collective: every rank therefore
-        # carries a watchdog that prints the line measured so far and ends the process)
-        import threading
-        variants = {}
-        result["cut_edges_variant"] = variants
-        try:   # which ranks the collective backend really spans (a first multi-GPU run should explain itself)
-            import torch.distributed as dist
-            mine = torch.tensor([rank, torch.cuda.current_device()], dtype=torch.int64, device=dev)
-            seen = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(seen, mine)
-            result["rccl_ranks_seen"] = [[int(v) for v in t.tolist()] for t in seen]
-            result["collective_backend"] = dist.get_backend()
-        except Exception as exc:  # noqa: BLE001
-            result["rccl_ranks_seen"] = {"error": f"{type(exc).__name__}: {exc}"}
-
-        def bail_out():
-            variants.setdefault("error", f"timed out after {VARIANT_DEADLINE_S} s (a rank failed or a collective hung)")
-            _log("sharded variants timed out: emitting the primary line")
-            if rank == 0:
-                sys.stdout.flush()
-                print(json.dumps(result), flush=True)
-            os._exit(0)
-        watchdog = threading.Timer(VARIANT_DEADLINE_S, bail_out)
-        watchdog.daemon = True
-        watchdog.start()
-        fault = os.environ.get("PTGNN_AMD_BENCH_FAULT", "")      # test hook: "hang:<rank>" stalls that rank here
-        if fault == f"hang:{rank}":
-            _log(f"fault injection: rank {rank} stalls before the sharded variants")
-            threading.Event().wait()
-        for key, fn in (("cfg5_shard", sharded_cfg5), ("cfg4_stack", sharded_cfg4)):
-            try:
-                _log(f"sharded cut-edge variant {key}")
-                variants[key] = fn(dev, rank, world)
-                torch.cuda.empty_cache()
-            except Exception as exc:  # noqa: BLE001
-                variants[key] = {"error": f"{type(exc).__name__}: {exc}"}
-                _log(f"variant {key} failed on rank {rank}: {exc}")
-                if world > 1:
-                    threading.Event().wait()   # peers are inside a collective: let the watchdog end every rank
-                break
-        watchdog.cancel()
-        # the north-star split (dst-range shards + RCCL halo all-to-all) next to the contract's replica line, where a
-        # SCALE record reads it: `value` stays the weak-scaling replica run (one batch per GPU, no collective)
-        lift = {"collective_backend": result.get("collective_backend"), "rccl_ranks_seen": result.get("rccl_ranks_seen")}
-        c5, c4 = variants.get("cfg5_shard"), variants.get("cfg4_stack")
-        if isinstance(c5, dict) and "ms_per_step" in c5:
-            lift["cfg5_shard"] = {k: c5[k] for k in ("ms_per_step", "ms_per_step_two_block_overlap", "all_to_all_ms",
-                                                     "halo_bytes_per_layer_all_ranks", "edges_per_sec_per_layer",
-                                                     "no_cut") if k in c5}
-        if isinstance(c4, dict):
-            for part in ("graph_boundaries", "through_graphs"):
-                if isinstance(c4.get(part), dict):
-                    lift["cfg4_stack_" + part] = {k: c4[part][k] for k in (
-                        "ms_per_forward", "ms_per_forward_two_block_overlap", "all_to_all_ms_per_layer",
-                        "halo_bytes_per_layer_all_ranks", "edges_per_sec_per_layer", "no_cut") if k in c4[part]}
-        if "error" in variants:
-            lift["error"] = variants["error"]
-        result["config"]["dst_range_split"] = lift
-    if rank == 0 and world == 1 and not args.force_sharded:
-        result["repeats"] = repeat_stats(step, args.steps)
+    if (world > 1 and not args.no_sharded_variants) or args.sharded_variants or (world == 1 and sharded_leg
+                                                                                and args.workload == "cfg3"):
+        from benchmarks import dst_range
+        try:
+            C.late_group(dev)
+            dst_range.run_variants(result, rank, world, dev)
+        except Exception as exc:  # noqa: BLE001  (world = 1 only: at N > 1 run_variants handles its own failures)
+            result["sharded_cfg5"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if rank == 0 and world == 1 and not (args.force_sharded and args.workload == "cfg2"):
+        result["repeats"] = C.repeat_stats(step, args.steps)
         if args.workload == "cfg3" and not args.no_sustained:
             _log("sustained: >= 10 s of the primary step over 4 rotating minibatches")
             try:
-                result["sustained"] = sustained_stats(dev, seconds=args.sustained_seconds)
+                result["sustained"] = G2C.sustained_stats(dev, seconds=args.sustained_seconds)
             except Exception as exc:  # noqa: BLE001  (never costs the primary line)
                 result["sustained"] = {"error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.empty_cache()
         if not args.no_secondary:
-            if args.workload == "cfg3":    # configs[1]: the synthetic 200k / 1.1M graph, one MLP-MP layer
-                _log("secondary: config 2")
-                st2 = make_cfg2(dev, 0, 1)
-                k2 = max(10, args.steps)
-                sec2, sum2 = timed_region(lambda: step_cfg2(st2, 1), k2, 3, 1, dev)
-                kt2 = kernel_table(sum2)
-                result["config2"] = {
-                    "workload": st2["desc"], "ms_per_step": round(sec2 / k2 * 1e3, 4),
-                    "edges_per_sec_per_layer": round(st2["E"] / (sec2 / k2), 1),
-                    "nodes_per_sec_per_layer": round(st2["N"] / (sec2 / k2), 1), "kernels": kt2}
-                if not args.no_cpu_baseline:   # full-size parity of config 2 (~2 s of oracle per forward)
-                    from oracle import mp_oracle as O
-                    with torch.no_grad():
-                        want2 = O.mlp_mp_layer(st2["cpu_x"], st2["cpu_adj"], [torch.empty(st2["E"], 0)],
-                                               st2["layer"].export_weights())
-                    err2 = float((step_cfg2(st2, 1).cpu() - want2).abs().max())
-                    result["config2"]["parity"] = {"max_abs": err2, "tol": PARITY_TOL, "n": st2["N"],
-                                                   "against": "oracle/mp_oracle.py at full size"}
-                    if not err2 <= PARITY_TOL:
-                        exit_code = 3
-                    del want2
-                del st2
+            check = not args.no_cpu_baseline
+
+            def leg(key, fn, parity_of=lambda r: r.get("parity")):
+                """One secondary config: its numbers never cost the primary line; its parity record joins the rollup and
+                a miss fails the run."""
+                nonlocal exit_code
+                _log(f"secondary: {key}")
                 try:
-                    _log("secondary: config 5 per-GPU shard")
-                    result["config5_shard"] = config5_shard(dev, parity=not args.no_cpu_baseline)
-                    if not result["config5_shard"].get("parity", {"ok": True})["ok"]:
-                        exit_code = 3
-                except Exception as exc:  # noqa: BLE001  (secondary numbers must never cost the primary line)
-                    result["config5_shard"] = {"error": f"{type(exc).__name__}: {exc}"}
-                try:
-                    _log("secondary: config 4 stack (one GPU, unsharded)")
-                    result["config4"] = config4(dev, parity=not args.no_cpu_baseline)
-                    if not result["config4"].get("parity", {"ok": True})["ok"]:
-                        exit_code = 3
+                    result[key] = fn()
+                    rec = parity_of(result[key])
+                    if check and rec is not None:
+                        parities[key] = rec
+                        if not rec.get("ok", True):
+                            exit_code = 3
                 except Exception as exc:  # noqa: BLE001
-                    result["config4"] = {"error": f"{type(exc).__name__}: {exc}"}
+                    result[key] = {"error": f"{type(exc).__name__}: {exc}"}
                 torch.cuda.empty_cache()
+
+            if args.workload == "cfg3":
+                from benchmarks import ppi, varmisuse
+                leg("config2", lambda: SYN.config2(dev, max(10, args.steps), parity=check))
+                leg("config3_sum", lambda: G2C.config3_sum(dev, args.steps, parity=check))
+                leg("config1", lambda: ppi.config1(dev, parity=check),
+                    parity_of=lambda r: {k: r[k]["parity"] for k in ("ggnn64", "ppi_arch_mlp256") if "parity" in r[k]} or None)
+                leg("config5_shard", lambda: SYN.config5_shard(dev, parity=check))
+                leg("config4", lambda: varmisuse.config4(dev, parity=check))
+                leg("config4_ggnn", lambda: varmisuse.config4(dev, parity=check, arch="ggnn"))
             else:
-                st3 = make_cfg3(dev)
-                k3 = max(10, args.steps // 2)
-                sec3, sum3 = timed_region(lambda: step_cfg3(st3), k3, 3, 1, dev)
-                result["graph2class"] = {
-                    "workload": st3["desc"], "ms_per_forward": round(sec3 / k3 * 1e3, 4),
-                    "edges_per_sec_per_layer": round(st3["E"] / (sec3 / k3 / 8), 1),
-                    "nodes_per_sec_per_layer": round(st3["N"] / (sec3 / k3 / 8), 1),
-                    "edges_per_sec_readme_convention": round(st3["E"] / (sec3 / k3), 1),
-                    "vs_readme_v100_inference_2527k": round(st3["E"] / (sec3 / k3) / 2.527e6, 2),
-                    "kernels": kernel_table(sum3)}
-                del st3
-            torch.cuda.empty_cache()
+                leg("graph2class", lambda: G2C.graph2class_forward(dev, max(10, args.steps // 2)))
             _log("secondary: Graph2Class training steps")
-            result["graph2class_train"] = [train_cfg3(dev, 0.0), train_cfg3(dev, 0.1)]
+            result["graph2class_train"] = [G2C.train_cfg3(dev, 0.0), G2C.train_cfg3(dev, 0.1)]
             torch.cuda.empty_cache()
             # like for like with README.md:15-18: the README's own (default) architecture and settings
             _log("secondary: README default architecture")
-            result["readme_default_arch"] = train_cfg3(dev, 0.1, arch="mlp", H=64, forward_too=True)
+            result["readme_default_arch"] = G2C.train_cfg3(dev, 0.1, arch="mlp", H=64, forward_too=True)
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             _log("cpu baseline (thread sweep) + full-size parity")
-            first = (lambda: step_cfg3(st)) if rotation is not None else step     # parity: the FIRST minibatch of the rotation
+            first = (lambda: G2C.step_cfg3(st)) if rotation is not None else step     # parity: the FIRST minibatch of the rotation
             with torch.no_grad():
                 gpu_out = first()
             gpu_out = gpu_out.output_node_representations if args.workload == "cfg3" else gpu_out
-            base, parity = (cpu_baseline_cfg2 if args.workload == "cfg2" else cpu_baseline_cfg3)(st, gpu_out)
-            result["cpu_baseline"], result["parity"] = base, parity
-            if not parity["max_abs"] <= PARITY_TOL:
+            base, parity = (CPU.cpu_baseline_cfg2 if args.workload == "cfg2" else CPU.cpu_baseline_cfg3)(st, gpu_out)
+            parity["strict_1e-5"] = bool(parity["max_abs"] <= C.PARITY_TOL)
+            result["cpu_baseline"] = base
+            # every config the run checked, rolled up: `strict_1e-5` (AND) and who passes on the float64-attributed bar only
+            result["parity"] = C.parity_rollup(parity, parities)
+            if not parity["max_abs"] <= C.PARITY_TOL:
                 exit_code = 3
-    if world > 1 or args.force_sharded or args.sharded_variants:
+    if C.have_group():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

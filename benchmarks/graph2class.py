@@ -1,0 +1,228 @@
+"""BASELINE configs[2]: the Graph2Class-style batch (48 graphs, ~116k nodes, T0 = 8 -> T = 17) through the Typilus stacks
+of ptgnn/implementations/typilus/train.py -- the forward step of the headline, its sum-aggregation twin, the sustained
+block and the training step."""
+import os
+import time
+
+import torch
+
+from benchmarks.common import _log, kernel_table
+
+
+def make_cfg3(dev, rank=0, agg="max"):
+    """configs[2]; every rank builds its own batch of 48 graphs (seed + rank).  `agg`: "max" as shipped
+    (typilus/train.py:45) or "sum" (SURVEY.md 8d config 3 names both)."""
+    from ptgnn_amd import layers as L, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    H = 128
+    mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234 + rank)
+    T = 17
+    torch.manual_seed(1234)
+    ggnn = L.GatedMessagePassingLayer(H, H, T, agg)
+    r1 = L.ConcatResidualLayer(H)
+    last = L.GatedMessagePassingLayer(2 * H, H, T, agg)
+    mods = [r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last]
+    specs = ([{"kind": "residual_origin", "name": "r1"}] + [ggnn.export_weights()] * 7
+             + [{"kind": "residual_concat", "name": "r1"}, last.export_weights()])
+    net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).to(dev).eval()
+    N = mb["num_nodes"]
+    E_raw = sum(int(a[0].shape[0]) for a in mb["adjacency_lists"])
+    x_cpu = workloads.node_states(N, H, seed=5 + rank)
+    return {"net": net, "x": x_cpu.to(dev), "cpu_x": x_cpu, "cpu_adj": mb["adjacency_lists"], "specs": specs,
+            "adj": [(s.to(dev), d.to(dev)) for s, d in mb["adjacency_lists"]],
+            "n2g": mb["node_to_graph_idx"].to(dev),
+            "refs": {k: v.to(dev) for k, v in mb["reference_node_ids"].items()},
+            "refg": {k: v.to(dev) for k, v in mb["reference_node_graph_idx"].items()},
+            "G": mb["num_graphs"], "N": N, "E": 2 * E_raw + N, "H": H, "layers_per_step": 8,
+            "desc": f"cfg3: Graph2Class-style batch, 48 graphs N={N}, T0=8->T=17, E={2 * E_raw + N} "
+                    f"(incl. reverse+self), Typilus GGNN arch: 8 GGNN layers H=128 (+concat residual), {agg}"}
+
+
+def typilus_stack(arch, H, T, dropout, agg=os.environ.get("TRAIN_AGG", "max")):
+    """The two architectures of ptgnn/implementations/typilus/train.py: "ggnn" = create_ggnn_mp_layers
+    (:37-64, the shape BASELINE configs[2] names, at the hidden size given) and "mlp" = create_mlp_mp_layers
+    (:66-99), the DEFAULT the README's V100 numbers were measured on (hidden 64)."""
+    from ptgnn_amd import layers as L
+    if arch == "ggnn":
+        ggnn = L.GatedMessagePassingLayer(H, H, T, agg, dropout_rate=dropout)
+        r1 = L.ConcatResidualLayer(H)
+        last = L.GatedMessagePassingLayer(2 * H, H, T, agg, dropout_rate=dropout)
+        return [r1.pass_through_dummy_layer()] + [ggnn] * 7 + [r1, last]
+    mk = lambda: L.MlpMessagePassingLayer(H, H, H, T, agg, dropout_rate=dropout)          # noqa: E731
+    mk2 = lambda: L.MlpMessagePassingLayer(2 * H, H, 2 * H, T, agg, dropout_rate=dropout)  # noqa: E731
+    r1, r2 = L.ConcatResidualLayer(H), L.ConcatResidualLayer(H)
+    return [r1.pass_through_dummy_layer(), mk(), mk(), mk(), r1, mk2(),
+            r2.pass_through_dummy_layer(), mk(), mk(), mk(), r2, mk2()]
+
+
+def train_cfg3(dev, dropout, steps=8, warmup=4, arch="ggnn", H=128, forward_too=False):
+    """Training step (forward + backward + Adam) of a Typilus stack on the Graph2Class-style batch with a
+    linear classification head on the `supernodes` references -- the quantity README.md:15-17 quotes
+    (1.13 M edges/s on a V100, for the default MLP-MP architecture at hidden 64).  `dropout` is the layers'
+    dropout rate (GGNN: per-edge input dropout; MLP-MP: on the node update)."""
+    from ptgnn_amd import ops, workloads
+    from ptgnn_amd.gnn import GraphNeuralNetwork
+    T = 17
+    mb = workloads.batched_graphs(48, 2500, 8, 2.2, seed=1234)
+    torch.manual_seed(1234)
+    mods = typilus_stack(arch, H, T, dropout)
+    net = GraphNeuralNetwork(mods, torch.nn.Identity(), True, True).to(dev).train()
+    N = mb["num_nodes"]
+    E = 2 * sum(int(a[0].shape[0]) for a in mb["adjacency_lists"]) + N
+    x = workloads.node_states(N, H, seed=5).to(dev)
+    adj = [(s.to(dev), d.to(dev)) for s, d in mb["adjacency_lists"]]
+    n2g = mb["node_to_graph_idx"].to(dev)
+    refs = {k: v.to(dev) for k, v in mb["reference_node_ids"].items()}
+    refg = {k: v.to(dev) for k, v in mb["reference_node_graph_idx"].items()}
+    head = torch.nn.Linear(net.output_node_state_dim, 100).to(dev)
+    opt = torch.optim.Adam(list(net.parameters()) + list(head.parameters()), lr=1e-4)
+    target = torch.randint(0, 100, (refs["supernodes"].shape[0],), device=dev)
+
+    def forward():
+        ops.clear_plan_cache()
+        return net(node_data={"input": x}, adjacency_lists=adj, edge_feature_data=[], node_to_graph_idx=n2g,
+                   reference_node_ids=refs, reference_node_graph_idx=refg, num_graphs=mb["num_graphs"])
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = forward()
+        logits = head(out.output_node_representations[out.node_idx_references["supernodes"]])
+        torch.nn.functional.cross_entropy(logits, target).backward()
+        opt.step()
+
+    def clock(fn, n, w):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    _log(f"  train {arch} dropout {dropout}: inputs built")
+    # median of three blocks of `steps` steps: the README architecture's step is ~90 small launches, and one host hiccup
+    # inside a single 8-step block moved its figure from 7.6-7.8 to 9.8 ms between two runs of the same tree (round 5)
+    blocks = [clock(step, steps, warmup if i == 0 else 0) for i in range(3)]
+    dt = sorted(blocks)[1]
+    _log(f"  train {arch} dropout {dropout}: {dt * 1e3:.2f} ms/step (blocks {[round(b * 1e3, 2) for b in blocks]})")
+    timer = ops.KernelTimer()          # a second pass over the same steps with a HIP-event bracket per C-ABI launch
+    ops.set_kernel_timer(timer)
+    for _ in range(4):
+        step()
+    ops.set_kernel_timer(None)
+    ktab = {k: {kk: v[kk] for kk in ("calls", "avg_ms", "bound", "achieved", "unit", "frac", "total_ms")}
+            for k, v in kernel_table(timer.summary()).items()}
+    res = {"arch": arch, "hidden": H, "dropout": dropout, "ms_per_train_step": round(dt * 1e3, 3),
+           "ms_per_train_step_is": f"median of 3 blocks of {steps} steps",
+           "ms_per_train_step_blocks": [round(b * 1e3, 3) for b in blocks],
+           "kernels_over_4_steps": ktab,
+           "edges_per_sec_readme_convention": round(E / dt, 1), "graphs_per_sec": round(mb["num_graphs"] / dt, 1),
+           "vs_readme_v100_training_1129k": round(E / dt / 1.129e6, 2)}
+    if forward_too:
+        net.eval()
+        with torch.no_grad():
+            df = clock(forward, 3 * steps, warmup)
+        res.update(ms_per_forward=round(df * 1e3, 3), inference_edges_per_sec_readme_convention=round(E / df, 1),
+                   vs_readme_v100_inference_2527k=round(E / df / 2.527e6, 2))
+    return res
+
+
+ROTATE_MINIBATCHES = 4
+
+
+def step_cfg3(st):
+    from ptgnn_amd import ops
+    ops.clear_plan_cache()
+    with torch.no_grad():
+        return st["net"](node_data={"input": st["x"]}, adjacency_lists=st["adj"], edge_feature_data=[],
+                         node_to_graph_idx=st["n2g"], reference_node_ids=st["refs"],
+                         reference_node_graph_idx=st["refg"], num_graphs=st["G"])
+
+
+
+def sustained_stats(dev, seconds=10.0, batches=4, block=40):
+    """>= `seconds` of the primary step back to back, ROTATING over `batches` minibatches of different seeds (the timed
+    region replays one minibatch for 80 ms: weights and states stay cache-warm and the clocks never settle; VERDICT r03
+    weak #12).  Blocks of `block` steps are timed with one synchronisation each; reports min / median / max ms per step
+    over the blocks and the first second against the last (DVFS steady state)."""
+    states = [make_cfg3(dev, r) for r in range(batches)]
+    for st in states:                     # warm every batch once (plan caches are cleared per step anyway)
+        step_cfg3(st)
+    torch.cuda.synchronize()
+    per, stamps, i = [], [], 0
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < seconds:
+        t0 = time.perf_counter()
+        for _ in range(block):
+            step_cfg3(states[i % batches])
+            i += 1
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        per.append((t1 - t0) / block * 1e3)
+        stamps.append(t1 - t_start)
+    total = time.perf_counter() - t_start
+    first = [p_ for p_, t_ in zip(per, stamps) if t_ <= 1.0] or per[:1]
+    last = [p_ for p_, t_ in zip(per, stamps) if t_ >= total - 1.0] or per[-1:]
+    srt = sorted(per)
+    edges = sum(st["E"] for st in states) / batches
+    med = srt[len(srt) // 2]
+    return {"seconds": round(total, 2), "steps": i, "minibatches_rotated": batches,
+            "nodes_per_minibatch": [st["N"] for st in states], "steps_per_block": block, "blocks": len(per),
+            "ms_per_step_min": round(srt[0], 4), "ms_per_step_median": round(med, 4), "ms_per_step_max": round(srt[-1], 4),
+            "ms_per_step_first_second": round(sum(first) / len(first), 4),
+            "ms_per_step_last_second": round(sum(last) / len(last), 4),
+            "edges_per_sec_per_layer_median": round(edges / (med / 1e3 / 8), 1)}
+
+
+
+def config3_sum(dev, steps=20, parity=True):
+    """configs[2] with SUM aggregation ("max (as shipped) and sum"; aggregation is a parameter of
+    typilus/train.py:39-65): the order-sensitive reduce through 8 tied GGNN layers, timed like the headline (rotating
+    over four minibatches) and checked at full size -- the stated 1e-5 against the fp32 oracle where fp32 holds it,
+    else attributed against a float64 evaluation of the same stack (the code of config 4 / 5)."""
+    from benchmarks.common import attributed_parity
+    from ptgnn_amd import ops
+    states = [make_cfg3(dev, r, agg="sum") for r in range(ROTATE_MINIBATCHES)]
+    for st in states:
+        step_cfg3(st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_cfg3(states[i % len(states)])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    edges = sum(states[i % len(states)]["E"] for i in range(steps)) / steps
+    nodes = sum(states[i % len(states)]["N"] for i in range(steps)) / steps
+    st = states[0]
+    res = {"workload": st["desc"], "ms_per_step": round(dt * 1e3, 4), "minibatches_rotated": len(states),
+           "edges_per_sec_per_layer": round(edges / (dt / 8), 1), "nodes_per_sec_per_layer": round(nodes / (dt / 8), 1),
+           "edges_per_sec_readme_convention": round(edges / dt, 1)}
+    if parity:
+        from oracle import mp_oracle as O
+        ops.clear_plan_cache()
+        got = step_cfg3(st).output_node_representations.cpu()
+        with torch.no_grad():
+            want, n_edges = O.gnn_forward(st["cpu_x"], st["cpu_adj"], st["specs"], True, True)
+            strict = float((got - want).abs().max()) <= 1e-5
+            exact = None
+            if not strict:      # only then pay for the float64 evaluation (~2x the fp32 oracle's time)
+                exact, _ = O.gnn_forward(st["cpu_x"].double(), st["cpu_adj"],
+                                         [O.cast_spec(sp, torch.float64) for sp in st["specs"]], True, True)
+        res["parity"] = attributed_parity(got, want, exact)
+        res["parity"].update(n=st["N"], edges_counted_match=bool(n_edges == st["E"]),
+                             against=f"oracle/mp_oracle.py at full size (N={st['N']}, E={st['E']}, 8 GGNN layers, sum)")
+    return res
+
+
+def graph2class_forward(dev, steps):
+    """The cfg3 forward as a secondary entry of a `--workload cfg2` run."""
+    from benchmarks.common import timed_region
+    st3 = make_cfg3(dev)
+    sec3, sum3 = timed_region(lambda: step_cfg3(st3), steps, 3, 1, dev)
+    return {"workload": st3["desc"], "ms_per_forward": round(sec3 / steps * 1e3, 4),
+            "edges_per_sec_per_layer": round(st3["E"] / (sec3 / steps / 8), 1),
+            "nodes_per_sec_per_layer": round(st3["N"] / (sec3 / steps / 8), 1),
+            "edges_per_sec_readme_convention": round(st3["E"] / (sec3 / steps), 1),
+            "vs_readme_v100_inference_2527k": round(st3["E"] / (sec3 / steps) / 2.527e6, 2),
+            "kernels": kernel_table(sum3)}

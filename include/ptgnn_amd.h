@@ -49,10 +49,11 @@ extern "C" {
  * symbols (`nm -D --defined-only libptgnn_amd.so` lists ptgnn_amd_* and nothing else). */
 #pragma GCC visibility push(default)
 
-/* 101: ptgnn_amd_shard_index gained `bad_index_count` (round 4, mid-signature), ptgnn_amd_gru_cell_csr_f32 and the
- * fused node-update entry points were added (round 5).  Callers check ptgnn_amd_version() >= the version their
- * header was compiled against (the Python host does, ptgnn_amd/_lib.py). */
-#define PTGNN_AMD_VERSION 101 /* 0.1.1 */
+/* 101: ptgnn_amd_shard_index gained `bad_index_count` (round 4, mid-signature); the fused aggregation + node-update
+ * entry point ptgnn_amd_gather_update_f32 was added (round 5).  102: ptgnn_amd_weighted_pool*_f32 (round 6).
+ * Callers check ptgnn_amd_version() >= the version their header was compiled against (the Python host does,
+ * ptgnn_amd/_lib.py). */
+#define PTGNN_AMD_VERSION 102 /* 0.1.2 */
 
 enum {
   PTGNN_AMD_OK = 0,
@@ -288,10 +289,11 @@ int ptgnn_amd_gather_reduce_f32(const float *ysrc, int64_t ld_ysrc,
                                 void *stream);
 /* The same aggregation for the destination rows [row_begin, row_end) only (every pointer and count keeps its
  * whole-plan meaning; rows outside the range are neither read nor written, hub rows outside it are skipped).  A
- * layer's aggregation -> node update chain (gatedmessagepassing.py:63-69) is row-wise after the aggregation, so the
- * host can pipeline it over row ranges: the update of the first range (MFMA-bound) overlaps the aggregation of the
- * second (latency-bound) on another stream -- ptgnn_amd.ops.aggregate_update_pipelined.  Launches over one plan
- * must not overlap EACH OTHER in time (they share `hub_tickets`). */
+ * layer's aggregation -> node update chain (gatedmessagepassing.py:63-69) is row-wise after the aggregation, so a
+ * host MAY pipeline it over row ranges (the update of one range on one stream, the aggregation of the next on
+ * another): ptgnn_amd.ops.aggregate_gru does, opt-in (PTGNN_AMD_AGG_PIPELINE=<ranges>; off by default -- it measured
+ * slower than the unsplit pair on MI355X, profiles/r05_notes.md).  Launches over one plan must not overlap EACH OTHER
+ * in time (they share `hub_tickets`). */
 int ptgnn_amd_gather_reduce_rows_f32(const float *ysrc, int64_t ld_ysrc,
                                      const float *ydst /* nullable */, int64_t ld_ydst,
                                      const int32_t *rowptr, const int32_t *col,
@@ -576,6 +578,29 @@ int ptgnn_amd_gru_cell_f32(const float *a, int64_t ld_a, const float *h, int64_t
                            const float *w_ih, const float *w_hh, const float *b_ih,
                            const float *b_hh, int64_t n, int32_t m, int32_t hd, float *out,
                            int64_t ld_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weighted-sum pooling of elements into samples (nodes into graphs):
+ *   out[g, :] = sum_{i : map[i] == g} sigmoid(x[i, :] . w) * x[i, :]
+ * Replaces: WeightedSumVarSizedElementReduce.forward, ptgnn/neuralmodels/reduceops/varsizedsummary.py:68-81 --
+ *   nn.Linear(D, 1, bias=False) (a gemv), torch.sigmoid, the broadcast multiply that materialises [N, D] and
+ *   torch_scatter.scatter_sum -- as used by GruGlobalStateUpdate (globalgraphexchange.py:37-45) in the VarMisuse GGNN
+ *   stack (varmisuse/train.py:87-92).  One pass over x; no float atomics (per-segment slices folded in a fixed order).
+ *   x [num_elements, dim], w [dim], rowptr int32 [num_segments + 1] / perm int32 [num_elements]: the stable plan of the
+ *   element -> sample map (ptgnn_amd_csr_build over (map, map); perm[s] = element of plan slot s), out [num_segments, dim].
+ *   dim <= 1024.  workspace: ptgnn_amd_weighted_pool_workspace_bytes.
+ * Backward: grad_x [num_elements, dim] and grad_w [dim] (both OVERWRITTEN; grad_w deterministic) from
+ *   grad_out [num_segments, dim] and the int64 map itself.
+ * ---------------------------------------------------------------------------------------- */
+size_t ptgnn_amd_weighted_pool_workspace_bytes(int64_t num_segments, int64_t num_elements, int32_t dim);
+int ptgnn_amd_weighted_pool_f32(const float *x, int64_t ld_x, const float *w, const int32_t *rowptr,
+                                const int32_t *perm, int64_t num_segments, int64_t num_elements, int32_t dim,
+                                float *out, int64_t ld_out, void *workspace, size_t workspace_bytes, void *stream);
+size_t ptgnn_amd_weighted_pool_backward_workspace_bytes(int64_t num_elements, int32_t dim);
+int ptgnn_amd_weighted_pool_backward_f32(const float *x, int64_t ld_x, const float *w, const int64_t *map,
+                                         const float *grad_out, int64_t ld_go, int64_t num_elements, int32_t dim,
+                                         float *grad_x, int64_t ld_gx, float *grad_w, void *workspace,
+                                         size_t workspace_bytes, void *stream);
 
 /* Row gather out[i, :] = x[idx[i], :] (F.embedding at gatedmessagepassing.py:54-56,
  * mlpmessagepassing.py:88,91) for the general per-edge path (edge features / training dropout /

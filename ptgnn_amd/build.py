@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libptgnn_amd.so")
-SOURCES = ["errors.cpp", "csr_build.hip", "gather_reduce.hip", "dense_f32.hip", "stream_gemm.hip", "edge_gemm.hip", "edge_wgrad.hip", "wgrad_stream.hip", "batching.hip", "row_epilogue.hip", "shard_index.hip", "segment_mul.hip"]
+SOURCES = ["errors.cpp", "csr_build.hip", "gather_reduce.hip", "dense_f32.hip", "stream_gemm.hip", "edge_gemm.hip", "edge_wgrad.hip", "wgrad_stream.hip", "batching.hip", "row_epilogue.hip", "shard_index.hip", "segment_mul.hip", "weighted_pool.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "dense_common.h"), os.path.join(CSRC, "stream_gemm.h"), os.path.join(CSRC, "wgrad_stream.h"),
            os.path.join(INCLUDE, "ptgnn_amd.h")]
 EXPORTS = os.path.join(CSRC, "exports.map")   # only ptgnn_amd_* leaves the library

@@ -126,12 +126,14 @@ def set_output_hint(buf: Optional[torch.Tensor]) -> None:
     _SCOPE.out_hint = buf
 
 
-def _take_output_hint(rows: int, cols: int, like: torch.Tensor) -> Optional[torch.Tensor]:
+def _take_output_hint(rows: int, cols: int, like: torch.Tensor, vector_stores: bool = False) -> Optional[torch.Tensor]:
     hint = getattr(_SCOPE, "out_hint", None)
     _SCOPE.out_hint = None
     if hint is None or torch.is_grad_enabled() and like.requires_grad:
         return None
     if tuple(hint.shape) != (rows, cols) or hint.dtype != torch.float32 or hint.device != like.device:
+        return None
+    if vector_stores and (hint.data_ptr() % 16 != 0 or (rows > 1 and hint.stride(0) % 4 != 0) or hint.stride(1) != 1):
         return None
     return hint
 
@@ -607,12 +609,14 @@ class MlpMessagePassingLayer(AbstractMessagePassingLayer):
         elif (fused and ydst is None and self._dense is not None
               and (self._dense_act is None or isinstance(self._dense_act, (nn.Tanh, nn.ReLU)))
               and not (self.training and getattr(self._dropout, "p", 0.0) > 0)
-              and ops.gather_update_supported(M, self._dense.out_features, plan)
-              and _no_grad_needed(ysrc, *self._dense.parameters())):
+              and _no_grad_needed(ysrc, *self._dense.parameters())
+              and ops.gather_update_supported(M, self._dense.out_features, plan)):
             # hidden 64 (the README's default architecture, BASELINE config 4), edge form: aggregation, GELU, LayerNorm,
             # Linear and Tanh in ONE launch -- the [N, M] aggregate never exists in memory (gather_reduce.hip)
             act = "tanh" if isinstance(self._dense_act, nn.Tanh) else ("relu" if isinstance(self._dense_act, nn.ReLU) else None)
-            hint = _take_output_hint(plan.num_nodes, self._dense.out_features, ysrc)
+            # (the fused launch stores 16-byte vectors: a hint whose rows are not 16-byte aligned -- the right half of a
+            # concat buffer whose left half is not a multiple of 4 wide -- is declined, the residual then concatenates)
+            hint = _take_output_hint(plan.num_nodes, self._dense.out_features, ysrc, vector_stores=True)
             out = ops.gather_update(ysrc, plan, self.__aggregation_fn, plan.col if col is None else col,
                                     plan.type_bits if type_bits is None else type_bits, epi.get("epilogue", 0),
                                     epi.get("ln_weight"), epi.get("ln_bias"), epi.get("ln_eps", 1e-5),

@@ -146,7 +146,7 @@ class GraphPlan:
     __slots__ = ("rowptr", "col", "perm", "type_bits", "num_nodes", "num_edges", "num_types",
                  "num_src_rows", "_backward", "_adj", "_adj_refs", "_inv_perm", "_ready", "_waited",
                  "_hub_tickets", "hub_entries", "hub_count", "_slot_rows", "_ident", "_transposed", "_uniq", "_hub_posted",
-                 "__weakref__")
+                 "_has_hubs", "__weakref__")
 
     def __init__(self, rowptr, col, perm, type_bits, num_nodes, num_edges, num_types):
         self.rowptr, self.col, self.perm = rowptr, col, perm
@@ -164,6 +164,7 @@ class GraphPlan:
         self._slot_rows = self._ident = self._transposed = None
         self._uniq = None      # UniqueMessages | pending read-back | False (not worth it / not applicable)
         self._hub_posted = False   # the hub count's asynchronous read-back has been posted (ops.gather_update_supported)
+        self._has_hubs = None      # ... and has arrived: True / False (None = not known on the host)
 
     def may_have_hubs(self) -> bool:
         """Only plans with more edges than the threshold can contain a hub row (whether they do is
@@ -787,29 +788,41 @@ GATHER_UPDATE_MAX_EDGES = 1 << 21
 # device only (`plan.hub_count`); it is read back asynchronously once per plan, and a non-zero count sends the next
 # GATHER_UPDATE_BACKOFF calls to the unfused pair (both forms are exact: this is a speed decision, never a correctness one).
 GATHER_UPDATE_BACKOFF = 64
-_HUB_PENDING: List[Tuple["torch.cuda.Event", torch.Tensor]] = []
+_HUB_PENDING: List[Tuple["torch.cuda.Event", torch.Tensor, "weakref.ref"]] = []
 _HUB_SKIP = [0]
 
 
 def _poll_hub_counts() -> None:
     for item in list(_HUB_PENDING):
-        ev, host = item
+        ev, host, plan_ref = item
         if ev.query():
             _HUB_PENDING.remove(item)
-            if int(host[0]) > 0:
+            hubs = int(host[0]) > 0
+            plan = plan_ref()
+            if plan is not None:
+                plan._has_hubs = hubs        # a fact of THIS plan: decides every later call over it
+            if hubs:
                 _HUB_SKIP[0] = GATHER_UPDATE_BACKOFF
             _PINNED_FREE.setdefault(1, []).append(host)
     del _HUB_PENDING[:-16]
 
 
 def gather_update_supported(msg_dim: int, out_dim: int, plan: "GraphPlan") -> bool:
+    """Whether the fused aggregation + update launch serves this call.  Callers evaluate their cheaper conditions
+    (gradients needed, dropout) FIRST: a True here may consume one step of the back-off below."""
     if not (GATHER_UPDATE and plan.num_edges < GATHER_UPDATE_MAX_EDGES
             and bool(_lib.load().ptgnn_amd_gather_update_supported(int(msg_dim), int(out_dim)))):
         return False
+    if plan.hub_count is None:              # too few edges for a hub row to exist
+        return True
+    if plan._has_hubs is not None:          # the plan's own count has come back (a cached plan of full-graph inference)
+        return not plan._has_hubs
     if torch.cuda.is_current_stream_capturing():
         return _HUB_SKIP[0] == 0
     _poll_hub_counts()
-    if plan.hub_count is not None and not plan._hub_posted:
+    if plan._has_hubs is not None:
+        return not plan._has_hubs
+    if not plan._hub_posted:
         plan._hub_posted = True
         plan.wait()
         dev = plan.hub_count.device
@@ -818,7 +831,8 @@ def gather_update_supported(msg_dim: int, out_dim: int, plan: "GraphPlan") -> bo
             host.copy_(plan.hub_count.to(torch.int64), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
-        _HUB_PENDING.append((ev, host))
+        _HUB_PENDING.append((ev, host, weakref.ref(plan)))
+    # this plan's count is still in flight: go by what the recent plans reported
     if _HUB_SKIP[0] > 0:
         _HUB_SKIP[0] -= 1
         return False
@@ -1406,3 +1420,53 @@ def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
                                        x.shape[1], out.data_ptr(), x.shape[1], _stream(out))
     _lib.check(rc, "ptgnn_amd_gather_rows_f32")
     return out
+
+
+def weighted_pool(x: torch.Tensor, w: torch.Tensor, plan: GraphPlan) -> torch.Tensor:
+    """out[g] = sum_{i in segment g} sigmoid(x_i . w) x_i over the plan of an element -> sample map
+    (ptgnn_amd_weighted_pool_f32: WeightedSumVarSizedElementReduce, varsizedsummary.py:68-81, in one pass over x)."""
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    x = _rowmajor(x)
+    n, d = x.shape
+    if n != plan.num_edges or w.numel() != d or plan.perm is None:
+        raise _lib.PtgnnAmdError(f"weighted_pool: x {tuple(x.shape)}, w {tuple(w.shape)} do not fit a plan over "
+                                 f"{plan.num_edges} elements")
+    w = w.detach().reshape(-1).contiguous()
+    G = plan.num_nodes
+    out = torch.empty(G, d, dtype=torch.float32, device=x.device)
+    ws_bytes = int(lib.ptgnn_amd_weighted_pool_workspace_bytes(G, n, d))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+    plan.wait()
+    with _timed("weighted_pool", bytes=4.0 * (n * d + G * d + d) + 4.0 * n):
+        rc = lib.ptgnn_amd_weighted_pool_f32(x.data_ptr() if n else None, _ld(x) if n else d, w.data_ptr(),
+                                             plan.rowptr.data_ptr(), plan.perm.data_ptr(), G, n, d, out.data_ptr(), d,
+                                             ws.data_ptr(), ws_bytes, _stream(out))
+    _lib.check(rc, "ptgnn_amd_weighted_pool_f32")
+    return out
+
+
+def weighted_pool_backward(x: torch.Tensor, w: torch.Tensor, index: torch.Tensor, grad_out: torch.Tensor):
+    """(grad_x [n, d], grad_w [d]) of `weighted_pool` from grad_out [G, d] and the int64 element -> sample map."""
+    lib = _lib.load()
+    _require_cuda_f32("x", x)
+    _require_cuda_f32("grad_out", grad_out)
+    x, grad_out = _rowmajor(x), _rowmajor(grad_out)
+    n, d = x.shape
+    if index.dtype != torch.int64 or not index.is_cuda or index.shape[0] != n:
+        raise _lib.PtgnnAmdError("weighted_pool_backward: the map must be a CUDA int64 tensor with one entry per element")
+    index = index.contiguous()
+    w = w.detach().reshape(-1).contiguous()
+    gx = torch.empty(n, d, dtype=torch.float32, device=x.device)
+    gw = torch.empty(d, dtype=torch.float32, device=x.device)
+    ws_bytes = int(lib.ptgnn_amd_weighted_pool_backward_workspace_bytes(n, d))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+    with _timed("weighted_pool_backward", bytes=4.0 * (3 * n * d) + 8.0 * n):
+        rc = lib.ptgnn_amd_weighted_pool_backward_f32(x.data_ptr() if n else None, _ld(x) if n else d, w.data_ptr(),
+                                                      index.data_ptr() if n else None,
+                                                      grad_out.data_ptr() if grad_out.numel() else None,
+                                                      _ld(grad_out) if grad_out.numel() else d, n, d,
+                                                      gx.data_ptr() if n else None, d, gw.data_ptr(), ws.data_ptr(),
+                                                      ws_bytes, _stream(gx))
+    _lib.check(rc, "ptgnn_amd_weighted_pool_backward_f32")
+    return gx, gw

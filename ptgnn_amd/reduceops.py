@@ -77,15 +77,46 @@ class SimpleVarSizedElementReduce(AbstractVarSizedElementReduce):
                      self.__summarization_type)
 
 
+class _WeightedPool(torch.autograd.Function):
+    """sum_{i in sample} sigmoid(x_i . w) x_i as ONE node: forward and backward are the two HIP entry points of
+    csrc/weighted_pool.hip (no gemv, no [N, D] product in memory, deterministic weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w, index, plan):
+        ctx.save_for_backward(x, w, index)
+        return ops.weighted_pool(x, w, plan)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w, index = ctx.saved_tensors
+        gx, gw = ops.weighted_pool_backward(x, w, index, grad_out.contiguous())
+        return gx, gw.reshape(w.shape), None, None
+
+
 class WeightedSumVarSizedElementReduce(AbstractVarSizedElementReduce):
     def __init__(self, representation_size: int):
         super().__init__()
         self.__weights_layer = nn.Linear(representation_size, 1, bias=False)
 
+    @property
+    def score_weight(self) -> torch.Tensor:
+        """[1, D] weight of the scoring Linear (varsizedsummary.py:71)."""
+        return self.__weights_layer.weight
+
     def forward(self, inputs: ElementsToSummaryRepresentationInput) -> torch.Tensor:
-        x = inputs.element_embeddings
-        weights = torch.sigmoid(self.__weights_layer(x).squeeze(-1))          # [num_elements]
-        return _pool(x * weights.unsqueeze(-1), inputs.element_to_sample_map, inputs.num_samples, "sum")
+        x, index = inputs.element_embeddings, inputs.element_to_sample_map
+        w = self.__weights_layer.weight
+        if not x.is_cuda:      # device dispatch: the reference's own operator sequence (varsizedsummary.py:73-81)
+            weights = torch.sigmoid(self.__weights_layer(x).squeeze(-1))          # [num_elements]
+            return _pool(x * weights.unsqueeze(-1), index, inputs.num_samples, "sum")
+        # GPU: score, scaling and segment sum in one HIP pass (csrc/weighted_pool.hip); fp16 / bf16 states (AMP) are
+        # pooled in fp32 and cast back, like every aggregation of the package
+        plan = _index_plan(index, int(inputs.num_samples))
+        dt = x.dtype
+        xf, wf = x.to(torch.float32), w.to(torch.float32)
+        if _no_grad_needed(xf, wf):
+            return ops.weighted_pool(xf, wf, plan).to(dt)
+        return _WeightedPool.apply(xf, wf, index, plan).to(dt)
 
 
 class AbstractGlobalGraphExchange(AbstractMessagePassingLayer):
@@ -99,6 +130,10 @@ class AbstractGlobalGraphExchange(AbstractMessagePassingLayer):
 
     def _update_node_states(self, node_states, global_info_per_node):
         raise NotImplementedError
+
+    @property
+    def pooling_module(self) -> AbstractVarSizedElementReduce:
+        return self.__global_graph_representation_module
 
     def forward(self, node_states, adjacency_lists, node_to_graph_idx, reference_node_ids,
                 reference_node_graph_idx, edge_features) -> torch.Tensor:
@@ -186,3 +221,14 @@ class GruGlobalStateUpdate(AbstractGlobalGraphExchange):
     @property
     def output_state_dimension(self) -> int:
         return self.__input_dim
+
+    def export_weights(self) -> dict:
+        """Weights in the layout the parity oracle consumes (tests only read this)."""
+        gru, pool = self.__gru_cell, self.pooling_module
+        spec = {"kind": "global_gru", "w_ih": gru.weight_ih.detach().cpu(), "w_hh": gru.weight_hh.detach().cpu(),
+                "b_ih": gru.bias_ih.detach().cpu(), "b_hh": gru.bias_hh.detach().cpu()}
+        if isinstance(pool, WeightedSumVarSizedElementReduce):
+            spec.update(pool="weighted_sum", pool_w=pool.score_weight.detach().cpu())
+        else:
+            spec["pool"] = pool.summarization_type
+        return spec

@@ -106,6 +106,30 @@ def _prepare(src: torch.Tensor, index: torch.Tensor, dim: int, out, dim_size):
     return src, squeeze, plan
 
 
+def _any_rank(fn):
+    """GPU tensors of any rank with a 1-D index along `dim` (grucopydecoder.py:108 scatter_adds a [I, L, H] tensor along
+    dim 0): the reduced dimension is moved to the front, the others flattened into the columns of the [E, D] form the HIP
+    kernels take, and the result is given its layout back -- views and reshapes only.  (An index that is itself
+    N-D / broadcast is served for CPU tensors only: torch_route._flatten.)"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(src, index, dim=-1, *args, **kwargs):
+        if src.is_cuda and index.dim() == 1 and src.dim() >= 2:
+            d = dim % src.dim()
+            if src.dim() > 2 or d != 0:
+                moved = src.movedim(d, 0)
+                rest = tuple(moved.shape[1:])
+                res = fn(moved.reshape(moved.shape[0], -1), index, 0, *args, **kwargs)
+
+                def back(t):
+                    return t.reshape(t.shape[0], *rest).movedim(0, d)
+                return tuple(back(t) for t in res) if isinstance(res, tuple) else back(res)
+        return fn(src, index, dim, *args, **kwargs)
+    return wrapped
+
+
+@_any_rank
 def scatter(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional[torch.Tensor] = None,
             dim_size: Optional[int] = None, reduce: str = "sum") -> torch.Tensor:
     """torch_scatter.scatter for the layout the ptgnn hot path uses (abstractmessagepassing.py:44-50,
@@ -135,6 +159,7 @@ def scatter_mean(src, index, dim: int = -1, out=None, dim_size: Optional[int] = 
     return scatter(src, index, dim, out, dim_size, "mean")
 
 
+@_any_rank
 def _scatter_minmax(src, index, dim, out, dim_size, reduce):
     if not src.is_cuda:
         return torch_route.scatter(src, index, dim, out, dim_size, reduce, return_arg=True)
@@ -183,6 +208,7 @@ def gather_rows(x: torch.Tensor, index: torch.Tensor, plan: "ops.GraphPlan") -> 
     return _GatherRows.apply(x, index, plan)
 
 
+@_any_rank
 def scatter_log_softmax(src, index, dim: int = -1, eps: float = 1e-12,
                         dim_size: Optional[int] = None) -> torch.Tensor:
     """torch_scatter.composite.scatter_log_softmax (varsizedsummary.py:57,106,158; varmisuse.py:79;
@@ -201,6 +227,7 @@ def scatter_log_softmax(src, index, dim: int = -1, eps: float = 1e-12,
     return res.squeeze(1) if squeeze else res
 
 
+@_any_rank
 def scatter_softmax(src, index, dim: int = -1, eps: float = 1e-12,
                     dim_size: Optional[int] = None) -> torch.Tensor:
     """torch_scatter.composite.scatter_softmax:  exp(src - max_seg) / (sum_seg exp(src - max_seg) + eps)."""
@@ -218,6 +245,7 @@ def scatter_softmax(src, index, dim: int = -1, eps: float = 1e-12,
     return res.squeeze(1) if squeeze else res
 
 
+@_any_rank
 def scatter_logsumexp(src, index, dim: int = -1, out=None, dim_size: Optional[int] = None,
                       eps: float = 1e-12) -> torch.Tensor:
     """torch_scatter.composite.scatter_logsumexp (grucopydecoder.py:122,190): log(sum_seg exp(src - max_seg) + eps)
@@ -241,6 +269,7 @@ def scatter_logsumexp(src, index, dim: int = -1, out=None, dim_size: Optional[in
     return res.squeeze(1) if squeeze else res
 
 
+@_any_rank
 def scatter_std(src, index, dim: int = -1, out=None, dim_size: Optional[int] = None,
                 unbiased: bool = True) -> torch.Tensor:
     """torch_scatter.scatter_std: sqrt(sum_seg (x - mean_seg)^2 / (max(count - 1, 1) + 1e-6)) (count, not count - 1,
@@ -301,6 +330,10 @@ def install(force: bool = False):
     top.composite = comp
     top.__version__ = FACADE_VERSION
     top.__path__ = []            # a package: `import torch_scatter.composite` resolves through sys.modules
+    # real specs: importlib.util.find_spec("torch_scatter") raises ValueError on a module whose __spec__ is None
+    from importlib.machinery import ModuleSpec
+    top.__spec__ = ModuleSpec("torch_scatter", None, is_package=True)
+    comp.__spec__ = ModuleSpec("torch_scatter.composite", None)
     sys.modules["torch_scatter"] = top
     sys.modules["torch_scatter.composite"] = comp
     return top

@@ -58,7 +58,10 @@ def _winner_positions(rows: torch.Tensor, index: torch.Tensor, best: torch.Tenso
     `E` for a segment without elements."""
     E, D = rows.shape
     pos = torch.arange(E, dtype=torch.int64).unsqueeze(1).expand(E, D)
-    attained = rows == best.index_select(0, index)
+    b = best.index_select(0, index)
+    attained = rows == b
+    if rows.is_floating_point():     # a NaN in a segment IS its extremum (torch_scatter and the reference propagate it)
+        attained = attained | (rows.isnan() & b.isnan())
     cand = torch.where(attained, pos, torch.full_like(pos, E))
     arg = torch.full((n, D), E, dtype=torch.int64)
     return arg.scatter_reduce_(0, index.unsqueeze(1).expand(E, D), cand, reduce="amin", include_self=True)

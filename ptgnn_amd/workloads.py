@@ -61,6 +61,29 @@ def batched_graphs(num_graphs: int, nodes_per_graph: int, num_raw_types: int,
     }
 
 
+def graph_list(num_graphs: int, nodes_lo: int, nodes_hi: int, num_raw_types: int, raw_edges_per_node: float,
+               refs_per_graph: int = 0, seed: int = 1234) -> List[Dict]:
+    """Config 1 "as the reference batches it" (SURVEY.md 8d): SEPARATE tensorized graphs -- the per-graph records
+    `GraphNeuralNetworkModel.tensorize` hands to `extend_minibatch_with` (graphneuralnetwork.py:325-367,386-438): int32
+    `(src, dst)` pairs per raw edge type with graph-local node ids, `num_nodes`, `reference_nodes` -- so that the batcher
+    (ptgnn_amd.batching.MinibatchBuilder here, oracle.mp_oracle.batch_graphs on the checker side) forms the
+    minibatches under its own node cap.  Node counts ~U[nodes_lo, nodes_hi], raw edges = raw_edges_per_node * n with
+    uniform endpoints, split over the raw types by the Zipf law of `batched_graphs`."""
+    rng = np.random.RandomState(seed)
+    zipf = 1.0 / np.arange(1, num_raw_types + 1)
+    zipf /= zipf.sum()
+    graphs = []
+    for _ in range(num_graphs):
+        n = int(rng.randint(nodes_lo, nodes_hi + 1))
+        counts = rng.multinomial(int(raw_edges_per_node * n), zipf)
+        adj = [(rng.randint(0, n, size=c).astype(np.int32), rng.randint(0, n, size=c).astype(np.int32)) for c in counts]
+        refs = {}
+        if refs_per_graph:
+            refs["supernodes"] = rng.choice(n, size=min(refs_per_graph, n), replace=False).astype(np.int32)
+        graphs.append({"num_nodes": n, "adjacency_lists": adj, "reference_nodes": refs})
+    return graphs
+
+
 def power_law_graph(num_nodes: int, num_edges: int, alpha: float = 0.8, seed: int = 1234,
                     chunk: int = 10_000_000) -> Adj:
     """Config 5: dst ~ power law (w_i = (i+1)^-alpha through a fixed random node permutation),

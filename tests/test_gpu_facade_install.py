@@ -78,3 +78,36 @@ def test_logsumexp_and_std_on_the_gpu_match_the_host_route_and_float64(shape):
     xh.grad = None
     (S.scatter_std(xh, idx, dim=0, dim_size=n) * w.cpu().double()).sum().backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), xh.grad.numpy(), rtol=0, atol=5e-5)
+
+
+def test_any_rank_src_on_the_gpu_equals_the_host_route():
+    """grucopydecoder.py:100-122 calls scatter_log_softmax / scatter_add / scatter_logsumexp with dim=0 on [I, L] and
+    [I, L, H] tensors: the GPU entry points flatten the trailing dimensions into the kernels' [E, D] form and restore the
+    layout (only the CPU route did), any `dim`, values and arg positions equal to the host route's."""
+    from ptgnn_amd import scatter as S
+    g = torch.Generator().manual_seed(11)
+    I, L, H, n = 700, 5, 8, 90
+    src = torch.randn(I, L, H, generator=g)
+    idx = torch.randint(0, n, (I,), generator=g)
+    got = S.scatter_add(src.cuda(), index=idx.cuda(), dim=0)
+    want = S.scatter_add(src, index=idx, dim=0)
+    assert tuple(got.shape) == tuple(want.shape) == (int(idx.max()) + 1, L, H)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5)
+    v, a = S.scatter_max(src.cuda(), idx.cuda(), dim=0, dim_size=n)
+    vh, ah = S.scatter_max(src, idx, dim=0, dim_size=n)
+    assert torch.equal(v.cpu(), vh) and torch.equal(a.cpu(), ah)
+    ls = S.scatter_log_softmax(src[:, :, 0].cuda(), index=idx.cuda(), dim=0, eps=0)
+    np.testing.assert_allclose(ls.cpu().numpy(), S.scatter_log_softmax(src[:, :, 0], index=idx, dim=0, eps=0).numpy(),
+                               rtol=0, atol=1e-5)
+    # the reduced dimension in the middle: index along dim 1 of [L, I, H]
+    mid = src.permute(1, 0, 2).contiguous()
+    got = S.scatter(mid.cuda(), idx.cuda(), dim=1, dim_size=n, reduce="mean")
+    want = S.scatter(mid, idx, dim=1, dim_size=n, reduce="mean")
+    assert tuple(got.shape) == (L, n, H)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5)
+    # gradients flow through the reshapes
+    x = src.cuda().requires_grad_(True)
+    S.scatter_logsumexp(x, idx.cuda(), dim=0, dim_size=n).clamp(min=-50).sum().backward()
+    xh = src.double().requires_grad_(True)
+    S.scatter_logsumexp(xh, idx, dim=0, dim_size=n).clamp(min=-50).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xh.grad.numpy(), rtol=0, atol=2e-5)

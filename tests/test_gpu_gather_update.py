@@ -174,7 +174,15 @@ def test_a_plan_with_hub_rows_sends_the_following_calls_to_the_unfused_pair(monk
     hubby = ops.build_plan(to_cuda_adj([(src, dst2)]), N)
     assert ops.gather_update_supported(64, 64, hubby)        # the count is not back yet: still fused (exact either way)
     torch.cuda.synchronize()
-    assert not ops.gather_update_supported(64, 64, plain)    # the read-back has arrived: back off
+    fresh = ops.build_plan(to_cuda_adj([(src, dst)]), N)     # a plan whose own count is still unknown ...
+    assert not ops.gather_update_supported(64, 64, fresh)    # ... goes by the recent plans: the read-back has arrived, back off
     assert ops._HUB_SKIP[0] == ops.GATHER_UPDATE_BACKOFF - 1
+    # what a plan reported about ITSELF decides its later calls, whatever the back-off says: the hub-free plan
+    # stays fused, the hub plan never takes the serial fold again -- also after the back-off has run out
+    assert plain._has_hubs is False and hubby._has_hubs is True
+    assert ops.gather_update_supported(64, 64, plain) and ops._HUB_SKIP[0] == ops.GATHER_UPDATE_BACKOFF - 1
+    monkeypatch.setattr(ops, "_HUB_SKIP", [0])
+    assert not ops.gather_update_supported(64, 64, hubby) and ops.gather_update_supported(64, 64, plain)
     monkeypatch.setattr(ops, "_HUB_SKIP", [1])
-    assert not ops.gather_update_supported(64, 64, plain) and ops.gather_update_supported(64, 64, plain)
+    other = ops.build_plan(to_cuda_adj([(src, dst)]), N)
+    assert not ops.gather_update_supported(64, 64, other) and ops.gather_update_supported(64, 64, other)

@@ -81,17 +81,18 @@ def test_bench_watchdog_emits_the_primary_line_when_a_rank_stalls():
 
 
 def test_bench_two_ranks_runs_the_sharded_variants_end_to_end():
-    """`bench.py --gpus 2` as the driver launches it, except over gloo with both ranks on cuda:0 (RCCL refuses two ranks
-    per device): the primary weak-scaling line plus BOTH dst-range-sharded workloads with real cut edges -- the cfg5
-    shard (HIP index pass, halo all-to-all, two-block mode) and the cfg4 stack in its graph-boundary and its
-    through-graphs partition -- must complete and explain themselves in the one JSON line."""
+    """`python bench.py --gpus 2` started PLAINLY -- no launcher, no WORLD_SIZE: bench.py starts its own ranks under
+    torch.distributed.run on 127.0.0.1 (round 6; the reference's multi-GPU entry spawns its ranks from one process too,
+    distributedtrainer.py:250-265), here over gloo with both ranks on cuda:0 (RCCL refuses two ranks per device): the
+    primary weak-scaling line plus BOTH dst-range-sharded workloads with real cut edges -- the cfg5 shard (HIP index pass,
+    halo all-to-all, two-block mode) and the cfg4 stack in its graph-boundary and its through-graphs partition -- must
+    complete and explain themselves in the one JSON line.  (The launcher form is covered by the watchdog test above.)"""
     import json
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-           "--no-secondary"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-secondary"]
+    assert "WORLD_SIZE" not in os.environ and "RANK" not in os.environ
     env = dict(os.environ, OMP_NUM_THREADS="4", PTGNN_AMD_BENCH_BACKEND="gloo", PTGNN_AMD_BENCH_SHARE_GPU="1")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + "\n" + r.stderr)[-4000:]
@@ -116,3 +117,7 @@ def test_bench_two_ranks_runs_the_sharded_variants_end_to_end():
     assert lift["cfg5_shard"]["ms_per_step"] == c5["ms_per_step"] and lift["cfg5_shard"]["all_to_all_ms"] > 0
     assert lift["cfg4_stack_through_graphs"]["ms_per_forward"] == tg["ms_per_forward"]
     assert lift["cfg4_stack_graph_boundaries"]["ms_per_forward"] > 0 and lift["collective_backend"] == "gloo"
+    # round 6: the north-star split's own edges/s is a first-class key with its one-GPU counterpart beside it
+    top = res["sharded_cfg5"]
+    assert top["n_gpus"] == 2 and top["edges_per_sec_per_layer"] == c5["edges_per_sec_per_layer"]
+    assert top["one_gpu_edges_per_sec_per_layer"] > 0 and 0 < top["vs_n_times_one_gpu"] < 2 and top["cut_fraction"] == 0.5

@@ -169,3 +169,25 @@ def test_host_route_edge_cases_empty_inputs_features_and_empty_edge_types():
     with torch.no_grad():
         assert tuple(g(torch.randn(4, 8), adj, None, {}, {}, feats).shape) == (4, 8)
         assert tuple(m(torch.randn(4, 8), adj, None, {}, {}, feats).shape) == (4, 6)
+
+
+def test_nan_is_the_extremum_of_its_segment_and_the_installed_module_has_a_spec():
+    """a NaN in a segment propagates through max / min like torch_scatter's comparison loop (it used to match
+    nothing and silently pool to 0), and `importlib.util.find_spec("torch_scatter")` works after `install()`."""
+    from ptgnn_amd import scatter as S
+    src = torch.tensor([[1.0, 2.0], [float("nan"), 0.5], [3.0, -1.0], [4.0, 4.0]])
+    idx = torch.tensor([0, 0, 0, 2])
+    v, a = S.scatter_max(src, idx, dim=0, dim_size=3)
+    assert bool(torch.isnan(v[0, 0])) and int(a[0, 0]) == 1              # the NaN element is the recorded winner
+    assert v[0, 1].item() == 2.0 and int(a[0, 1]) == 0
+    assert v[1].tolist() == [0.0, 0.0] and a[1].tolist() == [4, 4]        # empty segment: 0, arg = src.size(dim)
+    assert v[2].tolist() == [4.0, 4.0]
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import importlib.util, ptgnn_amd.scatter as S\n"
+            "S.install(force=True)\n"
+            "spec = importlib.util.find_spec('torch_scatter')\n"
+            "assert spec is not None and spec.name == 'torch_scatter'\n"
+            "assert importlib.util.find_spec('torch_scatter.composite').name == 'torch_scatter.composite'\n"
+            "print('SPEC_OK')\n" % ROOT)
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0 and "SPEC_OK" in proc.stdout, proc.stdout + proc.stderr
