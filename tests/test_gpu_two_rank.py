@@ -92,8 +92,8 @@ def test_bench_two_ranks_runs_the_sharded_variants_end_to_end():
         pytest.skip("needs a GPU")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", "--no-secondary"]
-    assert "WORLD_SIZE" not in os.environ and "RANK" not in os.environ
-    env = dict(os.environ, OMP_NUM_THREADS="4", PTGNN_AMD_BENCH_BACKEND="gloo", PTGNN_AMD_BENCH_SHARE_GPU="1")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="4", PTGNN_AMD_BENCH_BACKEND="gloo", PTGNN_AMD_BENCH_SHARE_GPU="1")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + "\n" + r.stderr)[-4000:]
     assert r.returncode == 0, tail

@@ -38,7 +38,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_version_and_pure_host_entry_points(lib):
-    assert lib.ptgnn_amd_version() == 101 >= __import__('ptgnn_amd')._lib.MIN_VERSION
+    assert lib.ptgnn_amd_version() == 102 >= __import__('ptgnn_amd')._lib.MIN_VERSION
     assert [lib.ptgnn_amd_type_bits(t) for t in (1, 2, 3, 4, 5, 17, 32, 33)] == [0, 1, 2, 2, 3, 5, 5, 6]
     assert lib.ptgnn_amd_last_error() is not None
 
@@ -354,3 +354,40 @@ def test_plan_build_refuses_sizes_beyond_the_int32_plan_format(lib):
     assert build([10] * 32, 1 << 26) == -2                             # rows * 2^type_bits = 2^26 * 2^5 = 2^31
     assert build([10], 1 << 31) == -2                                  # rows = 2^31
     assert build([10] * 17, 1000, num_src_rows=1 << 27) == -2          # halo table: source rows * 2^5 >= 2^31
+
+
+def test_parity_rollup_names_the_configs_on_the_relaxed_bar():
+    """the top-level `parity` of the bench line says which configs pass on the float64-attributed bar
+    only (`configs_on_relaxed_bar`), ANDs `strict_1e-5` over every config checked and lists failures."""
+    from benchmarks.common import attributed_parity, parity_rollup
+    strict = {"max_abs": 1.2e-6, "tol": 1e-5, "strict_1e-5": True}
+    got = torch.tensor([[1.0, 2.0]])
+    relaxed = attributed_parity(got + 5e-5, got, (got + 4e-5).double())       # ours 1e-5 from exact, the oracle 4e-5
+    assert relaxed["ok"] and not relaxed["strict_1e-5"]
+    failed = attributed_parity(got + 5e-4, got, got.double())
+    assert not failed["ok"]
+    roll = parity_rollup(strict, {"config2": {"max_abs": 2e-6, "tol": 1e-5}, "config4": relaxed,
+                                  "config5_shard": {"ok": True, "ggnn": {"strict_1e-5": False, "ok": True},
+                                                    "mlp_mp": {"strict_1e-5": True, "ok": True}},
+                                  "config1": {"ggnn64": strict, "ppi_arch_mlp256": strict}})
+    assert roll["max_abs"] == 1.2e-6 and roll["strict_1e-5"] is False and roll["configs_failed"] == []
+    assert roll["configs_on_relaxed_bar"] == ["config4", "config5_shard.ggnn"]
+    assert set(roll["configs_checked"]) == {"primary", "config2", "config4", "config5_shard.ggnn", "config5_shard.mlp_mp",
+                                            "config1.ggnn64", "config1.ppi_arch_mlp256"}
+    assert parity_rollup(strict, {"config2": strict})["strict_1e-5"] is True
+    assert parity_rollup(strict, {"config4": failed})["configs_failed"] == ["config4"]
+
+
+def test_bench_self_launch_refuses_more_ranks_than_gpus_with_a_clear_message():
+    """`python bench.py --gpus N` without WORLD_SIZE starts its own ranks (round 6); on a node with fewer GPUs it says so
+    instead of dying inside a rendezvous.  (The launch itself is exercised on the GPU box: tests/test_gpu_two_rank.py.)"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PTGNN_AMD_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 64: this node shows" in (r.stderr + r.stdout), r.stderr[-2000:]
+    # under a launcher with a mismatching world size the message names both ways of starting it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and ("WORLD_SIZE=3" in r.stderr or "needs an MI355X" in r.stderr), r.stderr[-2000:]
