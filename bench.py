@@ -222,14 +222,20 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 result[key] = {"error": f"{type(exc).__name__}: {exc}"}
                 break              # ranks may have diverged: do not enter another collective section
-    if (world > 1 and not args.no_sharded_variants) or args.sharded_variants or (world == 1 and sharded_leg
-                                                                                and args.workload == "cfg3"):
+    def sharded_variants():
         from benchmarks import dst_range
         try:
             C.late_group(dev)
             dst_range.run_variants(result, rank, world, dev)
         except Exception as exc:  # noqa: BLE001  (world = 1 only: at N > 1 run_variants handles its own failures)
             result["sharded_cfg5"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1:
+            # the collective backend's helper threads (RCCL watchdog / heartbeat) compete with this process's launch
+            # loop for the host: a launch-bound secondary measured 7 % slower with the group alive (round 6)
+            C.drop_group()
+
+    if (world > 1 and not args.no_sharded_variants) or (world > 1 and args.sharded_variants):
+        sharded_variants()
     if rank == 0 and world == 1 and not (args.force_sharded and args.workload == "cfg2"):
         result["repeats"] = C.repeat_stats(step, args.steps)
         if args.workload == "cfg3" and not args.no_sustained:
@@ -276,6 +282,10 @@ def main():
             _log("secondary: README default architecture")
             result["readme_default_arch"] = G2C.train_cfg3(dev, 0.1, arch="mlp", H=64, forward_too=True)
             torch.cuda.empty_cache()
+        if sharded_leg and args.workload == "cfg3":
+            # N = 1: the cfg5 shard through the dst-range code path (world-1 process group over RCCL, nothing cut), after
+            # every launch-bound measurement of the run
+            sharded_variants()
         if not args.no_cpu_baseline:
             _log("cpu baseline (thread sweep) + full-size parity")
             first = (lambda: G2C.step_cfg3(st)) if rotation is not None else step     # parity: the FIRST minibatch of the rotation

@@ -77,6 +77,14 @@ def dist_setup(args):
     return rank, world, torch.device("cuda", local if world > 1 else 0)
 
 
+def drop_group() -> None:
+    if _GROUP["up"]:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+        _GROUP["up"] = False
+
+
 def late_group(dev) -> None:
     """World-1 process group for the sharded leg of a plain N = 1 run, created right before that leg (inside its
     try/except): a collective backend that fails to come up then costs that leg, never the primary line."""

@@ -4,20 +4,19 @@
 //     score_i = sigmoid(x_i . w)                    nn.Linear(D, 1, bias=False) + torch.sigmoid
 //     out[g]  = sum_{i : map[i] == g} score_i x_i   scatter_sum over element_to_sample_map
 //
-// The reference runs a [N, D] x [D, 1] gemv, a sigmoid, a broadcast multiply that materialises [N, D], and the
-// scatter.  Here the score, the scaling and the segment sum are ONE pass over x: N * D * 4 bytes read, G * D * 4 written
-// -- HBM-bound integer-free streaming work (cfg4: 80 k x 64 = 20 MB).
-//
-// Segments are graphs: few (tens) and long (thousands of rows), so one workgroup per segment would leave the chip
-// empty.  Every segment is cut into `slices` equal position ranges (host-chosen from N / G); workgroup (g, s) folds its
-// range and writes a partial row, a second tiny launch adds the partials of a segment IN SLICE ORDER.  No float atomics:
-// the result is a fixed function of (x, w, map, slices), run to run.  The fold order differs from torch_scatter's
-// serial one (like the hub rows of gather_reduce.hip); the tests hold the pool to a relative 2e-5.
+// Forward = k_score_scale (this file: the gemv, the sigmoid and the broadcast multiply of the reference in ONE streaming
+// pass, y_i = score_i x_i rounded like the reference's product) followed by the package's ordinary segment sum over the
+// map's plan (gather_reduce.hip) -- the SAME in-order fold every aggregation uses, so the pool of a graph of <= 2048 nodes
+// adds its rows in the order the reference's CPU scatter_add_ does, and a sharded run (whole graphs per rank) reproduces
+// the unsharded pool bit for bit.  (Round 6 first folded score, scaling and sum into one kernel over position slices of
+// each segment: 1.3x less traffic on a 20 MB table that sits in the Infinity Cache anyway, but a fold order of its own --
+// 3e-5 from the oracle on 2 000-node graphs, where this form is within 3e-6.)
 //
 // Backward (training): with go = d out,
 //     d x_i = score_i go[g_i] + (go[g_i] . x_i) score_i (1 - score_i) w
 //     d w   = sum_i (go[g_i] . x_i) score_i (1 - score_i) x_i
-// one streaming pass for d x plus per-workgroup partial rows of d w that a second launch adds in a fixed order.
+// one streaming pass for d x plus per-workgroup partial rows of d w that a second launch adds in a fixed order (no float
+// atomics: d w is a fixed function of its inputs).
 #include "common.h"
 
 namespace ptgnn_amd {
@@ -37,30 +36,23 @@ __device__ __forceinline__ float group_sum(float v, int lanes) {
 constexpr int kPoolThreads = 256;
 // COLS = chunks (float4 or float) of one row a lane holds: 1 for dim <= lanes * VEC (hidden 64 ... 256), up to 16
 
-// x rows are read through `perm` (plan order -> element id): a sorted map (node_to_graph_idx) makes it the identity.
+// y[i, :] = sigmoid(x[i, :] . w) * x[i, :]  -- one row per group of `lanes` lanes, rows independent (any order)
 template <int VEC, int COLS>
-__global__ __launch_bounds__(kPoolThreads) void k_weighted_pool_partial(
-    const float *__restrict__ x, int64_t ld_x, const float *__restrict__ w, const int32_t *__restrict__ rowptr,
-    const int32_t *__restrict__ perm, int dim, int lanes, int slices, float *__restrict__ partial) {
-  extern __shared__ float lds[];                       // [groups, dim] partial rows of the workgroup
-  const int seg = blockIdx.x / slices, sl = blockIdx.x % slices;
-  const int beg = rowptr[seg], end = rowptr[seg + 1];
-  const int len = end - beg;
-  const int lo = beg + (int)((int64_t)len * sl / slices), hi = beg + (int)((int64_t)len * (sl + 1) / slices);
+__global__ __launch_bounds__(kPoolThreads) void k_score_scale(const float *__restrict__ x, int64_t ld_x,
+                                                              const float *__restrict__ w, int64_t n, int dim, int lanes,
+                                                              float *__restrict__ y, int64_t ld_y) {
   const int groups = kPoolThreads / lanes;
-  const int grp = threadIdx.x / lanes, g = threadIdx.x % lanes;
-  float wv[COLS][VEC], acc[COLS][VEC];
+  const int g = threadIdx.x % lanes;
+  float wv[COLS][VEC];
 #pragma unroll
   for (int c = 0; c < COLS; ++c) {
     const int col = (c * lanes + g) * VEC;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      wv[c][v] = col + v < dim ? w[col + v] : 0.0f;
-      acc[c][v] = 0.0f;
-    }
+    for (int v = 0; v < VEC; ++v) wv[c][v] = col + v < dim ? w[col + v] : 0.0f;
   }
-  for (int p = lo + grp; p < hi; p += groups) {        // the loop bound is uniform per row group: shuffles stay in step
-    const float *row = x + (int64_t)perm[p] * ld_x;
+  // every lane of a row group runs the same trip count: the shuffles of group_sum stay inside active lanes
+  for (int64_t i = (int64_t)blockIdx.x * groups + threadIdx.x / lanes; i < n; i += (int64_t)gridDim.x * groups) {
+    const float *row = x + i * ld_x;
     float xv[COLS][VEC];
     float dot = 0.0f;
 #pragma unroll
@@ -82,23 +74,15 @@ __global__ __launch_bounds__(kPoolThreads) void k_weighted_pool_partial(
     }
     const float s = pool_sigmoid(group_sum(dot, lanes));
 #pragma unroll
-    for (int c = 0; c < COLS; ++c)
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[c][v] = fmaf(s, xv[c][v], acc[c][v]);
-  }
-#pragma unroll
-  for (int c = 0; c < COLS; ++c) {
-    const int col = (c * lanes + g) * VEC;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v)
-      if (col + v < dim) lds[grp * dim + col + v] = acc[c][v];
-  }
-  __syncthreads();
-  float *dst = partial + (int64_t)blockIdx.x * dim;    // [segments, slices, dim]
-  for (int col = threadIdx.x; col < dim; col += kPoolThreads) {
-    float t = 0.0f;
-    for (int r = 0; r < groups; ++r) t += lds[r * dim + col];   // fixed order
-    dst[col] = t;
+    for (int c = 0; c < COLS; ++c) {
+      const int col = (c * lanes + g) * VEC;
+      if (col < dim) {
+        if constexpr (VEC == 4)
+          *reinterpret_cast<float4 *>(y + i * ld_y + col) = make_float4(s * xv[c][0], s * xv[c][1], s * xv[c][2], s * xv[c][3]);
+        else
+          y[i * ld_y + col] = s * xv[c][0];
+      }
+    }
   }
 }
 
@@ -230,47 +214,24 @@ PoolShape pool_shape(int dim, bool aligned) {
     }                                                                                                       \
   } while (0)
 
-int pool_slices(int64_t segments, int64_t elements) {
-  // ~256 rows per workgroup, at most 64 slices per segment, at least one
-  int64_t s = segments > 0 ? elements / (segments * 256) : 1;
-  return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
-}
-
 }  // namespace
 }  // namespace ptgnn_amd
 
 using namespace ptgnn_amd;
 
-extern "C" size_t ptgnn_amd_weighted_pool_workspace_bytes(int64_t num_segments, int64_t num_elements, int32_t dim) {
-  if (num_segments <= 0 || dim <= 0) return 0;
-  return (size_t)num_segments * pool_slices(num_segments, num_elements) * dim * sizeof(float);
-}
-
-extern "C" int ptgnn_amd_weighted_pool_f32(const float *x, int64_t ld_x, const float *w, const int32_t *rowptr,
-                                           const int32_t *perm, int64_t num_segments, int64_t num_elements, int32_t dim,
-                                           float *out, int64_t ld_out, void *workspace, size_t workspace_bytes,
-                                           void *stream_) {
-  PTGNN_REQUIRE(num_segments >= 0 && num_elements >= 0 && dim > 0, PTGNN_AMD_EINVAL, "weighted_pool: bad sizes");
-  if (num_segments == 0) return PTGNN_AMD_OK;
-  PTGNN_REQUIRE(w && rowptr && out && (num_elements == 0 || (x && perm)), PTGNN_AMD_EINVAL, "weighted_pool: null pointer");
-  PTGNN_REQUIRE(ld_out >= dim && (num_elements == 0 || ld_x >= dim), PTGNN_AMD_EINVAL, "weighted_pool: bad leading dimension");
-  const PoolShape sh = pool_shape(dim, ld_x % 4 == 0 && aligned16(x));
-  PTGNN_REQUIRE(sh.cols > 0, PTGNN_AMD_EUNSUPPORTED, "weighted_pool: dim %d exceeds 1024", dim);
-  const int slices = pool_slices(num_segments, num_elements);
-  const size_t need = (size_t)num_segments * slices * dim * sizeof(float);
-  PTGNN_REQUIRE(workspace && workspace_bytes >= need, PTGNN_AMD_EWORKSPACE, "weighted_pool: workspace of %zu bytes, need %zu",
-                workspace_bytes, need);
-  const int64_t blocks = num_segments * slices;
-  PTGNN_REQUIRE(blocks < ((int64_t)1 << 31) && num_elements < ((int64_t)1 << 31), PTGNN_AMD_EUNSUPPORTED,
-                "weighted_pool: too many segments / elements");
+extern "C" int ptgnn_amd_score_scale_f32(const float *x, int64_t ld_x, const float *w, int64_t num_rows, int32_t dim,
+                                         float *y, int64_t ld_y, void *stream_) {
+  PTGNN_REQUIRE(num_rows >= 0 && dim > 0, PTGNN_AMD_EINVAL, "score_scale: bad sizes");
+  if (num_rows == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(x && w && y, PTGNN_AMD_EINVAL, "score_scale: null pointer");
+  PTGNN_REQUIRE(ld_x >= dim && ld_y >= dim, PTGNN_AMD_EINVAL, "score_scale: bad leading dimension");
+  const PoolShape sh = pool_shape(dim, ld_x % 4 == 0 && ld_y % 4 == 0 && aligned16(x) && aligned16(y));
+  PTGNN_REQUIRE(sh.cols > 0, PTGNN_AMD_EUNSUPPORTED, "score_scale: dim %d exceeds 1024", dim);
+  const int groups = kPoolThreads / sh.lanes;
+  int64_t blocks = (num_rows + groups - 1) / groups;
+  if (blocks > 256 * 16) blocks = 256 * 16;       // grid-stride beyond 16 workgroups per CU
   hipStream_t st = (hipStream_t)stream_;
-  float *partial = static_cast<float *>(workspace);
-  const size_t lds = (size_t)(kPoolThreads / sh.lanes) * dim * sizeof(float);
-  POOL_DISPATCH(k_weighted_pool_partial, sh, (unsigned)blocks, lds, st, x, ld_x, w, rowptr, perm, dim, sh.lanes, slices,
-                partial);
-  PTGNN_LAUNCH_CHECK();
-  const int64_t total = num_segments * dim;
-  k_fold_partials<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(partial, slices, dim, num_segments, out, ld_out);
+  POOL_DISPATCH(k_score_scale, sh, (unsigned)blocks, 0, st, x, ld_x, w, num_rows, dim, sh.lanes, y, ld_y);
   PTGNN_LAUNCH_CHECK();
   return PTGNN_AMD_OK;
 }

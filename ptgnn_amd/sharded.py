@@ -56,6 +56,110 @@ def _to_device_ints(values: Sequence[int], device) -> torch.Tensor:
     return t.to(device)
 
 
+# Device -> host reads made by the shard builds.  "blocking": the host waits for work it has just enqueued (a `.tolist()`
+# of this minibatch's counts: the stream drains first); "late": values of the PREVIOUS minibatch, copied asynchronously
+# when that minibatch was built and picked up now (the copy finished long ago: the host does not wait).  The steady state
+# of a build with an `ExchangePlanner` makes no blocking read (tests/test_sharded_cpu.py, tests/two_rank_gpu_check.py).
+HOST_READS = {"blocking": 0, "late": 0}
+
+
+def _read_now(t: torch.Tensor) -> list:
+    HOST_READS["blocking"] += 1
+    return t.tolist()
+
+
+class ExchangePlanner:
+    """Learned capacities of the per-layer halo exchange, kept ACROSS the minibatches of one process group (one planner
+    per model / data loader and rank; every rank of the group must use one).
+
+    `ShardedGraph.build` needs host integers for the all-to-all of halo rows: how many rows travel per peer pair.  The
+    exact build reads them back from the device once per minibatch -- a blocking read that drains the stream, of the same
+    order as a whole cfg4 forward.  With a planner only the FIRST build (and a build after an overflow) does that.  Every
+    later build exchanges FIXED-capacity blocks instead: per peer pair the largest count seen so far x `slack`, rounded up
+    to `granule` rows (grow-only; both ends of a pair learn from the same number, need_counts[p <- q] == got_counts[q -> p],
+    by the same rule at the same build, so their split sizes always agree).  Unused capacity is padding: requests for the
+    owner's first row, never referenced by an edge.  The true counts of build k are copied to the host asynchronously and
+    looked at during build k + 1: if a pair exceeded its capacity (summed over the group, so every rank sees it), that
+    build raises PtgnnAmdError on EVERY rank -- the outputs of minibatch k were computed from a truncated halo and are
+    wrong (the same contract as the asynchronous node-id guard, ptgnn_amd.ops.check_indices) -- with the capacities
+    already grown, so repeating the build succeeds.  `last_overflow` keeps the count for callers that prefer to poll."""
+
+    def __init__(self, slack: float = 1.125, granule: int = 64):
+        self.slack, self.granule = float(slack), int(granule)
+        self.recv_caps: Optional[List[int]] = None      # rows reserved per owner in this rank's halo table
+        self.send_caps: Optional[List[int]] = None      # rows this rank sends per peer
+        self.global_stats: Tuple[int, int, int] = (0, 0, 0)
+        self.ever_cut = False
+        self._pending = None                              # (host tensor, event | None) of the previous build
+        self._layout = None                               # device tensors derived from the capacities (rebuilt on growth)
+        self.builds = self.exact_builds = self.overflows = 0
+        self.last_overflow = 0
+
+    def ready(self) -> bool:
+        return self.recv_caps is not None
+
+    def _cap(self, old: int, seen: int) -> int:
+        if seen <= old:
+            return old
+        want = int(seen * self.slack + 0.999)
+        return (want + self.granule - 1) // self.granule * self.granule
+
+    def learn(self, need: Sequence[int], got: Sequence[int], stats: Sequence[int]) -> None:
+        old_r = self.recv_caps or [0] * len(need)
+        old_s = self.send_caps or [0] * len(got)
+        new_r = [self._cap(o, int(c)) for o, c in zip(old_r, need)]
+        new_s = [self._cap(o, int(c)) for o, c in zip(old_s, got)]
+        if new_r != self.recv_caps or new_s != self.send_caps:
+            self._layout = None
+        self.recv_caps, self.send_caps = new_r, new_s
+        self.global_stats = (int(stats[1]), int(stats[2]), int(stats[3]))
+        self.ever_cut = self.ever_cut or int(stats[0]) > 0
+
+    def post(self, values: torch.Tensor) -> None:
+        """Start the asynchronous copy of this build's counts to the host (read by the next build)."""
+        if values.is_cuda:
+            host = torch.empty(values.shape, dtype=values.dtype).pin_memory()
+            with torch.cuda.device(values.device):
+                host.copy_(values, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(values.device))
+            self._pending = (host, ev)
+        else:
+            self._pending = (values.clone(), None)
+
+    def collect(self, world: int) -> None:
+        """Look at the previous build's counts (posted one minibatch ago): learn from them; an overflow raises."""
+        if self._pending is None:
+            return
+        host, ev = self._pending
+        self._pending = None
+        if ev is not None:
+            ev.synchronize()       # recorded a whole minibatch ago: already complete, the host does not wait
+        HOST_READS["late"] += 1
+        vals = [int(v) for v in host.tolist()]
+        stats, need, got = vals[:5], vals[5: 5 + world], vals[5 + world: 5 + 2 * world]
+        self.learn(need, got, stats)
+        self.last_overflow = stats[4]
+        if stats[4] > 0:
+            self.overflows += 1
+            from ptgnn_amd import _lib
+            raise _lib.PtgnnAmdError(
+                f"halo exchange: {stats[4]} (rank, owner) pair(s) needed more halo rows than the learned capacity in the "
+                "PREVIOUS sharded minibatch; its halo table was truncated and its outputs are wrong.  The capacities "
+                "have been grown: rebuild (and recompute that minibatch if its results matter).")
+
+    def layout(self, world: int, device, bounds: torch.Tensor):
+        """(owner of every padded halo position, start of every owner's block, capacities) as device tensors."""
+        if self._layout is None or self._layout[0].device != torch.device(device):
+            caps = torch.tensor(self.recv_caps, dtype=torch.int64)
+            off = torch.cumsum(caps, 0) - caps
+            owner = torch.repeat_interleave(torch.arange(world, dtype=torch.int64), caps)
+            if torch.device(device).type == "cuda":
+                caps, off, owner = (t.pin_memory().to(device, non_blocking=True) for t in (caps, off, owner))
+            self._layout = (owner, off, caps)
+        return self._layout
+
+
 def balanced_node_ranges(in_degree: torch.Tensor, world: int) -> List[Tuple[int, int]]:
     """Contiguous ranges with ~equal numbers of in-edges (+1 per node so empty rows count a bit):
     the balance criterion that matters for power-law graphs."""
@@ -139,12 +243,15 @@ class ShardedGraph:
     @staticmethod
     def build(adjacency_lists: Adj, node_range: Tuple[int, int], group=None,
               build_plan: bool = True, all_ranges: Optional[Sequence[Tuple[int, int]]] = None,
-              overlap: Optional[bool] = None, assume_no_cut: bool = False) -> "ShardedGraph":
+              overlap: Optional[bool] = None, assume_no_cut: bool = False,
+              planner: Optional["ExchangePlanner"] = None) -> "ShardedGraph":
         """adjacency_lists: int64 (src, dst) per edge type in GLOBAL node ids, holding exactly the
         edges whose dst lies in this rank's `node_range`.  `all_ranges` (every rank's range, in rank
         order) skips the all-gather when the partition is static.  `overlap` (default: env
         PTGNN_AMD_SHARD_OVERLAP, off): split the edges into an own-source and a halo-source block so that
-        inference layers aggregate the first while the halo rows travel (see `aggregate_two_blocks`)."""
+        inference layers aggregate the first while the halo rows travel (see `aggregate_two_blocks`).
+        `planner` (an `ExchangePlanner` kept across minibatches): after its first build the exchange sizes come from
+        learned capacities and the build makes NO blocking host read (single-block mode; `overlap` builds stay exact)."""
         g = ShardedGraph()
         g.group = group
         if overlap is None:
@@ -180,45 +287,46 @@ class ShardedGraph:
             mine = _to_device_ints([g.lo, g.hi], dev)
             allr = [torch.empty_like(mine) for _ in range(g.world)]
             dist.all_gather(allr, mine, group=group)
-            all_ranges = torch.stack(allr).tolist()
+            all_ranges = _read_now(torch.stack(allr))
         g.set_bounds(all_ranges, dev)
 
         # One tiny collective decides whether this minibatch has ANY cut edge.  A disjoint-union batch
         # partitioned on graph boundaries (graphneuralnetwork.py:418-423 keeps a graph's node ids
         # contiguous) has none: every rank then runs the single-GPU path with no data-path collective
         # and skips the halo bookkeeping altogether.
-        hip = dev.type == "cuda"
-        if hip:
-            # the whole index pass in HIP (csrc/shard_index.hip: 5 launches over the edge lists and a BITMAP of the
-            # global id space, no host sync): local ids of every endpoint, the sorted distinct halo ids, halo rows per
-            # owner, remote-source edge count, own-source edges per type
-            ls, ld, counts, need_buf, sstats = ops.shard_index(adjacency_lists, g.lo, g.hi, g.bounds, g.bounds_host[-1])
-            need_counts = sstats[: g.world]
-            flag = sstats[g.world: g.world + 1]                     # edges with a remote source (0 = nothing is cut)
-            halo_total = sstats[g.world + 1: g.world + 2]
-            own_counts_dev = sstats[g.world + 2:]
-            n_edges = sum(counts)
-        else:   # gloo / CPU tests of the host logic: the same results from torch ops
-            src, dst, counts = _flatten(adjacency_lists)
-            flag = torch.zeros(1, dtype=torch.int64, device=dev)
-            if src.numel():
-                lo_s, hi_s = torch.aminmax(src)
-                flag = ((lo_s < g.lo) | (hi_s >= g.hi)).to(torch.int64).reshape(1)
-            need_counts = g.index_locally(adjacency_lists, (src, dst, counts))   # device int64 [world], no host sync yet
-            halo_total = need_counts.sum().reshape(1)
-            n_edges = int(src.numel())
-        # ONE small all-reduce: the cut flag and the group-wide (edges, own rows, halo rows) the layers choose their
-        # form from -- a per-rank choice would make ranks disagree on what the halo all-to-all carries
-        stats = torch.cat([flag, _to_device_ints([n_edges, g.n_local], dev), halo_total])
+        steady = planner is not None and planner.ready() and not overlap
+        if planner is not None:
+            planner.builds += 1
+            if steady:
+                planner.collect(g.world)      # the previous minibatch's counts; an overflow raises on every rank
+        ls, ld, counts, need_buf, need_counts, flag, halo_total, own_counts_dev = g._index_pass(adjacency_lists, overlap)
+        n_edges = sum(counts)
+        over = torch.zeros(1, dtype=torch.int64, device=dev)
+        if steady:
+            over = (need_counts > planner.layout(g.world, dev, g.bounds)[2]).sum().reshape(1)
+        # ONE small all-reduce: the cut flag, the group-wide (edges, own rows, halo rows) the layers choose their form
+        # from -- a per-rank choice would make ranks disagree on what the halo all-to-all carries -- and (planner) the
+        # number of peer pairs over their learned capacity
+        stats = torch.cat([flag, _to_device_ints([n_edges, g.n_local], dev), halo_total, over])
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
         got_counts = torch.empty_like(need_counts)
         dist.all_to_all_single(got_counts, need_counts.contiguous(), group=group)
+        if steady:
+            # no host read-back: fixed-capacity exchange blocks, the true counts travel to the host behind our back
+            planner.post(torch.cat([stats, need_counts, got_counts]))
+            g._finish_steady(planner, ls, ld, counts, need_buf, need_counts, group)
+            if build_plan:
+                g.build_plan()
+            return g
         # ONE host read-back per minibatch: the flag + stats, the split sizes all_to_all_single wants as host ints
         # and (two-block mode) the per-type own-source edge counts
-        extra = [own_counts_dev if hip else g.own_source_counts()] if overlap else []
-        both = torch.cat([stats, need_counts, got_counts] + extra).tolist()
+        extra = [own_counts_dev] if overlap else []
+        both = _read_now(torch.cat([stats, need_counts, got_counts] + extra))
         g.global_stats = (int(both[1]), int(both[2]), int(both[3]))
-        both = [both[0]] + both[4:]
+        if planner is not None:
+            planner.exact_builds += 1
+            planner.learn(both[5: 5 + g.world], both[5 + g.world: 5 + 2 * g.world], both[:5])
+        both = [both[0]] + both[5:]
         if int(both[0]) == 0:
             g.no_cut = True
             g.n_halo = 0
@@ -226,7 +334,7 @@ class ShardedGraph:
             g.send_ids = g.need_ids
             g.send_splits = [0] * g.world
             g.recv_splits = [0] * g.world
-            g.local_adj = _unflatten(ls, ld, counts) if hip else _unflatten(src - g.lo, dst - g.lo, counts)
+            g.local_adj = _unflatten(ls, ld, counts)
             g._flat = g._slot = g._mark = None
             if build_plan:
                 g.build_plan()
@@ -235,12 +343,10 @@ class ShardedGraph:
         g.recv_splits = [int(v) for v in both[: g.world]]            # halo rows I receive per owner
         g.send_splits = [int(v) for v in both[g.world: 2 * g.world]]  # rows I send per peer
         g.n_halo = sum(g.recv_splits)
-        if hip:
-            g.need_ids = need_buf[: g.n_halo]
-            g._flat = g._local_flat = (ls, ld, counts)               # `_flat` only serves `_type_ids` (device + counts)
-            g.local_adj = _unflatten(ls, ld, counts)
-        else:
-            g.finish_local_index()
+        g.need_ids = need_buf[: g.n_halo]
+        g._flat = g._local_flat = (ls, ld, counts)                   # `_flat` only serves `_type_ids` (device + counts)
+        g.local_adj = _unflatten(ls, ld, counts)
+        g._slot = g._mark = None
         if overlap:
             g.split_blocks([int(v) for v in both[2 * g.world:]])
         g._flat = None
@@ -250,6 +356,72 @@ class ShardedGraph:
         if build_plan and not overlap:
             g.build_plan()
         return g
+
+    def _index_pass(self, adjacency_lists: Adj, want_own_counts: bool):
+        """The collective-free, host-read-free part of `build`: local ids of every endpoint (remote sources as
+        n_local + their slot in the sorted distinct halo id list), that list, halo rows per owner, the number of
+        remote-source edges, the halo total and (two-block mode) own-source edges per type -- all DEVICE tensors."""
+        dev = adjacency_lists[0][0].device
+        if dev.type == "cuda":
+            # the whole index pass in HIP (csrc/shard_index.hip: 5 launches over the edge lists and a BITMAP of the
+            # global id space, no host sync)
+            ls, ld, counts, need_buf, sstats = ops.shard_index(adjacency_lists, self.lo, self.hi, self.bounds,
+                                                               self.bounds_host[-1])
+            w = self.world
+            return (ls, ld, counts, need_buf, sstats[:w], sstats[w: w + 1], sstats[w + 1: w + 2], sstats[w + 2:])
+        # gloo / CPU tests of the host logic: the same results from torch ops
+        src, dst, counts = _flatten(adjacency_lists)
+        rem = (src < self.lo) | (src >= self.hi)
+        flag = rem.sum().reshape(1).to(torch.int64)
+        need_counts = self.index_locally(adjacency_lists, (src, dst, counts))
+        need_buf = torch.nonzero(self._mark, as_tuple=False).flatten()
+        ls = torch.where(rem, self._slot[src].to(torch.int64) + self.n_local, src - self.lo)
+        own = self.own_source_counts() if want_own_counts else None
+        return ls, dst - self.lo, counts, need_buf, need_counts, flag, need_counts.sum().reshape(1), own
+
+    def _finish_steady(self, planner: "ExchangePlanner", ls, ld, counts, need_buf, need_counts, group) -> None:
+        """The rest of a build whose exchange sizes come from the planner's learned capacities (host integers known
+        BEFORE this minibatch was looked at): halo table = [own rows | capacity block of owner 0 | of owner 1 | ...]."""
+        dev = ls.device
+        world, n = self.world, self.n_local
+        R, S = planner.recv_caps, planner.send_caps
+        self.global_stats = planner.global_stats          # one minibatch old: a speed decision, the same on every rank
+        self.recv_splits, self.send_splits = list(R), list(S)
+        self._slot = self._mark = self._flat = None
+        if not planner.ever_cut:
+            # no minibatch so far had a cut edge (the caller partitions on graph boundaries): predict the same -- no
+            # exchange, no collective per layer.  A cut edge that does appear is an overflow (capacity 0) AND trips the
+            # plan build's range guard (its source lies outside the own rows).
+            self.no_cut, self.n_halo = True, 0
+            self.need_ids = torch.zeros(0, dtype=torch.int64, device=dev)
+            self.send_ids = self.need_ids
+            self.local_adj = _unflatten(ls, ld, counts)
+            return
+        owner, off, caps = planner.layout(world, dev, self.bounds)
+        total = sum(R)
+        incl = torch.cumsum(need_counts, 0)
+        prefix = incl - need_counts
+        if total:
+            j = torch.arange(total, dtype=torch.int64, device=dev) - off[owner]
+            if need_buf.numel():
+                pos = (prefix[owner] + j).clamp_(0, need_buf.numel() - 1)
+                need_pad = torch.where(j < need_counts[owner], need_buf[pos], self.bounds[owner])
+            else:
+                need_pad = self.bounds[owner].clone()
+        else:
+            need_pad = torch.zeros(0, dtype=torch.int64, device=dev)
+        # remote sources: n_local + slot in the dense halo list  ->  n_local + start of the owner's block + rank inside it
+        slot = (ls - n).clamp_(min=0)
+        q = torch.searchsorted(incl, slot, right=True).clamp_(max=world - 1)
+        inside = torch.minimum(slot - prefix[q], (caps[q] - 1).clamp_(min=0))
+        ls = torch.where(ls >= n, n + off[q] + inside, ls)
+        self.n_halo = total
+        self.need_ids = need_pad
+        self.local_adj = _unflatten(ls, ld, counts)
+        self._local_flat = (ls, ld, counts)
+        wanted = torch.empty(sum(S), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(wanted, need_pad, list(S), list(R), group=group)
+        self.send_ids = (wanted - self.lo).clamp_(0, max(n - 1, 0))   # padding asks for the owner's first row
 
     def attach_graph_index(self, node_to_graph_idx_local: torch.Tensor, num_graphs: int) -> "ShardedGraph":
         """`node_to_graph_idx` of the OWN rows (global graph ids, graphneuralnetwork.py:440-443,469-477) and the
@@ -370,10 +542,15 @@ class ShardedGraph:
         (the own-source block) run while the rows travel over xGMI."""
         if self.no_cut:
             return None
-        own = table[: self.n_local]
-        send = ops.gather_rows(own, self.send_ids) if own.is_cuda else own.index_select(0, self.send_ids)
-        return dist.all_to_all_single(table[self.n_local:], send, self.recv_splits, self.send_splits,
+        return dist.all_to_all_single(table[self.n_local:], self._send_rows(table), self.recv_splits, self.send_splits,
                                       group=self.group, async_op=True)
+
+    def _send_rows(self, table: torch.Tensor) -> torch.Tensor:
+        """The rows of this rank's block of `table` its peers asked for, in peer order (HIP row gather on the GPU)."""
+        own = table[: self.n_local]
+        if self.n_local == 0:      # (planner padding can reserve rows on a rank that owns none in this minibatch)
+            return torch.zeros(self.send_ids.shape[0], table.shape[1], dtype=table.dtype, device=table.device)
+        return ops.gather_rows(own, self.send_ids) if own.is_cuda else own.index_select(0, self.send_ids)
 
     @staticmethod
     def build_local(adjacency_lists: Adj, all_ranges: Sequence[Tuple[int, int]], rank: int,
@@ -443,12 +620,7 @@ class ShardedGraph:
         """table[:n_local] holds this rank's rows; fills table[n_local:] with the halo rows."""
         if self.no_cut:      # agreed on by every rank at build time: nobody enters the collective
             return table
-        own = table[: self.n_local]
-        if own.is_cuda:
-            send = ops.gather_rows(own, self.send_ids)
-        else:
-            send = own.index_select(0, self.send_ids)
-        dist.all_to_all_single(table[self.n_local:], send, self.recv_splits, self.send_splits,
+        dist.all_to_all_single(table[self.n_local:], self._send_rows(table), self.recv_splits, self.send_splits,
                                group=self.group)
         return table
 
@@ -560,7 +732,8 @@ def layer_forward(layer, state: Dict) -> torch.Tensor:
     """One sharded message-passing layer: (re)build the shard plan for the minibatch, exchange halo
     rows, aggregate, update.  Nothing is cached across calls (bench.py times the whole thing)."""
     shard = ShardedGraph.build(state["adj_global"], state["range"], build_plan=False,
-                               all_ranges=state.get("all_ranges"), overlap=state.get("overlap"))
+                               all_ranges=state.get("all_ranges"), overlap=state.get("overlap"),
+                               planner=state.get("planner"))
     if shard.no_cut:   # no edge crosses a rank boundary: exactly the single-GPU layer on the local block
         return layer(state["x"], shard.local_adj, None, {}, {}, [None] * len(shard.local_adj))
     if not shard.overlap:

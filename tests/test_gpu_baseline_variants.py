@@ -86,7 +86,8 @@ def test_config1_as_the_reference_batches_it_every_minibatch():
     the shipped 5 x MLP-MP @ 256 -- match the oracle on EVERY minibatch."""
     from benchmarks import ppi
     res = ppi.config1(torch.device("cuda"), parity=True, passes=1)
-    assert 12 <= res["minibatches"] <= 24 and res["nodes_per_minibatch_min_max"][0] >= ppi.NODE_CAP, res
+    # every minibatch but the last closes at the first graph that takes it to the cap (graphneuralnetwork.py:438)
+    assert 12 <= res["minibatches"] <= 24 and ppi.NODE_CAP <= res["nodes_per_minibatch_min_max"][1] < 2 * ppi.NODE_CAP + 500, res
     for key in ("ggnn64", "ppi_arch_mlp256"):
         p = res[key]["parity"]
         print(f"cfg1 {key}: {res[key]['ms_per_minibatch']} ms/minibatch, {res[key]['c_abi_launches_per_layer']} launches/layer, {p}")

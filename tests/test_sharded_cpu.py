@@ -508,3 +508,110 @@ def test_layer_form_is_one_decision_for_the_group():
     assert res[0][2] == res[1][2], "group-wide sizes give one decision"
     assert res[0][3] == res[1][3] and res[0][3][0] == 4 * 8000 + 4 * 300 and res[0][3][1] == 4000
     assert res[0][4] and res[1][4]
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: learned exchange capacities -- no blocking host read in a steady-state cut-edge build
+# ------------------------------------------------------------------------------------------------
+def _planner_minibatch(world, n, e, seed, spread):
+    """One random graph over `world` equal ranges; `spread` = the fraction of sources drawn from ALL nodes (the others
+    stay inside the destination's range): how many halo rows a minibatch needs varies with it."""
+    g = torch.Generator().manual_seed(seed)
+    per = n // world
+    dst = torch.randint(0, n, (e,), generator=g)
+    own = dst // per * per + torch.randint(0, per, (e,), generator=g)
+    anywhere = torch.randint(0, n, (e,), generator=g)
+    src = torch.where(torch.rand(e, generator=g) < spread, anywhere, own)
+    half = e // 2
+    return [(src[:half], dst[:half]), (src[half:], dst[half:])], torch.randn(n, 6, generator=g)
+
+
+def _worker_planner(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import scatter_ref
+        from ptgnn_amd import sharded
+        from ptgnn_amd._lib import PtgnnAmdError
+        n = 120 * world
+        per = n // world
+        lo, hi = rank * per, (rank + 1) * per
+        ranges = [(p * per, (p + 1) * per) for p in range(world)]
+        planner = sharded.ExchangePlanner(slack=1.25, granule=8)
+        log = []
+
+        def run(seed, spread, e=900):
+            adj, x = _planner_minibatch(world, n, e, seed, spread)
+            mine = [(s[(d >= lo) & (d < hi)], d[(d >= lo) & (d < hi)]) for s, d in adj]
+            before = dict(sharded.HOST_READS)
+            shard = sharded.ShardedGraph.build(mine, (lo, hi), build_plan=False, all_ranges=ranges, planner=planner)
+            reads = {k: sharded.HOST_READS[k] - before[k] for k in before}
+            table = shard.exchange(x[lo:hi].contiguous())
+            assert table.shape[0] == shard.n_local + shard.n_halo == per + sum(shard.recv_splits)
+            msgs = torch.cat([table.index_select(0, s) for s, _ in shard.local_adj])
+            tgt = torch.cat([d for _, d in shard.local_adj])
+            got = scatter_ref.scatter(msgs, tgt, dim=0, dim_size=per, reduce="sum")
+            gm = torch.cat([x.index_select(0, s) for s, _ in adj])
+            gt = torch.cat([d for _, d in adj])
+            want = scatter_ref.scatter(gm, gt, dim=0, dim_size=n, reduce="sum")[lo:hi]
+            np.testing.assert_array_equal(got.numpy(), want.numpy())       # same rows, same fold order: same bits
+            log.append((reads, shard.n_halo))
+            return shard
+
+        run(1, 0.5)                                    # first build: exact (one blocking read), capacities learned
+        assert log[-1][0] == {"blocking": 1, "late": 0} and planner.exact_builds == 1 and planner.ready()
+        caps0 = list(planner.recv_caps)
+        assert all(c % 8 == 0 for c in caps0) and caps0[rank] == 0 and sum(caps0) > 0
+        for seed in (2, 3, 4):                         # steady state: smaller or equal demand -> NO blocking read
+            sh = run(seed, 0.4)
+            assert log[-1][0]["blocking"] == 0 and log[-1][1] == sum(planner.recv_caps), log[-1]
+            assert sh.recv_splits == planner.recv_caps and not sh.no_cut
+        assert planner.exact_builds == 1 and planner.builds == 4 and sharded.HOST_READS["late"] >= 2
+        # peers agree on every pair's capacity without ever having talked about it: send_caps[p -> q] == recv_caps[q <- p]
+        mine_caps = torch.tensor(planner.recv_caps + planner.send_caps)
+        allc = [torch.empty_like(mine_caps) for _ in range(world)]
+        dist.all_gather(allc, mine_caps)
+        for p in range(world):
+            for q in range(world):
+                assert int(allc[p][q]) == int(allc[q][world + p]), (p, q)
+        # demand beyond the learned capacity: this build still makes no blocking read (its halo is truncated) ...
+        adj, x = _planner_minibatch(world, n, 4000, 9, 1.0)
+        mine = [(s[(d >= lo) & (d < hi)], d[(d >= lo) & (d < hi)]) for s, d in adj]
+        b0 = sharded.HOST_READS["blocking"]
+        sharded.ShardedGraph.build(mine, (lo, hi), build_plan=False, all_ranges=ranges, planner=planner)
+        assert sharded.HOST_READS["blocking"] == b0
+        # ... and the NEXT build raises on every rank (the overflow count is all-reduced), capacities grown
+        try:
+            run(10, 0.4)
+            raise AssertionError("the overflow of the previous minibatch went unnoticed")
+        except PtgnnAmdError as exc:
+            assert "learned capacity" in str(exc) and planner.last_overflow > 0 and planner.overflows == 1
+        assert sum(planner.recv_caps) > sum(caps0)
+        run(9, 1.0, e=4000)                            # the minibatch that overflowed now fits: exact results, no blocking read
+        assert log[-1][0]["blocking"] == 0
+        run(11, 0.4)
+        out_q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        out_q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_planner_builds_make_no_blocking_host_read_in_steady_state(world):
+    """`ShardedGraph.build(..., planner=ExchangePlanner())` -- after the first (exact) build the halo
+    exchange runs on learned per-pair capacities: a cut-edge minibatch is built, exchanged and aggregated with ZERO
+    blocking device -> host reads (sharded.HOST_READS), bit-identical to the global aggregation; both ends of every peer
+    pair hold the same capacity; a minibatch over capacity is reported by the next build on EVERY rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_planner, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert r[1] == "ok", r[1]

@@ -208,6 +208,40 @@ def case_graph_boundaries(rank, world):
     ops.check_indices(sync=True)     # the range guard saw no source outside the own rows
 
 
+def case_planner(rank, world):
+    """Learned exchange capacities on the DEVICE path (HIP index pass, HIP row gather, torch remap): three cut-edge
+    minibatches of different sizes through ONE ExchangePlanner -- the first build is exact, the next two make no blocking
+    host read (sharded.HOST_READS) -- each bit-identical to the unsharded layer (max: any fold order; padding rows of the
+    halo table are never referenced)."""
+    from ptgnn_amd import layers as L, ops, sharded, workloads
+    H = 64
+    L.EDGE_PATH_BIAS = 1e9                         # table form: message rows travel
+    torch.manual_seed(81)
+    layer = L.MlpMessagePassingLayer(H, H, H, 1, "max").cuda().eval()
+    planner = sharded.ExchangePlanner()
+    n = 6000
+    ranges = [(p * n // world, (p + 1) * n // world) for p in range(world)]
+    lo, hi = ranges[rank]
+    for i, e in enumerate((30_000, 24_000, 27_000)):
+        g = torch.Generator().manual_seed(82 + i)
+        adj = [(torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g))]
+        x = workloads.node_states(n, H, seed=90 + i).cuda()
+        ops.clear_plan_cache()
+        with torch.no_grad():
+            want = layer(x, _cuda_adj(adj), None, {}, {}, [None])[lo:hi]
+        before = dict(sharded.HOST_READS)
+        shard = sharded.ShardedGraph.build(_mine(adj, lo, hi), (lo, hi), all_ranges=ranges, planner=planner)
+        with torch.no_grad():
+            got = layer.forward_sharded(x[lo:hi].contiguous(), shard)
+        blocking = sharded.HOST_READS["blocking"] - before["blocking"]
+        assert blocking == (1 if i == 0 else 0), (i, blocking)
+        assert not shard.no_cut and shard.n_halo == sum(planner.recv_caps) > 0
+        np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
+    assert planner.exact_builds == 1 and planner.builds == 3 and planner.overflows == 0
+    ops.check_indices(sync=True)
+    _ok(rank, f"planner_steady_state halo_capacity={sum(planner.recv_caps)}")
+
+
 def case_powerlaw_hubs(rank, world):
     """BASELINE config 5's shape, scaled: ONE power-law graph (Zipf-0.8 destinations => hub rows of > 2048 in-edges,
     long rows of 257..2048) whose sources are uniform over ALL ranks' nodes, so every hub row has in-edges from every
@@ -261,7 +295,7 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     which = os.environ.get("TWO_RANK_CASES", "default")
-    cases = {"default": (case_layers, case_stack, case_training, case_graph_boundaries),
+    cases = {"default": (case_layers, case_stack, case_training, case_graph_boundaries, case_planner),
              "powerlaw": (case_powerlaw_hubs,)}[which]
     try:
         for case in cases:
