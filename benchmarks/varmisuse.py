@@ -109,18 +109,29 @@ def config4(dev, k=20, parity=True, arch="mlp"):
             want = O.run_layer_stack(x_cpu, adj_cpu, specs, node_to_graph_idx=n2g_cpu, trace=trace)
             exact = O.run_layer_stack(x_cpu.double(), adj_cpu, [O.cast_spec(sp, torch.float64) for sp in specs],
                                       node_to_graph_idx=n2g_cpu)
-            worst = 0.0
+            worst, pools = 0.0, []
             for mod, spec, (x_in, x_out) in zip(mods, specs, trace):
                 if spec["kind"] not in ("mlp", "ggnn", "global_gru"):
                     continue
                 ops.clear_plan_cache()
                 got = mod(x_in.to(dev), adj, n2g, {}, {}, feats).cpu()
-                worst = max(worst, float((got - x_out).abs().max()))
+                if spec["kind"] == "global_gru":
+                    # a pool adds ~2 000 fp32 node states per graph: ANY two fold orders differ by ~3e-5 behind the GRU
+                    # (the oracle's own serial order sits that far from float64), so this layer is attributed
+                    ex = O.global_gru_exchange(x_in.double(), n2g_cpu, O.cast_spec(spec, torch.float64))
+                    pools.append(attributed_parity(got, x_out, ex))
+                else:
+                    worst = max(worst, float((got - x_out).abs().max()))
             got = step().cpu()
         rec = attributed_parity(got, want, exact)
         rec.update(per_layer_max=worst, end_to_end=rec["max_abs"], n=n,
-                   ok=bool(worst <= PARITY_TOL and rec["ok"]),
+                   ok=bool(worst <= PARITY_TOL and rec["ok"] and all(p_["ok"] for p_ in pools)),
                    against="oracle/mp_oracle.py at full size: per layer (each layer fed the oracle's input of that "
                            "layer) and end to end, attributed against a float64 evaluation of the stack")
+        if pools:
+            rec["global_exchange_layers"] = {"layers": len(pools), "max_abs": max(p_["max_abs"] for p_ in pools),
+                                             "ours_vs_fp64": max(p_["ours_vs_fp64"] for p_ in pools),
+                                             "oracle_vs_fp64": max(p_["oracle_vs_fp64"] for p_ in pools),
+                                             "ok": all(p_["ok"] for p_ in pools)}
         res["parity"] = rec
     return res

@@ -50,7 +50,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 /* 101: ptgnn_amd_shard_index gained `bad_index_count` (round 4, mid-signature); the fused aggregation + node-update
- * entry point ptgnn_amd_gather_update_f32 was added (round 5).  102: ptgnn_amd_score_scale_f32, ptgnn_amd_weighted_pool_backward*_f32 (round 6).
+ * entry point ptgnn_amd_gather_update_f32 was added (round 5).  102: ptgnn_amd_weighted_pool*_f32 (round 6).
  * Callers check ptgnn_amd_version() >= the version their header was compiled against (the Python host does,
  * ptgnn_amd/_lib.py). */
 #define PTGNN_AMD_VERSION 102 /* 0.1.2 */
@@ -583,17 +583,21 @@ int ptgnn_amd_gru_cell_f32(const float *a, int64_t ld_a, const float *h, int64_t
  * Weighted-sum pooling of elements into samples (nodes into graphs):
  *   out[g, :] = sum_{i : map[i] == g} sigmoid(x[i, :] . w) * x[i, :]
  * Replaces: WeightedSumVarSizedElementReduce.forward, ptgnn/neuralmodels/reduceops/varsizedsummary.py:68-81 --
- *   nn.Linear(D, 1, bias=False) (a gemv), torch.sigmoid, the broadcast multiply and torch_scatter.scatter_sum -- as used
- *   by GruGlobalStateUpdate (globalgraphexchange.py:37-45) in the VarMisuse GGNN stack (varmisuse/train.py:87-92).
- * Forward: ptgnn_amd_score_scale_f32 writes y[i, :] = sigmoid(x[i, :] . w) * x[i, :] (gemv, sigmoid and multiply in one
- *   pass; x, y [num_rows, dim], w [dim], dim <= 1024); the sum over the map is ptgnn_amd_gather_reduce_f32 over the map's
- *   plan (reduce = sum, col = perm, type_bits = 0) -- the in-order fold of every other aggregation.
- * Backward: ptgnn_amd_weighted_pool_backward_f32 -> grad_x [num_elements, dim] and grad_w [dim] (both OVERWRITTEN;
- *   grad_w deterministic: per-workgroup partial rows in `workspace` added in a fixed order) from grad_out
- *   [num_segments, dim] and the int64 map itself.
+ *   nn.Linear(D, 1, bias=False) (a gemv), torch.sigmoid, the broadcast multiply that materialises [N, D] and
+ *   torch_scatter.scatter_sum -- as used by GruGlobalStateUpdate (globalgraphexchange.py:37-45) in the VarMisuse GGNN
+ *   stack (varmisuse/train.py:87-92).  One pass over x; no float atomics: a segment is cut into 128-row chunks counted
+ *   from its own start, the chunk partials are added in chunk order -- a fixed function of the segment's rows and their
+ *   order, wherever the segment sits in the batch (not the reference's serial fold order: fp32 rounding only).
+ *   x [num_elements, dim], w [dim], rowptr int32 [num_segments + 1] / perm int32 [num_elements]: the stable plan of the
+ *   element -> sample map (ptgnn_amd_csr_build over (map, map); perm[s] = element of plan slot s), out [num_segments, dim].
+ *   dim <= 1024.  workspace: ptgnn_amd_weighted_pool_workspace_bytes.
+ * Backward: grad_x [num_elements, dim] and grad_w [dim] (both OVERWRITTEN; grad_w deterministic) from
+ *   grad_out [num_segments, dim] and the int64 map itself.
  * ---------------------------------------------------------------------------------------- */
-int ptgnn_amd_score_scale_f32(const float *x, int64_t ld_x, const float *w, int64_t num_rows, int32_t dim, float *y,
-                              int64_t ld_y, void *stream);
+size_t ptgnn_amd_weighted_pool_workspace_bytes(int64_t num_segments, int64_t num_elements, int32_t dim);
+int ptgnn_amd_weighted_pool_f32(const float *x, int64_t ld_x, const float *w, const int32_t *rowptr,
+                                const int32_t *perm, int64_t num_segments, int64_t num_elements, int32_t dim,
+                                float *out, int64_t ld_out, void *workspace, size_t workspace_bytes, void *stream);
 size_t ptgnn_amd_weighted_pool_backward_workspace_bytes(int64_t num_elements, int32_t dim);
 int ptgnn_amd_weighted_pool_backward_f32(const float *x, int64_t ld_x, const float *w, const int64_t *map,
                                          const float *grad_out, int64_t ld_go, int64_t num_elements, int32_t dim,

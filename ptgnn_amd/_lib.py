@@ -91,7 +91,9 @@ SIGNATURES = {
     "ptgnn_amd_gru_cell_backward_gates_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp,
                                                          _vp]),
     "ptgnn_amd_gather_rows_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
-    "ptgnn_amd_score_scale_f32": (_c.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "ptgnn_amd_weighted_pool_workspace_bytes": (_c.c_size_t, [_i64, _i64, _i32]),
+    "ptgnn_amd_weighted_pool_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _c.c_size_t,
+                                               _vp]),
     "ptgnn_amd_weighted_pool_backward_workspace_bytes": (_c.c_size_t, [_i64, _i32]),
     "ptgnn_amd_weighted_pool_backward_f32": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp,
                                                         _c.c_size_t, _vp]),

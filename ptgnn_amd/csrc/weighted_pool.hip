@@ -4,19 +4,25 @@
 //     score_i = sigmoid(x_i . w)                    nn.Linear(D, 1, bias=False) + torch.sigmoid
 //     out[g]  = sum_{i : map[i] == g} score_i x_i   scatter_sum over element_to_sample_map
 //
-// Forward = k_score_scale (this file: the gemv, the sigmoid and the broadcast multiply of the reference in ONE streaming
-// pass, y_i = score_i x_i rounded like the reference's product) followed by the package's ordinary segment sum over the
-// map's plan (gather_reduce.hip) -- the SAME in-order fold every aggregation uses, so the pool of a graph of <= 2048 nodes
-// adds its rows in the order the reference's CPU scatter_add_ does, and a sharded run (whole graphs per rank) reproduces
-// the unsharded pool bit for bit.  (Round 6 first folded score, scaling and sum into one kernel over position slices of
-// each segment: 1.3x less traffic on a 20 MB table that sits in the Infinity Cache anyway, but a fold order of its own --
-// 3e-5 from the oracle on 2 000-node graphs, where this form is within 3e-6.)
+// The reference runs a [N, D] x [D, 1] gemv, a sigmoid, a broadcast multiply that materialises [N, D], and the
+// scatter.  Here the score, the scaling and the segment sum are ONE pass over x: N * D * 4 bytes read, G * D * 4 written
+// -- HBM-bound streaming work (cfg4: 80 k x 64 = 20 MB).
+//
+// Segments are graphs: few (tens) and long (thousands of rows).  One lane group per segment folding in the reference's
+// serial order is what the package's ordinary segment sum does for rows of <= 2048 slots -- ~250 dependent round trips,
+// 0.36 ms per pool at cfg4, 60 % on top of the whole 8-layer forward (measured, round 6) -- and segments beyond 2048 rows
+// leave that order anyway (hub chunks).  So every segment is cut into CHUNKS OF 128 ROWS COUNTED FROM ITS OWN START:
+// workgroup b folds chunk c of segment g (k_pool_chunk_starts gives the (g, c) of every workgroup), a last launch adds the
+// chunk partials of a segment in chunk order.  No float atomics; the value of a segment is a fixed function of ITS rows
+// and their order -- independent of where the segment sits in the batch, so a sharded run that keeps whole graphs on a
+// rank reproduces the unsharded pool bit for bit.  The fold order is not the reference's serial one: a sum of ~2 000
+// fp32 rows of magnitude <= 1 differs by ~3e-5 between ANY two orders (the fp32 oracle itself sits 2e-5 from float64 on
+// such pools); the tests hold the pool, and the GRU update behind it, to "no further from float64 than 2 x the oracle".
 //
 // Backward (training): with go = d out,
 //     d x_i = score_i go[g_i] + (go[g_i] . x_i) score_i (1 - score_i) w
 //     d w   = sum_i (go[g_i] . x_i) score_i (1 - score_i) x_i
-// one streaming pass for d x plus per-workgroup partial rows of d w that a second launch adds in a fixed order (no float
-// atomics: d w is a fixed function of its inputs).
+// one streaming pass for d x plus per-workgroup partial rows of d w that a second launch adds in a fixed order.
 #include "common.h"
 
 namespace ptgnn_amd {
@@ -36,23 +42,68 @@ __device__ __forceinline__ float group_sum(float v, int lanes) {
 constexpr int kPoolThreads = 256;
 // COLS = chunks (float4 or float) of one row a lane holds: 1 for dim <= lanes * VEC (hidden 64 ... 256), up to 16
 
-// y[i, :] = sigmoid(x[i, :] . w) * x[i, :]  -- one row per group of `lanes` lanes, rows independent (any order)
+constexpr int kPoolChunk = 128;       // rows of one chunk, counted from the start of its segment
+
+// chunk_start[g] = chunks of the segments in front of g (chunk_start[G] = all chunks); one workgroup
+__global__ __launch_bounds__(1024) void k_pool_chunk_starts(const int32_t *__restrict__ rowptr, int num_segments,
+                                                           int32_t *__restrict__ chunk_start) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < num_segments; base += 1024) {
+    const int gseg = base + threadIdx.x;
+    const int c = gseg < num_segments ? (rowptr[gseg + 1] - rowptr[gseg] + kPoolChunk - 1) / kPoolChunk : 0;
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int run = carry + inc - c;
+    for (int v = 0; v < wave; ++v) run += wsum[v];
+    if (gseg < num_segments) chunk_start[gseg] = run;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = run + c;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) chunk_start[num_segments] = carry;
+}
+
+// x rows are read through `perm` (plan order -> element id): a sorted map (node_to_graph_idx) makes it the identity.
 template <int VEC, int COLS>
-__global__ __launch_bounds__(kPoolThreads) void k_score_scale(const float *__restrict__ x, int64_t ld_x,
-                                                              const float *__restrict__ w, int64_t n, int dim, int lanes,
-                                                              float *__restrict__ y, int64_t ld_y) {
+__global__ __launch_bounds__(kPoolThreads) void k_weighted_pool_partial(
+    const float *__restrict__ x, int64_t ld_x, const float *__restrict__ w, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ perm, int dim, int lanes, int num_segments, const int32_t *__restrict__ chunk_start,
+    float *__restrict__ partial) {
+  extern __shared__ float lds[];                       // [groups, dim] partial rows of the workgroup
+  const int b = blockIdx.x;
+  if (b >= chunk_start[num_segments]) return;          // the grid is the host's upper bound n / 128 + G
+  int seg = 0, hi_seg = num_segments;                  // chunk_start[seg] <= b < chunk_start[seg + 1] (workgroup-uniform)
+  while (hi_seg - seg > 1) {
+    const int mid = (seg + hi_seg) >> 1;
+    if (chunk_start[mid] <= b) seg = mid; else hi_seg = mid;
+  }
+  const int beg = rowptr[seg], end = rowptr[seg + 1];
+  const int lo = beg + (b - chunk_start[seg]) * kPoolChunk;
+  const int hi = lo + kPoolChunk < end ? lo + kPoolChunk : end;
   const int groups = kPoolThreads / lanes;
-  const int g = threadIdx.x % lanes;
-  float wv[COLS][VEC];
+  const int grp = threadIdx.x / lanes, g = threadIdx.x % lanes;
+  float wv[COLS][VEC], acc[COLS][VEC];
 #pragma unroll
   for (int c = 0; c < COLS; ++c) {
     const int col = (c * lanes + g) * VEC;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) wv[c][v] = col + v < dim ? w[col + v] : 0.0f;
+    for (int v = 0; v < VEC; ++v) {
+      wv[c][v] = col + v < dim ? w[col + v] : 0.0f;
+      acc[c][v] = 0.0f;
+    }
   }
-  // every lane of a row group runs the same trip count: the shuffles of group_sum stay inside active lanes
-  for (int64_t i = (int64_t)blockIdx.x * groups + threadIdx.x / lanes; i < n; i += (int64_t)gridDim.x * groups) {
-    const float *row = x + i * ld_x;
+  for (int p = lo + grp; p < hi; p += groups) {        // the loop bound is uniform per row group: shuffles stay in step
+    const float *row = x + (int64_t)perm[p] * ld_x;
     float xv[COLS][VEC];
     float dot = 0.0f;
 #pragma unroll
@@ -74,16 +125,37 @@ __global__ __launch_bounds__(kPoolThreads) void k_score_scale(const float *__res
     }
     const float s = pool_sigmoid(group_sum(dot, lanes));
 #pragma unroll
-    for (int c = 0; c < COLS; ++c) {
-      const int col = (c * lanes + g) * VEC;
-      if (col < dim) {
-        if constexpr (VEC == 4)
-          *reinterpret_cast<float4 *>(y + i * ld_y + col) = make_float4(s * xv[c][0], s * xv[c][1], s * xv[c][2], s * xv[c][3]);
-        else
-          y[i * ld_y + col] = s * xv[c][0];
-      }
-    }
+    for (int c = 0; c < COLS; ++c)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[c][v] = fmaf(s, xv[c][v], acc[c][v]);
   }
+#pragma unroll
+  for (int c = 0; c < COLS; ++c) {
+    const int col = (c * lanes + g) * VEC;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+      if (col + v < dim) lds[grp * dim + col + v] = acc[c][v];
+  }
+  __syncthreads();
+  float *dst = partial + (int64_t)blockIdx.x * dim;    // [chunks, dim], the chunks of a segment consecutive
+  for (int col = threadIdx.x; col < dim; col += kPoolThreads) {
+    float t = 0.0f;
+    for (int r = 0; r < groups; ++r) t += lds[r * dim + col];   // fixed order
+    dst[col] = t;
+  }
+}
+
+// out[g, :] = the chunk partials of segment g added in chunk order (a segment without elements pools to 0)
+__global__ __launch_bounds__(256) void k_fold_segments(const float *__restrict__ partial,
+                                                        const int32_t *__restrict__ chunk_start, int dim, int64_t segments,
+                                                        float *__restrict__ out, int64_t ld_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= segments * dim) return;
+  const int64_t g = i / dim;
+  const int col = (int)(i % dim);
+  float t = 0.0f;
+  for (int c = chunk_start[g]; c < chunk_start[g + 1]; ++c) t += partial[(int64_t)c * dim + col];
+  out[g * ld_out + col] = t;
 }
 
 // out[r, :] = sum over the `parts` rows partial[r * parts + s, :], s ascending
@@ -214,24 +286,49 @@ PoolShape pool_shape(int dim, bool aligned) {
     }                                                                                                       \
   } while (0)
 
+int64_t pool_chunk_bound(int64_t segments, int64_t elements) { return elements / kPoolChunk + segments; }
+
+size_t pool_starts_bytes(int64_t segments) { return (size_t)((segments + 1 + 3) / 4 * 4) * sizeof(int32_t); }
+
 }  // namespace
 }  // namespace ptgnn_amd
 
 using namespace ptgnn_amd;
 
-extern "C" int ptgnn_amd_score_scale_f32(const float *x, int64_t ld_x, const float *w, int64_t num_rows, int32_t dim,
-                                         float *y, int64_t ld_y, void *stream_) {
-  PTGNN_REQUIRE(num_rows >= 0 && dim > 0, PTGNN_AMD_EINVAL, "score_scale: bad sizes");
-  if (num_rows == 0) return PTGNN_AMD_OK;
-  PTGNN_REQUIRE(x && w && y, PTGNN_AMD_EINVAL, "score_scale: null pointer");
-  PTGNN_REQUIRE(ld_x >= dim && ld_y >= dim, PTGNN_AMD_EINVAL, "score_scale: bad leading dimension");
-  const PoolShape sh = pool_shape(dim, ld_x % 4 == 0 && ld_y % 4 == 0 && aligned16(x) && aligned16(y));
-  PTGNN_REQUIRE(sh.cols > 0, PTGNN_AMD_EUNSUPPORTED, "score_scale: dim %d exceeds 1024", dim);
-  const int groups = kPoolThreads / sh.lanes;
-  int64_t blocks = (num_rows + groups - 1) / groups;
-  if (blocks > 256 * 16) blocks = 256 * 16;       // grid-stride beyond 16 workgroups per CU
+extern "C" size_t ptgnn_amd_weighted_pool_workspace_bytes(int64_t num_segments, int64_t num_elements, int32_t dim) {
+  if (num_segments <= 0 || dim <= 0) return 0;
+  return pool_starts_bytes(num_segments) + (size_t)pool_chunk_bound(num_segments, num_elements) * dim * sizeof(float);
+}
+
+extern "C" int ptgnn_amd_weighted_pool_f32(const float *x, int64_t ld_x, const float *w, const int32_t *rowptr,
+                                           const int32_t *perm, int64_t num_segments, int64_t num_elements, int32_t dim,
+                                           float *out, int64_t ld_out, void *workspace, size_t workspace_bytes,
+                                           void *stream_) {
+  PTGNN_REQUIRE(num_segments >= 0 && num_elements >= 0 && dim > 0, PTGNN_AMD_EINVAL, "weighted_pool: bad sizes");
+  if (num_segments == 0) return PTGNN_AMD_OK;
+  PTGNN_REQUIRE(w && rowptr && out && (num_elements == 0 || (x && perm)), PTGNN_AMD_EINVAL, "weighted_pool: null pointer");
+  PTGNN_REQUIRE(ld_out >= dim && (num_elements == 0 || ld_x >= dim), PTGNN_AMD_EINVAL, "weighted_pool: bad leading dimension");
+  const PoolShape sh = pool_shape(dim, ld_x % 4 == 0 && aligned16(x));
+  PTGNN_REQUIRE(sh.cols > 0, PTGNN_AMD_EUNSUPPORTED, "weighted_pool: dim %d exceeds 1024", dim);
+  const int64_t bound = pool_chunk_bound(num_segments, num_elements);
+  const size_t need = pool_starts_bytes(num_segments) + (size_t)bound * dim * sizeof(float);
+  PTGNN_REQUIRE(workspace && workspace_bytes >= need, PTGNN_AMD_EWORKSPACE, "weighted_pool: workspace of %zu bytes, need %zu",
+                workspace_bytes, need);
+  PTGNN_REQUIRE(bound < ((int64_t)1 << 31) && num_elements < ((int64_t)1 << 31) && num_segments < ((int64_t)1 << 31),
+                PTGNN_AMD_EUNSUPPORTED, "weighted_pool: too many segments / elements");
   hipStream_t st = (hipStream_t)stream_;
-  POOL_DISPATCH(k_score_scale, sh, (unsigned)blocks, 0, st, x, ld_x, w, num_rows, dim, sh.lanes, y, ld_y);
+  int32_t *chunk_start = static_cast<int32_t *>(workspace);
+  float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + pool_starts_bytes(num_segments));
+  k_pool_chunk_starts<<<1, 1024, 0, st>>>(rowptr, (int)num_segments, chunk_start);
+  PTGNN_LAUNCH_CHECK();
+  if (bound > 0) {
+    const size_t lds = (size_t)(kPoolThreads / sh.lanes) * dim * sizeof(float);
+    POOL_DISPATCH(k_weighted_pool_partial, sh, (unsigned)bound, lds, st, x, ld_x, w, rowptr, perm, dim, sh.lanes,
+                  (int)num_segments, chunk_start, partial);
+    PTGNN_LAUNCH_CHECK();
+  }
+  const int64_t total = num_segments * dim;
+  k_fold_segments<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(partial, chunk_start, dim, num_segments, out, ld_out);
   PTGNN_LAUNCH_CHECK();
   return PTGNN_AMD_OK;
 }

@@ -1422,30 +1422,28 @@ def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def score_scale(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """y[i] = sigmoid(x_i . w) x_i (ptgnn_amd_score_scale_f32: the gemv, sigmoid and broadcast multiply of
-    WeightedSumVarSizedElementReduce, varsizedsummary.py:73-77, in one pass)."""
+def weighted_pool(x: torch.Tensor, w: torch.Tensor, plan: GraphPlan) -> torch.Tensor:
+    """out[g] = sum_{i in segment g} sigmoid(x_i . w) x_i over the plan of an element -> sample map
+    (ptgnn_amd_weighted_pool_f32: WeightedSumVarSizedElementReduce, varsizedsummary.py:68-81, in one pass over x)."""
     lib = _lib.load()
     _require_cuda_f32("x", x)
     x = _rowmajor(x)
     n, d = x.shape
-    if w.numel() != d:
-        raise _lib.PtgnnAmdError(f"score_scale: x {tuple(x.shape)} and w {tuple(w.shape)} do not agree")
+    if n != plan.num_edges or w.numel() != d or plan.perm is None:
+        raise _lib.PtgnnAmdError(f"weighted_pool: x {tuple(x.shape)}, w {tuple(w.shape)} do not fit a plan over "
+                                 f"{plan.num_edges} elements")
     w = w.detach().reshape(-1).contiguous()
-    y = torch.empty(n, d, dtype=torch.float32, device=x.device)
-    with _timed("score_scale", bytes=8.0 * n * d + 4.0 * d):
-        rc = lib.ptgnn_amd_score_scale_f32(x.data_ptr() if n else None, _ld(x) if n else d, w.data_ptr(), n, d,
-                                           y.data_ptr() if n else None, d, _stream(y))
-    _lib.check(rc, "ptgnn_amd_score_scale_f32")
-    return y
-
-
-def weighted_pool(x: torch.Tensor, w: torch.Tensor, plan: GraphPlan) -> torch.Tensor:
-    """out[g] = sum_{i in segment g} sigmoid(x_i . w) x_i over the plan of an element -> sample map: `score_scale`, then the
-    in-order segment sum every aggregation uses (WeightedSumVarSizedElementReduce, varsizedsummary.py:68-81)."""
-    if x.shape[0] != plan.num_edges or plan.perm is None:
-        raise _lib.PtgnnAmdError(f"weighted_pool: x {tuple(x.shape)} does not fit a plan over {plan.num_edges} elements")
-    return gather_reduce(score_scale(x, w), plan, x.shape[1], "sum", type_bits=0, col=plan.perm)
+    G = plan.num_nodes
+    out = torch.empty(G, d, dtype=torch.float32, device=x.device)
+    ws_bytes = int(lib.ptgnn_amd_weighted_pool_workspace_bytes(G, n, d))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+    plan.wait()
+    with _timed("weighted_pool", bytes=4.0 * (n * d + G * d + d) + 4.0 * n):
+        rc = lib.ptgnn_amd_weighted_pool_f32(x.data_ptr() if n else None, _ld(x) if n else d, w.data_ptr(),
+                                             plan.rowptr.data_ptr(), plan.perm.data_ptr(), G, n, d, out.data_ptr(), d,
+                                             ws.data_ptr(), ws_bytes, _stream(out))
+    _lib.check(rc, "ptgnn_amd_weighted_pool_f32")
+    return out
 
 
 def weighted_pool_backward(x: torch.Tensor, w: torch.Tensor, index: torch.Tensor, grad_out: torch.Tensor):

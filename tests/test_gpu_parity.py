@@ -1671,10 +1671,12 @@ def test_global_exchange_training_gradients_match_oracle_autograd(pool, sizes):
     xg = x.cuda().requires_grad_(True)
     yg = mod(xg, [], n2g.cuda(), {}, {}, [])
     yg.backward(gout.cuda())
-    if max(sizes) > 4096:
+    if max(sizes) > 4096 or pool == "weighted_sum":
         # a hub row (a graph of thousands of nodes) is folded chunk-wise, not in the reference's serial order, and a
         # 6000-term fp32 sum of O(1) values carries ~1e-3 of rounding in EITHER order before it enters the GRU: attribute
-        # against a float64 evaluation -- the HIP path may sit no further from it than the fp32 oracle does (x2)
+        # against a float64 evaluation -- the HIP path may sit no further from it than the fp32 oracle does (x2).  The
+        # weighted-sum pool folds 128-row chunks of every graph (csrc/weighted_pool.hip), whatever its size: same rule
+        # (1 300 fp32 rows: 1.2e-5 from the oracle's serial order on one element, round 6)
         x64 = x.double().requires_grad_(True)
         y64 = O.global_gru_exchange(x64, n2g, {k: (v.detach().double() if isinstance(v, torch.Tensor) else v) for k, v in spec.items()})
         y64.backward(gout.double())
