@@ -27,9 +27,13 @@
  *         used under mutexes -- two caller streams never share an event; at most 64 sets, beyond that
  *         the launches stay on the caller's stream;
  *       * launch counters (ptgnn_amd_launch_count): relaxed atomics, never read by the library;
- *       * PROCESS-WIDE knobs, meant to be set once at start-up and not while other threads are inside
- *         the library: ptgnn_amd_set_gemm_mode (which arithmetic the GEMMs use) and
- *         ptgnn_amd_set_plan_path (developer A/B of the plan build).  Environment variables
+ *       * two TEST / DEVELOPER switches, process-wide on purpose (a torch backward runs on autograd worker threads,
+ *         which have to see the setting of the thread that built the graph): ptgnn_amd_set_gemm_mode (which of two
+ *         kernel families with identical bits serves the dense blocks) and ptgnn_amd_set_plan_path (which record
+ *         format the plan build uses at small sizes).  RESULTS NEVER DEPEND ON EITHER -- they exist so that the
+ *         parity tests can drive every kernel family / sort path on every shape; relaxed atomics, safe to flip
+ *         between calls, not meant for production code (two models in one process simply share the default:
+ *         dispatch by shape).  Environment variables
  *         (PTGNN_AMD_*) are read per call or once at first use; they are developer / test switches.
  *     Caller-owned state with an ownership rule: the plan build's `control` block and the hub
  *     `hub_tickets` counters are ZERO AT REST and belong to the launches of ONE stream at a time --
@@ -80,8 +84,8 @@ enum { PTGNN_AMD_ACT_NONE = 0, PTGNN_AMD_ACT_TANH = 1, PTGNN_AMD_ACT_RELU = 2 };
 int ptgnn_amd_version(void);
 const char *ptgnn_amd_last_error(void);
 
-/* Kernel family of the dense blocks (ptgnn_amd_linear_f32, ptgnn_amd_gru_cell*_f32,
- * ptgnn_amd_edge_linear_f32) -- i.e. of what replaces nn.Linear / nn.GRUCell at
+/* TEST / DEVELOPER switch (see "Conventions"): kernel family of the dense blocks (ptgnn_amd_linear_f32,
+ * ptgnn_amd_gru_cell*_f32, ptgnn_amd_edge_linear_f32) -- i.e. of what replaces nn.Linear / nn.GRUCell at
  * gatedmessagepassing.py:57-69 and mlpmessagepassing.py:96-117.  Process-wide; initial value from the
  * environment variable PTGNN_AMD_GEMM (default 1).
  *   0  128 x 128 tile kernels, exact fp32 MFMA

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -753,7 +754,7 @@ int end_bit_for(int64_t num_rows) {
   return b;
 }
 
-int g_force_path = 0;   // ptgnn_amd_set_plan_path: 0 auto, 1 force the wide-record MSD form, 2 force the LSD form
+std::atomic<int> g_force_path{0};   // test switch (relaxed; results never depend on it), ptgnn_amd_set_plan_path: 0 auto, 1 force the wide-record MSD form, 2 force the LSD form
 
 // How a build of (edges, rows) is split into passes.
 //   MSD (<= 4 M edges, <= 21 row bits): first level on the high bits, k_plan_buckets on the low bits -- the lists

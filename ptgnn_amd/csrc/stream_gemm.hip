@@ -49,6 +49,8 @@
 #include <unordered_map>
 
 #include "dense_common.h"
+#include <atomic>
+
 #include "stream_gemm.h"
 
 namespace ptgnn_amd {
@@ -1291,7 +1293,7 @@ __global__ __launch_bounds__(512, 2) void k_stream_edge_v2(EdgeV2Args q) {
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-int g_mode = -1;
+std::atomic<int> g_mode{-1};   // test / developer switch: relaxed, results never depend on it
 
 bool debug_on() {
   static int v = -1;
@@ -1336,15 +1338,17 @@ void dense_runs(int nrb, int ncs, int &rps, int &run_len, int max_wg = 0) {
 }  // namespace
 
 int stream_gemm_mode() {
-  if (g_mode < 0) {
+  int mode = g_mode.load(std::memory_order_relaxed);
+  if (mode < 0) {
     const char *e = getenv("PTGNN_AMD_GEMM");
-    int m = e ? atoi(e) : 1;
-    g_mode = (m == 0 || m == 1) ? m : 1;
+    const int m = e ? atoi(e) : 1;
+    mode = (m == 0 || m == 1) ? m : 1;
+    g_mode.store(mode, std::memory_order_relaxed);
   }
-  return g_mode;
+  return mode;
 }
 
-void stream_gemm_set_mode(int mode) { g_mode = mode; }
+void stream_gemm_set_mode(int mode) { g_mode.store(mode, std::memory_order_relaxed); }
 
 #define PTGNN_STREAM_DISPATCH_NB(NBV, KERN, ...)     \
   switch (NBV) {                                      \

@@ -1,6 +1,6 @@
 import sys, json, torch
 sys.path.insert(0, '/root/repo')
-import bench
+from benchmarks import synthetic as bench
 dev = torch.device('cuda:0')
 for i in range(2):
     r = bench.config5_shard(dev, parity=False)

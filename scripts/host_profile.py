@@ -8,7 +8,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402
+from benchmarks import graph2class as bench  # noqa: E402
 
 dev = torch.device("cuda:0")
 st = bench.make_cfg3(dev)

@@ -9,7 +9,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402
+from benchmarks import graph2class as bench  # noqa: E402
 from ptgnn_amd import ops, workloads  # noqa: E402
 from ptgnn_amd.gnn import GraphNeuralNetwork  # noqa: E402
 

@@ -1,6 +1,6 @@
 import sys, time, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
+from benchmarks import synthetic as bench
 from ptgnn_amd import ops
 dev = torch.device('cuda:0')
 st = bench.make_cfg2(dev, 0, 1)

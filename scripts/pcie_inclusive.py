@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402
+from benchmarks import graph2class as bench  # noqa: E402
 from ptgnn_amd import ops  # noqa: E402
 from ptgnn_amd.batching import MinibatchBuilder  # noqa: E402
 
