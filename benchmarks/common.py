@@ -180,8 +180,8 @@ def pmc_traffic(workload, kernel):
     FETCH_SIZE x2 wide-read correction + WRITE_SIZE, separate --pmc runs; newest round first).  PMC counters
     cannot be read from inside a plain bench run, so the figure is the profiled one and names its source; null
     when no profile holds the kernel."""
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    root = os.path.join(ROOT, "profiles")
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(root, f"{rnd}_{workload}_traffic.json")
         try:
             with open(path) as f:
