@@ -79,10 +79,10 @@ def cpu_baseline_cfg2(st, gpu_out):
     return {"value": round(st["E"] / sweep[best], 1), "unit": "edges/s", "cores": int(best), "kind": "port",
             "host_cpus": os.cpu_count(), "seconds_by_threads": sweep,
             "value_1_thread": round(st["E"] / sweep["1"], 1),
-            "sample": "cfg2 full size (N=200k, E=1.1M), 1 MLP-MP layer forward; per thread count 1 warm-up + 3 timed, "
-                      "median; best thread count reported in `cores`. torch-CPU fp32 restatement of the reference "
-                      "layer (oracle/mp_oracle.py): the reference's own modules cannot be imported on the GPU box "
-                      "(no /root/reference there); their timing in the authoring container is in BASELINE.md"}, parity
+            "sample": "kind \"port\": the torch-CPU fp32 RESTATEMENT of the reference layer (oracle/mp_oracle.py), not the "
+                      "reference's own module (no /root/reference on the GPU box; the two time within 5-25 % of each other in "
+                      "the authoring container, BASELINE.md 3). cfg2 full size (N=200k, E=1.1M), 1 MLP-MP layer forward; per "
+                      "thread count 1 warm-up + 3 timed, median; best thread count reported in `cores`"}, parity
 
 
 def cpu_baseline_cfg3(st, gpu_out):
@@ -119,11 +119,12 @@ def cpu_baseline_cfg3(st, gpu_out):
             "full_batch_seconds_by_threads": full_by_threads,
             "sample_value": round(e_small / (sweep[best] / layers), 1),
             "sample_value_1_thread": round(e_small / (sweep["1"] / layers), 1),
-            "sample": f"`value` = E / t_layer of the FULL Graph2Class batch (the GPU line's own inputs: N={st['N']}, "
+            "sample": "kind \"port\": the torch-CPU fp32 RESTATEMENT of the reference layers (oracle/mp_oracle.py), not the "
+                      "reference's own modules -- those cannot be imported on the GPU box (no /root/reference there); in the "
+                      "authoring container the two time within 5-25 % of each other (BASELINE.md 3). "
+                      f"`value` = E / t_layer of the FULL Graph2Class batch (the GPU line's own inputs: N={st['N']}, "
                       f"E={st['E']}, {layers}-layer GGNN stack forward) at the best thread count (`cores`), 1 warm-up + "
                       "3 timed forwards, median -- also the parity reference; the thread count is the better of the two "
                       f"best of a sweep {{1, 8, 32, all}} on the first 8 of the 48 graphs (N={small['num_nodes']}, E={e_small}; "
-                      "`sample_value*`). torch-CPU fp32 restatement of the reference layers "
-                      "(oracle/mp_oracle.py): the reference's own modules cannot be imported on the GPU box (no "
-                      "/root/reference there); their timing in the authoring container is in BASELINE.md"}, parity
+                      "`sample_value*`)"}, parity
 

@@ -9,7 +9,7 @@ cd "$(dirname "$0")/../ptgnn_amd/csrc"
 base=${src%.*}
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -x hip "$@" -c $src -o ${base}_${tag}.o
 objs=""
-for o in errors csr_build gather_reduce dense_f32 stream_gemm edge_gemm edge_wgrad wgrad_stream batching row_epilogue shard_index segment_mul; do
+for o in errors csr_build gather_reduce dense_f32 stream_gemm edge_gemm edge_wgrad wgrad_stream batching row_epilogue shard_index segment_mul weighted_pool; do
   if [ "$o" = "$base" ]; then objs="$objs ${base}_${tag}.o"; else objs="$objs $o.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o libptgnn_amd_${tag}.so $objs
