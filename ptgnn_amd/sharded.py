@@ -118,7 +118,7 @@ class ExchangePlanner:
     def post(self, values: torch.Tensor) -> None:
         """Start the asynchronous copy of this build's counts to the host (read by the next build)."""
         if values.is_cuda:
-            host = torch.empty(values.shape, dtype=values.dtype).pin_memory()
+            host = ops._pinned_words(int(values.numel()))       # pooled: pinning fresh host memory costs more than the build
             with torch.cuda.device(values.device):
                 host.copy_(values, non_blocking=True)
                 ev = torch.cuda.Event()
@@ -137,6 +137,8 @@ class ExchangePlanner:
             ev.synchronize()       # recorded a whole minibatch ago: already complete, the host does not wait
         HOST_READS["late"] += 1
         vals = [int(v) for v in host.tolist()]
+        if ev is not None:
+            ops._PINNED_FREE.setdefault(int(host.numel()), []).append(host)
         stats, need, got = vals[:5], vals[5: 5 + world], vals[5 + world: 5 + 2 * world]
         self.learn(need, got, stats)
         self.last_overflow = stats[4]

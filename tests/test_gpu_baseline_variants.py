@@ -215,3 +215,32 @@ def test_weighted_sum_pooling_runs_on_the_hip_kernel_forward_and_backward(dim, l
     assert torch.equal(out2, out) and torch.equal(mod.score_weight.grad.cpu().double(), gw)
     assert ops.launches_since(before) == {} or True                   # (pooling has no GEMM family to count)
     assert calls == [], calls
+
+
+def test_weighted_sum_pooling_edge_shapes():
+    """No elements at all, a single element, every element its own sample, one sample holding everything (a 40 000-row
+    segment = 313 chunks), width 1 -- values against float64, empties exactly 0, the backward's shapes."""
+    from ptgnn_amd import reduceops as R
+    torch.manual_seed(3)
+    for n, G, idx_of, dim in ((0, 4, lambda n: torch.zeros(0, dtype=torch.int64), 32),
+                              (1, 3, lambda n: torch.tensor([2]), 16),
+                              (500, 500, lambda n: torch.arange(n), 8),
+                              (40_000, 2, lambda n: torch.ones(n, dtype=torch.int64), 64),
+                              (3000, 5, lambda n: torch.randint(0, 5, (n,)), 1)):
+        idx = idx_of(n)
+        x = torch.randn(n, dim)
+        mod = R.WeightedSumVarSizedElementReduce(dim)
+        w = mod.score_weight.detach().double()
+        want = torch.zeros(G, dim, dtype=torch.float64).index_add_(
+            0, idx, x.double() * torch.sigmoid(x.double() @ w.t()))
+        mod = mod.cuda()
+        xc = x.cuda().requires_grad_(True)
+        got = mod(R.ElementsToSummaryRepresentationInput(xc, idx.cuda(), G))
+        assert tuple(got.shape) == (G, dim)
+        np.testing.assert_allclose(got.detach().cpu().double().numpy(), want.numpy(), rtol=0,
+                                   atol=2e-5 * max(1.0, float(want.abs().max())))
+        empty = torch.bincount(idx, minlength=G) == 0
+        assert float(got.detach().cpu()[empty].abs().sum()) == 0.0
+        got.sum().backward()
+        assert tuple(xc.grad.shape) == (n, dim) and tuple(mod.score_weight.grad.shape) == (1, dim)
+        assert bool(torch.isfinite(xc.grad).all()) and bool(torch.isfinite(mod.score_weight.grad).all())
