@@ -939,7 +939,8 @@ extern "C" int ptgnn_amd_gather_reduce_rows_f32(const float *ysrc, int64_t ld_y,
   PTGNN_REQUIRE(type_bits >= 0 && type_bits < 16, PTGNN_AMD_EINVAL, "gather_reduce: bad type_bits");
   if (num_nodes == 0) return PTGNN_AMD_OK;
   PTGNN_REQUIRE(rowptr && out && ld_out >= msg_dim, PTGNN_AMD_EINVAL, "gather_reduce: null/ld");
-  PTGNN_REQUIRE(ysrc && col, PTGNN_AMD_EINVAL, "gather_reduce: null ysrc/col");
+  // a plan without edges (every edge type of the minibatch empty) reads no message row: its table may be a null pointer
+  PTGNN_REQUIRE(col && (ysrc || num_edges == 0), PTGNN_AMD_EINVAL, "gather_reduce: null ysrc/col");
   PTGNN_REQUIRE(!(epilogue & PTGNN_AMD_EPI_LAYERNORM) || (ln_gamma && ln_beta), PTGNN_AMD_EINVAL,
                 "gather_reduce: LayerNorm epilogue needs gamma/beta");
   PTGNN_REQUIRE(argout == nullptr || reduce >= PTGNN_AMD_MAX, PTGNN_AMD_EINVAL,

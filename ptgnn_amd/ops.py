@@ -129,6 +129,12 @@ def _rowmajor(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+def _ptr_or(t: torch.Tensor, stand_in: torch.Tensor) -> int:
+    """Device pointer of `t`; a tensor WITHOUT elements (the message table of a minibatch whose edge types are all empty)
+    has none, so a stand-in that is never dereferenced (no CSR slot refers to a row of it) is passed instead."""
+    return t.data_ptr() if t.numel() else stand_in.data_ptr()
+
+
 def _ld(t: torch.Tensor) -> int:
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
@@ -763,7 +769,7 @@ def gather_reduce(ysrc: torch.Tensor, plan: GraphPlan, msg_dim: int, reduce: str
     hub_ws, hub_bytes = _hub_workspace(plan, msg_dim, arg is not None, ysrc.device)
     with _timed("gather_reduce", bytes=nbytes):
         rc = lib.ptgnn_amd_gather_reduce_rows_f32(
-            ysrc.data_ptr(), ld_y, ydst.data_ptr() if ydst is not None else None, ld_yd,
+            _ptr_or(ysrc, plan.rowptr), ld_y, ydst.data_ptr() if ydst is not None else None, ld_yd,
             plan.rowptr.data_ptr(), colt.data_ptr(), tb, N, msg_dim,
             REDUCE_IDS[reduce], epilogue,
             ln_weight.data_ptr() if ln_weight is not None else None,
@@ -866,7 +872,7 @@ def gather_update(msgs: torch.Tensor, plan: GraphPlan, reduce: str, col: torch.T
     with _timed("gather_update", bytes=E * (4.0 * M + 4) + N * (4.0 * out_dim + 4) + 4.0 * out_dim * M,
                 flops=2.0 * N * M * out_dim):
         rc = lib.ptgnn_amd_gather_update_f32(
-            msgs.data_ptr(), _ld(msgs), plan.rowptr.data_ptr(), col.data_ptr(), int(type_bits), N, M, REDUCE_IDS[reduce],
+            _ptr_or(msgs, plan.rowptr), _ld(msgs), plan.rowptr.data_ptr(), col.data_ptr(), int(type_bits), N, M, REDUCE_IDS[reduce],
             int(epilogue), ln_weight.data_ptr() if epilogue & EPI_LAYERNORM else None,
             ln_bias.data_ptr() if epilogue & EPI_LAYERNORM else None, float(ln_eps), weight.data_ptr(),
             bias.data_ptr() if bias is not None else None, out_dim, ACT_IDS[act], out.data_ptr(), _ld(out), _stream(out))
@@ -884,7 +890,7 @@ def gather_reduce_masked(grad: torch.Tensor, arg: torch.Tensor, bplan: GraphPlan
     out = torch.empty(bplan.num_nodes, msg_dim, dtype=torch.float32, device=grad.device)
     hub_ws, hub_bytes = _hub_workspace(bplan, msg_dim, False, grad.device)
     with _timed("gather_reduce_masked", bytes=bplan.num_edges * (8.0 * msg_dim + 8) + bplan.num_nodes * (4.0 * msg_dim + 4)):
-        rc = lib.ptgnn_amd_gather_reduce_masked_f32(grad.data_ptr(), _ld(grad), arg.data_ptr(),
+        rc = lib.ptgnn_amd_gather_reduce_masked_f32(_ptr_or(grad, bplan.rowptr), _ld(grad), _ptr_or(arg, bplan.rowptr),
                                                     bplan.rowptr.data_ptr(), bplan.col.data_ptr(),
                                                     slot_of.data_ptr(), bplan.num_nodes, msg_dim,
                                                     out.data_ptr(), msg_dim, bplan.num_edges,
