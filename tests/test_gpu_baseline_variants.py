@@ -168,7 +168,7 @@ def test_weighted_sum_pooling_runs_on_the_hip_kernel_forward_and_backward(dim, l
     F.linear (the reference's [N, D] x [D, 1] gemv), no torch.sigmoid, no [N, D] product -- in inference and in training;
     values and the gradients of x and of the score weight against float64 on the host.  Widths that are not multiples of
     4 / beyond one wave's float4 span, an unsorted map, empty and very long segments."""
-    from ptgnn_amd import ops, reduceops as R
+    from ptgnn_amd import reduceops as R
     calls = []
     real_linear, real_sig = torch.nn.functional.linear, torch.sigmoid
     monkeypatch.setattr(torch.nn.functional, "linear", lambda *a, **k: (calls.append("F.linear"), real_linear(*a, **k))[1])
@@ -200,7 +200,6 @@ def test_weighted_sum_pooling_runs_on_the_hip_kernel_forward_and_backward(dim, l
     np.testing.assert_allclose(got.cpu().double().numpy(), want.detach().numpy(), rtol=0, atol=2e-5 * scale)
     empty = torch.bincount(idx, minlength=G) == 0
     assert float(got.cpu()[empty].abs().sum()) == 0.0               # samples without elements pool to 0
-    before = ops.launch_counts()
     xc = x.cuda().requires_grad_(True)
     out = mod(R.ElementsToSummaryRepresentationInput(xc, idx.cuda(), G))
     assert torch.equal(out.detach(), got)                             # the training node runs the same forward launch
@@ -213,7 +212,6 @@ def test_weighted_sum_pooling_runs_on_the_hip_kernel_forward_and_backward(dim, l
     mod.score_weight.grad = None
     out2.backward(gout.cuda())
     assert torch.equal(out2, out) and torch.equal(mod.score_weight.grad.cpu().double(), gw)
-    assert ops.launches_since(before) == {} or True                   # (pooling has no GEMM family to count)
     assert calls == [], calls
 
 
