@@ -34,9 +34,9 @@ def test_sharded_paths_over_real_process_group(world):
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     tail = (r.stdout + "\n" + r.stderr)[-6000:]
     assert r.returncode == 0, tail
-    # 8 layer cases + 1 stack + 2 training cases + 2 graph-boundary cases + 1 planner case per rank (ranks may interleave
-    # their lines)
-    assert len(re.findall(r"rank \d+ ok ", r.stdout)) == 14 * world, tail
+    # 8 layer cases + 1 stack + 2 training cases + 2 graph-boundary cases + 1 planner case + 1 fuzz case per rank (ranks may
+    # interleave their lines)
+    assert len(re.findall(r"rank \d+ ok ", r.stdout)) == 15 * world, tail
 
 
 @pytest.mark.parametrize("world", [4, 8])

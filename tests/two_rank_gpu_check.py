@@ -244,6 +244,77 @@ def case_planner(rank, world):
     _ok(rank, f"planner_steady_state halo_capacity={sum(planner.recv_caps)}")
 
 
+def case_fuzz(rank, world):
+    """Seeded random sweep over real collectives: random graphs (1-5 edge types, some empty, a hot destination), widths,
+    reduces, layer kinds and forms; every build goes through ONE ExchangePlanner shared by all cases, so later (larger)
+    graphs overflow the capacities learned from earlier ones -- the next build then raises on EVERY rank, is repeated, and
+    the truncated minibatch is recomputed.  Own rows must equal the unsharded layer bit for bit (max / min always; sums too:
+    a row is reduced on one rank in the unsharded order; no row here reaches the hub threshold)."""
+    from ptgnn_amd import layers as L, ops, sharded
+    from ptgnn_amd._lib import PtgnnAmdError
+    planner = sharded.ExchangePlanner()
+    raised = 0
+    rng = np.random.RandomState(4242)            # the SAME stream on every rank
+    for case in range(10):
+        n = (600, 600, 2500, 9000, 2500, 9000, 600, 9000, 2500, 9000)[case]      # growing: capacities learned small overflow
+        T = int(rng.choice([1, 2, 5]))
+        H = int(rng.choice([32, 64, 128]))
+        kind = ["ggnn", "mlp", "mlp_notarget"][rng.randint(3)]
+        agg = ["sum", "mean", "max", "min"][rng.randint(4)]
+        L.EDGE_PATH_BIAS = 0.0 if (T > 1 and rng.rand() < 0.5) else 1e9       # pin the form (shard and whole graph alike)
+        adj = []
+        for t in range(T):
+            e = 0 if (T > 1 and rng.rand() < 0.2) else int(rng.randint(n, 6 * n))
+            s_, d_ = rng.randint(0, n, e), rng.randint(0, n, e)
+            if e > 100:
+                d_[:300] = rng.randint(0, n)                                   # a hot destination (< hub threshold)
+            adj.append((torch.from_numpy(s_.astype(np.int64)), torch.from_numpy(d_.astype(np.int64))))
+        if sum(int(a[0].shape[0]) for a in adj) == 0:
+            continue
+        torch.manual_seed(100 + case)
+        layer = (L.GatedMessagePassingLayer(H, H, T, agg) if kind == "ggnn" else
+                 L.MlpMessagePassingLayer(H, H, H, T, agg, use_target_state_as_message_input=kind == "mlp")).cuda().eval()
+        x = torch.randn(n, H, generator=torch.Generator().manual_seed(200 + case)).cuda()
+        cadj = _cuda_adj(adj)
+        ops.clear_plan_cache()
+        with torch.no_grad():
+            want = layer(x, cadj, None, {}, {}, [None] * T)
+        ranges = _ranges(adj, n, world)
+        lo, hi = ranges[rank]
+        mine = _mine(adj, lo, hi)
+
+        def run():
+            shard = sharded.ShardedGraph.build(mine, (lo, hi), all_ranges=ranges, planner=planner)
+            with torch.no_grad():
+                return layer.forward_sharded(x[lo:hi].contiguous(), shard)
+        try:
+            got = run()
+        except PtgnnAmdError as exc:              # the PREVIOUS case overflowed: every rank is here together
+            assert "learned capacity" in str(exc)
+            raised += 1
+            got = run()
+        # did THIS build overflow?  its count is known one build late: look now (a blocking look is fine in a test)
+        pending = planner._pending
+        over = 0
+        if pending is not None:
+            if pending[1] is not None:
+                pending[1].synchronize()
+            over = int(pending[0][4])
+        if over:
+            try:
+                got = run()                         # raises (capacities grown) ...
+                raise AssertionError("an overflow went unreported")
+            except PtgnnAmdError:
+                raised += 1
+                got = run()                         # ... and the repeat is exact
+        np.testing.assert_array_equal(got.cpu().numpy(), want[lo:hi].cpu().numpy())
+    L.EDGE_PATH_BIAS = 1.25
+    total = torch.tensor([raised])
+    dist.all_reduce(total)
+    assert int(total) == raised * world and raised >= 2   # every rank raised the same number of times
+    _ok(rank, f"fuzz_planner_real_collectives overflows_recovered={raised} exact_builds={planner.exact_builds} builds={planner.builds}")
+
+
 def case_powerlaw_hubs(rank, world):
     """BASELINE config 5's shape, scaled: ONE power-law graph (Zipf-0.8 destinations => hub rows of > 2048 in-edges,
     long rows of 257..2048) whose sources are uniform over ALL ranks' nodes, so every hub row has in-edges from every
@@ -297,7 +368,7 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     which = os.environ.get("TWO_RANK_CASES", "default")
-    cases = {"default": (case_layers, case_stack, case_training, case_graph_boundaries, case_planner),
+    cases = {"default": (case_layers, case_stack, case_training, case_graph_boundaries, case_planner, case_fuzz),
              "powerlaw": (case_powerlaw_hubs,)}[which]
     try:
         for case in cases:
