@@ -115,6 +115,7 @@ def main():
         sys.exit(self_launch(args))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    C.hold_stdout()
     rank, world, dev = C.dist_setup(args)
     # N = 1: the cfg5 shard also runs through the dst-range code path (world-1 process group, nothing cut) unless skipped
     sharded_leg = (not args.no_sharded_variants and not args.no_secondary) or args.sharded_variants or args.force_sharded
@@ -303,17 +304,9 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
-    # RCCL prints a banner through C stdio, which is block-buffered on a pipe and would otherwise land
-    # AFTER the JSON line at process exit: drain it first so the JSON is the last line of stdout
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:  # noqa: BLE001
-        pass
     _log("done")
-    if rank == 0:
-        sys.stdout.flush()
-        print(json.dumps(result), flush=True)
+    if rank == 0:      # the one line of stdout (C.hold_stdout parked everything else, RCCL's banner included, on stderr)
+        C.emit_line(json.dumps(result))
     if exit_code:
         sys.stderr.write("bench.py: GPU output is outside the parity tolerance of the CPU oracle (see \"parity\")\n")
         sys.exit(exit_code)

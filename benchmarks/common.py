@@ -260,3 +260,32 @@ def parity_rollup(primary, by_config):
     out["configs_on_relaxed_bar"] = relaxed
     out["configs_failed"] = failed
     return out
+
+
+# stdout carries exactly ONE line, the JSON.  The collective backend prints a banner through C stdio (RCCL: "RCCL version :
+# ...", five lines, block-buffered on a pipe until some later flush), and since round 6 a process group exists in every run,
+# N = 1 included.  So file descriptor 1 points at stderr for the whole run -- C stdio and Python's sys.stdout alike -- and is
+# handed back for the one line that belongs there.
+_STDOUT = {"fd": None}
+
+
+def hold_stdout() -> None:
+    if _STDOUT["fd"] is None:
+        sys.stdout.flush()
+        _STDOUT["fd"] = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(line: str) -> None:
+    """Drain whatever C stdio still buffers (into stderr), restore stdout, print the line."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    if _STDOUT["fd"] is not None:
+        os.dup2(_STDOUT["fd"], 1)
+        os.close(_STDOUT["fd"])
+        _STDOUT["fd"] = None
+    print(line, flush=True)

@@ -185,8 +185,8 @@ def run_variants(result, rank, world, dev):
         variants.setdefault("error", f"timed out after {VARIANT_DEADLINE_S} s (a rank failed or a collective hung)")
         _log("sharded variants timed out: emitting the primary line")
         if rank == 0:
-            sys.stdout.flush()
-            print(json.dumps(result), flush=True)
+            from benchmarks.common import emit_line
+            emit_line(json.dumps(result))
         os._exit(0)
     watchdog = threading.Timer(VARIANT_DEADLINE_S, bail_out)
     watchdog.daemon = True

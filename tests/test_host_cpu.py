@@ -391,3 +391,16 @@ def test_bench_self_launch_refuses_more_ranks_than_gpus_with_a_clear_message():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and ("WORLD_SIZE=3" in r.stderr or "needs an MI355X" in r.stderr), r.stderr[-2000:]
+
+
+def test_bench_stdout_carries_only_the_json_line():
+    """benchmarks.common.hold_stdout / emit_line: whatever C stdio (the collective backend's banner) or Python prints while
+    the run is in progress lands on stderr; stdout gets the one JSON line."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys\nsys.path.insert(0, %r)\nfrom benchmarks import common as C\nC.hold_stdout()\n"
+            "ctypes.CDLL(None).printf(b'RCCL version : banner through C stdio\\n')\nprint('python noise')\n"
+            "C.emit_line('{\"ok\": 1}')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout == '{"ok": 1}\n', (r.stdout, r.stderr[-500:])
+    assert "banner through C stdio" in r.stderr and "python noise" in r.stderr
