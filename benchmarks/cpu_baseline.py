@@ -12,6 +12,18 @@ from benchmarks.common import PARITY_TOL
 CPU_FORWARD_BUDGET_S = 6.0    # per thread count: a warm-up slower than this is reported as is (no timed repeats)
 
 
+def cpu_model() -> str:
+    """CPU model string of the host the baseline ran on ("CPU model string")."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def _timed_forwards(fn, n_timed=3, budget=None):
     """1 warm-up + n timed forwards, median (SURVEY.md 8d / BASELINE.md 3).  Time-boxed: when the warm-up alone
     exceeds the budget (e.g. 256 threads on a cgroup-limited host: 105 s per forward) its time is the figure and
@@ -77,7 +89,7 @@ def cpu_baseline_cfg2(st, gpu_out):
     parity = {"max_abs": float((gpu_out.cpu() - want).abs().max()), "tol": PARITY_TOL, "n": st["N"],
               "against": "oracle/mp_oracle.py at full size (N=200k, E=1.1M)"}
     return {"value": round(st["E"] / sweep[best], 1), "unit": "edges/s", "cores": int(best), "kind": "port",
-            "host_cpus": os.cpu_count(), "seconds_by_threads": sweep,
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model(), "seconds_by_threads": sweep,
             "value_1_thread": round(st["E"] / sweep["1"], 1),
             "sample": "kind \"port\": the torch-CPU fp32 RESTATEMENT of the reference layer (oracle/mp_oracle.py), not the "
                       "reference's own module (no /root/reference on the GPU box; the two time within 5-25 % of each other in "
@@ -114,7 +126,7 @@ def cpu_baseline_cfg3(st, gpu_out):
               "edges_counted_match": bool(n_edges == st["E"]),
               "against": f"oracle/mp_oracle.py at full size (N={st['N']}, E={st['E']}, 8 GGNN layers)"}
     return {"value": round(st["E"] / (full / layers), 1), "unit": "edges/s", "cores": int(best),
-            "kind": "port", "host_cpus": os.cpu_count(), "seconds_by_threads_8_graph_sample": sweep,
+            "kind": "port", "host_cpus": os.cpu_count(), "cpu_model": cpu_model(), "seconds_by_threads_8_graph_sample": sweep,
             "full_batch_seconds": round(full, 3), "full_batch_timed_forwards": n_timed,
             "full_batch_seconds_by_threads": full_by_threads,
             "sample_value": round(e_small / (sweep[best] / layers), 1),
