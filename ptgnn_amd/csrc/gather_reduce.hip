@@ -399,6 +399,13 @@ struct RowOp {
 #endif
 template <int CH, bool HAS_DST, bool HAS_ARG, bool MASKED>
 constexpr bool hub_fuses() { return PTGNN_HUB_FUSED_BLOCKS > 0 && CH == 1 && !HAS_DST && !HAS_ARG && !MASKED; }
+// The destination-term variants (MLP-MP table form) can walk the hub list inside the main launch too, but pay for it with
+// registers: measured in round 6 (profiles/r06_notes.md 6), BASELINE config 2 (1.1 M edges, 144 us launch) gets 1.5 % SLOWER,
+// the 80-150 k-edge minibatches of config 1 (19 us launches, five per forward) 5.8 % faster.  So it is a second instantiation,
+// taken below this many edges.
+constexpr int64_t kFuseDstMaxEdges = (int64_t)1 << 19;
+template <int CH, bool HAS_DST, bool HAS_ARG, bool MASKED>
+constexpr bool hub_fuses_small() { return PTGNN_HUB_FUSED_BLOCKS > 0 && CH == 1 && HAS_DST && !HAS_ARG && !MASKED; }
 
 template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED, bool FUSED = false>
 __device__ __forceinline__ void hub_chunks_body(const Args &a, int first, int stride) {
@@ -494,14 +501,15 @@ __global__ __launch_bounds__(256) void k_hub_chunks(Args a) {
 // ------------------------------------------------------------------------------------------------
 // main kernel: one row per lane group
 // ------------------------------------------------------------------------------------------------
-template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED, bool DST1 = false>
+template <int VEC, int LPR, int CH, int REDUCE, bool HAS_DST, bool HAS_ARG, bool MASKED, bool DST1 = false,
+          bool HUBF = hub_fuses<CH, HAS_DST, HAS_ARG, MASKED>()>
 __global__ __launch_bounds__(256) void k_gather_reduce(Args a) {
   constexpr int ROWS_PER_BLOCK = 256 / LPR;
   // the first `hub_blocks` workgroups (a multiple of 8: the XCD mapping of the row tiles is unchanged) walk the plan's
   // hub list instead of row tiles -- on a minibatch-sized plan the list is almost always empty and they leave at once,
   // where a hub launch of its own behind this one cost ~4.6 us of dependent launch latency per aggregation
   // (only the variants whose register budget -- 8 / 7 waves per SIMD -- the hub body fits: plain rows, one column chunk)
-  if constexpr (hub_fuses<CH, HAS_DST, HAS_ARG, MASKED>()) {
+  if constexpr (HUBF) {
     if ((int)blockIdx.x < a.hub_blocks) {
       hub_chunks_body<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED, true>(a, (int)blockIdx.x, a.hub_blocks);
       return;
@@ -780,15 +788,27 @@ int launch_all(const Args &a0, int col_blocks, hipStream_t stream) {
     }
   }
   constexpr bool kFuseHub = hub_fuses<CH, HAS_DST, HAS_ARG, MASKED>();
+  constexpr bool kFuseSmall = hub_fuses_small<CH, HAS_DST, HAS_ARG, MASKED>();
   // minibatch-sized plans only (below the side streams' threshold): there the list is almost always empty.  A large plan that
   // stays on one stream (side streams switched off or exhausted) keeps the dedicated hub launch with its full grid.
-  if (kFuseHub && !side && a.hub_threshold > 0 && a.num_edges < side_min_edges) {
+  const bool fuse_small = kFuseSmall && a.num_edges < kFuseDstMaxEdges;
+  if ((kFuseHub || fuse_small) && !side && a.hub_threshold > 0 && a.num_edges < side_min_edges) {
     const int64_t chunks = (a.num_edges + kHubChunk - 1) / kHubChunk;
     a.hub_blocks = (int)(((chunks < PTGNN_HUB_FUSED_BLOCKS ? chunks : PTGNN_HUB_FUSED_BLOCKS) + 7) / 8 * 8);
   }
   dim3 grid((unsigned)(xcd_padded_blocks(a.num_tiles) + a.hub_blocks), (unsigned)col_blocks);
   // one edge type (type_bits == 0): the destination term of a row is one row -> the DST1 variant loads it once
   constexpr bool kDst1Variant = VEC == 4 && HAS_DST && !MASKED;
+  if constexpr (kFuseSmall) {
+    if (a.hub_blocks > 0) {      // the small-plan instantiation that walks the hub list itself
+      if (kDst1Variant && a.type_bits == 0)
+        k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED, kDst1Variant, true><<<grid, 256, 0, stream>>>(a);
+      else
+        k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED, false, true><<<grid, 256, 0, stream>>>(a);
+      PTGNN_LAUNCH_CHECK();
+      return PTGNN_AMD_OK;
+    }
+  }
   if (kDst1Variant && a.type_bits == 0)
     k_gather_reduce<VEC, LPR, CH, REDUCE, HAS_DST, HAS_ARG, MASKED, kDst1Variant><<<grid, 256, 0, stream>>>(a);
   else
