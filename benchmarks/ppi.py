@@ -84,13 +84,15 @@ def config1(dev, parity=True, passes=5):
                            reference_node_graph_idx=mb["reference_node_graph_idx"], num_graphs=mb["num_graphs"])
         for i in range(len(mbs)):
             forward(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        blocks = []      # median over the passes (each a sweep over all minibatches)
         for _ in range(passes):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             for i in range(len(mbs)):
                 forward(i)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / (passes * len(mbs))
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / len(mbs))
+        dt = sorted(blocks)[len(blocks) // 2]
         before = ops.launch_counts()
         timer = ops.KernelTimer()
         ops.set_kernel_timer(timer)
