@@ -29,6 +29,22 @@ def shapes(names, dev):
             out["cfg3"] = (cadj, n, 0)
         if "cfg3_bwd" in names:
             out["cfg3_bwd"] = (cadj, n * len(cadj), 2)
+    if "cfg1" in names:       # one PPI-cap minibatch: ~4.4 k nodes, ~120 k edges after reverse + self augmentation, T = 3
+        mb = workloads.batched_graphs(2, 2200, 1, 14.0, seed=7)
+        n = mb["num_nodes"]
+        adj = list(mb["adjacency_lists"])
+        adj = adj + [(d, s) for s, d in adj]
+        ar = torch.arange(n, dtype=torch.int64)
+        adj.append((ar, ar))
+        out["cfg1"] = ([(s.to(dev).contiguous(), d.to(dev).contiguous()) for s, d in adj], n, 0)
+    if "cfg4" in names:
+        mb = workloads.batched_graphs(40, 2000, 10, 2.4, seed=21)
+        n = mb["num_nodes"]
+        adj = list(mb["adjacency_lists"])
+        adj = adj + [(d, s) for s, d in adj]
+        ar = torch.arange(n, dtype=torch.int64)
+        adj.append((ar, ar))
+        out["cfg4"] = ([(s.to(dev).contiguous(), d.to(dev).contiguous()) for s, d in adj], n, 0)
     if "cfg5" in names:
         adj = workloads.power_law_graph(1_250_000, 12_500_000, alpha=0.8, seed=1234)
         out["cfg5"] = ([(s.to(dev), d.to(dev)) for s, d in adj], 1_250_000, 0)
@@ -38,7 +54,7 @@ def shapes(names, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
-    ap.add_argument("--shapes", default="cfg2,cfg3,cfg3_bwd,cfg5")
+    ap.add_argument("--shapes", default="cfg1,cfg4,cfg2,cfg3,cfg3_bwd,cfg5")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     res = {"lib": os.environ.get("PTGNN_AMD_LIB", "default")}
